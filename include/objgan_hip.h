@@ -1,0 +1,127 @@
+/*
+ * objgan_hip.h -- C ABI of libobjgan_hip.so: the MI355X (gfx950) native kernels behind the
+ * Obj-GAN image_generation G+D training step.
+ *
+ * This is the drop-in boundary of the hot path.  The reference's only native boundary is the
+ * cffi module `models/roi_align/_ext/roi_align` (reference
+ * image_generation/models/roi_align/src/roi_align.h:1-5, src/roi_align_cuda.h:1-5):
+ *
+ *     int roi_align_forward_cuda (int aligned_height, int aligned_width, float spatial_scale,
+ *                                 THCudaTensor* features, THCudaTensor* rois, THCudaTensor* output);
+ *     int roi_align_backward_cuda(int aligned_height, int aligned_width, float spatial_scale,
+ *                                 THCudaTensor* top_grad, THCudaTensor* rois, THCudaTensor* bottom_grad);
+ *
+ * objgan_roi_align_forward / _backward replace exactly those two (same argument meaning; the
+ * TH tensor handles become raw device pointers + sizes, the implicit THC "current stream"
+ * becomes an explicit hipStream_t).  Everything else the reference step obtains from
+ * cuDNN / cuBLAS / THC through PyTorch (conv, norms, attention bmm+softmax, masked max,
+ * bilinear resize, Adam) is exported here with the same conventions so that the host side
+ * (Python, ctypes) stays a thin binding.
+ *
+ * Conventions (identical to the reference FFI, roi_align_cuda.c:7-40):
+ *   - the library never allocates, frees or retains memory; the caller owns every buffer,
+ *     including scratch / workspace buffers named in the signatures;
+ *   - all tensors are contiguous fp32, NCHW, device memory;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant,
+ *     and keeps no global state;
+ *   - return value: 1 = launched, 0 = argument error (the reference returns 0 when
+ *     rois.size(1) != 5), < 0 = -(hipError_t) of a failed launch (the reference calls exit(-1)).
+ */
+#ifndef OBJGAN_HIP_H
+#define OBJGAN_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- ROIAlign (reference models/roi_align/src/roi_align_kernel.cu:15-143) ------------------ */
+/* features [B, C, H, W], rois [num_rois, roi_cols = 5] = (batch_idx, x1, y1, x2, y2),
+ * output [num_rois, C, aligned_height, aligned_width].  Returns 0 if roi_cols != 5. */
+int objgan_roi_align_forward(const float* features, const float* rois, float* output,
+                             int num_rois, int roi_cols, int channels, int height, int width,
+                             int aligned_height, int aligned_width, float spatial_scale,
+                             void* stream);
+/* bottom_grad [batch_size, C, H, W] must be zero-filled by the caller (it is accumulated with
+ * atomics, exactly like the reference kernel). */
+int objgan_roi_align_backward(const float* top_grad, const float* rois, float* bottom_grad,
+                              int batch_size, int num_rois, int roi_cols, int channels,
+                              int height, int width, int aligned_height, int aligned_width,
+                              float spatial_scale, void* stream);
+/* avg_pool2d(kernel_size=2, stride=1) tail of RoIAlignAvg (modules/roi_align.py:26-29). */
+int objgan_avgpool2s1_forward(const float* in, float* out, long planes, int ih, int iw, void* stream);
+int objgan_avgpool2s1_backward(const float* grad_out, float* grad_in, long planes, int ih, int iw,
+                               void* stream);
+
+/* ---- implicit-GEMM convolution on MFMA (reference model.py conv stacks, via cuDNN) ---------- */
+long objgan_conv_packed_floats(int M, int K);
+/* y[n,m,a*osh+ooh,b*osw+oow] = act(bias[m] + sum_{c,t} Wp[m][c*Tg+t] * x[n,c,a*s+dh[t],b*s+dw[t]])
+ * for (a,b) in PH x PW.  w: [Cout][Cin][Torig]; transpose=0 -> m=cout,c=cin; 1 -> m=cin,c=cout.
+ * src_tap[t]: which of the Torig taps GEMM tap t uses (-1 = zero).  Tg in {1,4,9,16}.
+ * upsample=1: taps address a nearest-x2 upsampled view of x; pad_mode 0 zeros, 1 reflect.
+ * act: 0 none, 1 LeakyReLU(0.2), 2 tanh, 3 sigmoid.  wt: scratch of
+ * objgan_conv_packed_floats(M, C*Tg) floats. */
+int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* y, float* wt,
+                      int N, int C, int H, int W, int upsample, int pad_mode,
+                      int Cout, int Cin, int Torig, int transpose,
+                      int Tg, const int* dh, const int* dw, const int* src_tap,
+                      int PH, int PW, int stride,
+                      int OHf, int OWf, int osh, int osw, int ooh, int oow,
+                      int act, void* stream);
+/* dw[co][ci][kh][kw] += sum dy * x (dw zero-filled / accumulated by the caller); ksize in {1,3,4} */
+int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
+                      int N, int Cin, int H, int W, int upsample, int pad_mode,
+                      int Cout, int OH, int OW, int ksize, int stride, int pad, void* stream);
+
+/* ---- normalisation + GLU / LeakyReLU / residual (BatchNorm train mode, InstanceNorm) -------- */
+int objgan_norm_forward(const float* x, float* y, const float* residual,
+                        const float* gamma, const float* beta,
+                        float* running_mean, float* running_var,
+                        float* sums, float* mean, float* rstd,
+                        int N, int C, int HW, int per_channel, int mode,
+                        float eps, float momentum, void* stream);
+int objgan_norm_backward(const float* x, const float* dy, const float* mean, const float* rstd,
+                         const float* gamma, const float* beta, float* bsums,
+                         float* dx, float* dgamma, float* dbeta,
+                         int N, int C, int HW, int per_channel, int mode, void* stream);
+int objgan_act_backward(const float* dy, const float* y, float* dz, long total, int kind, void* stream);
+int objgan_channel_sum(const float* x, float* out, int N, int C, int HW, void* stream);
+
+/* ---- attention (reference GlobalAttention.py:32-181, miscc/utils.py:401-413) ---------------- */
+int objgan_attn_general_forward(const float* x, const float* src, const unsigned char* mask,
+                                float* wc, float* attn, int B, int idf, int Q, int L, void* stream);
+int objgan_attn_general_backward(const float* x, const float* src, const float* attn,
+                                 const float* dwc, const float* dattn, float* dx, float* dsrc,
+                                 int B, int idf, int Q, int L, void* stream);
+int objgan_attn_bu_forward(const float* tgt, const float* ctx1, const float* src,
+                           const unsigned char* mask, float* wc, float* attn,
+                           int B, int d2, int idf, int R, int L, int normalize, float eps,
+                           void* stream);
+int objgan_attn_bu_backward(const float* dwc, const float* attn, float* dsrc,
+                            int B, int idf, int R, int L, void* stream);
+int objgan_masked_max_forward(const float* f, const float* m, float* out, int B, int num, int R,
+                              int P, long m_stride_b, long m_stride_r, long m_stride_c, void* stream);
+int objgan_masked_max_backward(const float* f, const float* m, const float* dout, float* df,
+                               int B, int num, int R, int P, long m_stride_b, long m_stride_r,
+                               long m_stride_c, void* stream);
+int objgan_softmax_strided_forward(const float* x, float* y, long outer, int dim, long inner,
+                                   float scale, const int* lens, int nlens,
+                                   const unsigned char* rowvalid, void* stream);
+int objgan_softmax_strided_backward(const float* y, const float* dy, float* dx, long outer, int dim,
+                                    long inner, float scale, void* stream);
+
+/* ---- resize, gradient folds, optimiser ------------------------------------------------------ */
+int objgan_bilinear_forward(const float* x, float* y, long planes, int ih, int iw, int oh, int ow,
+                            void* stream);
+int objgan_bilinear_backward(const float* dy, float* dx, long planes, int ih, int iw, int oh, int ow,
+                             void* stream);
+int objgan_sum2x2(const float* dy, float* dx, long planes, int h, int w, void* stream);
+int objgan_reflect_fold(const float* dxp, float* dx, long planes, int h, int w, void* stream);
+int objgan_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
+                     float beta2, float eps, int step, void* stream);
+int objgan_ema_update(float* avg, const float* p, long n, float decay, float one_minus_decay,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OBJGAN_HIP_H */

@@ -1,0 +1,323 @@
+// Normalisation + gated/leaky activations, forward and backward, for gfx950.
+//
+// Covers, as fused HBM-bound passes, what the reference expresses as separate
+// nn.BatchNorm2d / nn.BatchNorm1d (train mode, batch statistics) / nn.InstanceNorm2d
+// (affine=False) modules followed by GLU / LeakyReLU(0.2) / a residual add:
+//   reference image_generation/model.py:19-27 (GLU), :43-49 (upBlock: conv -> BN -> GLU),
+//   :63-81 (HmapResBlock: conv -> IN -> GLU -> conv -> IN -> +x), :486-518 (fc -> BN1d -> GLU),
+//   :589-617 / :1119-1123 (conv -> IN -> LeakyReLU), :989-995, :1008-1012 (conv -> BN -> LeakyReLU).
+//
+// A "group" is the set of elements that share statistics: one (n, c) plane for
+// InstanceNorm, one channel c across the batch for BatchNorm.  Statistics are accumulated
+// as shifted sums  sum(x - K), sum((x - K)^2)  with K = first element of the group (kills the
+// cancellation of the naive E[x^2] - E[x]^2 form), wave-shuffle reduced, one atomic pair
+// per workgroup.  The apply pass normalises, applies gamma/beta, the activation and the
+// optional residual in one read + one write; GLU reads both gate halves and writes C/2
+// channels, so the 2C-channel normalised tensor never exists in HBM.
+#include "common.h"
+
+#define OG_NORM_NONE 0
+#define OG_NORM_LRELU 1
+#define OG_NORM_GLU 2
+
+struct NormGeom {
+    int N, C, HW;
+    int per_channel;   // 1 = BatchNorm (group = c), 0 = InstanceNorm (group = n*C + c)
+};
+
+__device__ __forceinline__ float og_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// ---- statistics ------------------------------------------------------------------------
+// grid = (G, S).  sums[g*2 + {0,1}] must be zero on entry.
+__global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict__ x,
+                                                         float* __restrict__ sums, NormGeom gm) {
+    __shared__ float red[16];
+    const int g = blockIdx.x;
+    const int planes = gm.per_channel ? gm.N : 1;
+    const size_t base = gm.per_channel ? (size_t)g * gm.HW : (size_t)g * gm.HW;
+    const size_t pstride = (size_t)gm.C * gm.HW;
+    const long total = (long)planes * gm.HW;
+    const float K = x[base];
+    const long chunk = (total + gridDim.y - 1) / gridDim.y;
+    const long e0 = (long)blockIdx.y * chunk;
+    const long e1 = min(total, e0 + chunk);
+    float s1 = 0.f, s2 = 0.f;
+    for (long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+        const long p = e / gm.HW;
+        const long i = e - p * gm.HW;
+        const float d = x[base + p * pstride + i] - K;
+        s1 += d;
+        s2 += d * d;
+    }
+    s1 = og_block_sum(s1, red);
+    s2 = og_block_sum(s2, red);
+    if (threadIdx.x == 0 && e0 < e1) {
+        atomicAdd(&sums[2 * g], s1);
+        atomicAdd(&sums[2 * g + 1], s2);
+    }
+}
+
+// mean/rstd per group; optional BatchNorm running-statistics update (momentum, unbiased var)
+__global__ __launch_bounds__(256) void norm_finalize_kernel(
+    const float* __restrict__ x, const float* __restrict__ sums, float* __restrict__ mean,
+    float* __restrict__ rstd, float* __restrict__ running_mean, float* __restrict__ running_var,
+    NormGeom gm, int G, float eps, float momentum) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const float cnt = gm.per_channel ? (float)gm.N * gm.HW : (float)gm.HW;
+    const float K = x[(size_t)g * gm.HW];
+    const float m1 = sums[2 * g] / cnt;
+    float var = sums[2 * g + 1] / cnt - m1 * m1;
+    var = fmaxf(var, 0.f);
+    const float mu = K + m1;
+    mean[g] = mu;
+    rstd[g] = 1.0f / sqrtf(var + eps);
+    if (running_mean) {
+        const float unbiased = cnt > 1.f ? var * cnt / (cnt - 1.f) : var;
+        running_mean[g] = (1.f - momentum) * running_mean[g] + momentum * mu;
+        running_var[g] = (1.f - momentum) * running_var[g] + momentum * unbiased;
+    }
+}
+
+// ---- forward apply ---------------------------------------------------------------------
+// out channels: C (NONE / LRELU) or C/2 (GLU).  residual (same shape as out) optional.
+__global__ __launch_bounds__(256) void norm_apply_kernel(
+    const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ residual, float* __restrict__ y, NormGeom gm, int mode) {
+    const int Co = mode == OG_NORM_GLU ? gm.C / 2 : gm.C;
+    const long total = (long)gm.N * Co * gm.HW;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long)gridDim.x * blockDim.x) {
+        const long plane = e / gm.HW;          // n*Co + c
+        const int i = (int)(e - plane * gm.HW);
+        const int n = (int)(plane / Co);
+        const int c = (int)(plane - (long)n * Co);
+        const int ga = gm.per_channel ? c : n * gm.C + c;
+        const size_t xa = ((size_t)n * gm.C + c) * gm.HW + i;
+        float za = (x[xa] - mean[ga]) * rstd[ga];
+        if (gamma) za = za * gamma[c] + beta[c];
+        float v;
+        if (mode == OG_NORM_GLU) {
+            const int cb = c + Co;
+            const int gb = gm.per_channel ? cb : n * gm.C + cb;
+            float zb = (x[xa + (size_t)Co * gm.HW] - mean[gb]) * rstd[gb];
+            if (gamma) zb = zb * gamma[cb] + beta[cb];
+            v = za * og_sigmoid(zb);
+        } else if (mode == OG_NORM_LRELU) {
+            v = za > 0.f ? za : 0.2f * za;
+        } else {
+            v = za;
+        }
+        if (residual) v += residual[e];
+        y[e] = v;
+    }
+}
+
+// ---- backward --------------------------------------------------------------------------
+// dz (gradient w.r.t. the normalised+affine value z) recomputed from x, dy and the mode.
+__device__ __forceinline__ float norm_dz(const float* __restrict__ x, const float* __restrict__ dy,
+                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         const NormGeom& gm, int mode, int n, int c, int i,
+                                         float& xhat_out) {
+    const int g = gm.per_channel ? c : n * gm.C + c;
+    const size_t xa = ((size_t)n * gm.C + c) * gm.HW + i;
+    const float xhat = (x[xa] - mean[g]) * rstd[g];
+    xhat_out = xhat;
+    if (mode == OG_NORM_NONE) return dy[xa];
+    float z = xhat;
+    if (gamma) z = z * gamma[c] + beta[c];
+    if (mode == OG_NORM_LRELU) return dy[xa] * (z > 0.f ? 1.f : 0.2f);
+    // GLU: channels [0, C/2) are the value half, [C/2, C) the gate half
+    const int Ch = gm.C / 2;
+    const bool is_gate = c >= Ch;
+    const int co = is_gate ? c - Ch : c;
+    const int cp = is_gate ? c - Ch : c + Ch;     // partner channel
+    const int gp = gm.per_channel ? cp : n * gm.C + cp;
+    const size_t xp = ((size_t)n * gm.C + cp) * gm.HW + i;
+    float zp = (x[xp] - mean[gp]) * rstd[gp];
+    if (gamma) zp = zp * gamma[cp] + beta[cp];
+    const float d = dy[((size_t)n * Ch + co) * gm.HW + i];
+    if (!is_gate) return d * og_sigmoid(zp);
+    const float sg = og_sigmoid(z);
+    return d * zp * sg * (1.f - sg);
+}
+
+// grid = (G, S): bsums[g*2] += sum dz, bsums[g*2+1] += sum dz*xhat   (zero on entry)
+__global__ __launch_bounds__(256) void norm_bwd_stats_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ bsums, NormGeom gm, int mode) {
+    __shared__ float red[16];
+    const int g = blockIdx.x;
+    const int planes = gm.per_channel ? gm.N : 1;
+    const long total = (long)planes * gm.HW;
+    const long chunk = (total + gridDim.y - 1) / gridDim.y;
+    const long e0 = (long)blockIdx.y * chunk;
+    const long e1 = min(total, e0 + chunk);
+    float s1 = 0.f, s2 = 0.f;
+    for (long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+        const int p = (int)(e / gm.HW);
+        const int i = (int)(e - (long)p * gm.HW);
+        const int n = gm.per_channel ? p : g / gm.C;
+        const int c = gm.per_channel ? g : g - n * gm.C;
+        float xhat;
+        const float dz = norm_dz(x, dy, mean, rstd, gamma, beta, gm, mode, n, c, i, xhat);
+        s1 += dz;
+        s2 += dz * xhat;
+    }
+    s1 = og_block_sum(s1, red);
+    s2 = og_block_sum(s2, red);
+    if (threadIdx.x == 0 && e0 < e1) {
+        atomicAdd(&bsums[2 * g], s1);
+        atomicAdd(&bsums[2 * g + 1], s2);
+    }
+}
+
+// dx = gamma * rstd * (dz - mean(dz) - xhat * mean(dz * xhat))
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ bsums, float* __restrict__ dx, NormGeom gm, int mode) {
+    const long total = (long)gm.N * gm.C * gm.HW;
+    const float inv_cnt = 1.0f / (gm.per_channel ? (float)gm.N * gm.HW : (float)gm.HW);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long)gridDim.x * blockDim.x) {
+        const long plane = e / gm.HW;
+        const int i = (int)(e - plane * gm.HW);
+        const int n = (int)(plane / gm.C);
+        const int c = (int)(plane - (long)n * gm.C);
+        const int g = gm.per_channel ? c : n * gm.C + c;
+        float xhat;
+        const float dz = norm_dz(x, dy, mean, rstd, gamma, beta, gm, mode, n, c, i, xhat);
+        const float gw = gamma ? gamma[c] : 1.f;
+        dx[e] = gw * rstd[g] * (dz - bsums[2 * g] * inv_cnt - xhat * bsums[2 * g + 1] * inv_cnt);
+    }
+}
+
+// dgamma[c] = bsums[2c+1], dbeta[c] = bsums[2c]   (BatchNorm only)
+__global__ void norm_affine_grad_kernel(const float* __restrict__ bsums, float* __restrict__ dgamma,
+                                        float* __restrict__ dbeta, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) { dbeta[c] = bsums[2 * c]; dgamma[c] = bsums[2 * c + 1]; }
+}
+
+// ---- plain activations on conv outputs (forward is fused in the conv epilogue) ----------
+// kind 1: LeakyReLU(0.2) from the OUTPUT y (sign(y) == sign(z));  2: tanh;  3: sigmoid
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy,
+                                                      const float* __restrict__ y,
+                                                      float* __restrict__ dz, long total, int kind) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long)gridDim.x * blockDim.x) {
+        const float o = y[e], d = dy[e];
+        float r;
+        if (kind == 1) r = d * (o > 0.f ? 1.f : 0.2f);
+        else if (kind == 2) r = d * (1.f - o * o);
+        else r = d * o * (1.f - o);
+        dz[e] = r;
+    }
+}
+
+// per-channel sum over (N, HW): out[c] = sum_n sum_i x[n, c, i]   (conv bias gradient)
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x,
+                                                          float* __restrict__ out, int N, int C, int HW) {
+    __shared__ float red[16];
+    const int c = blockIdx.x;
+    const long total = (long)N * HW;
+    const long chunk = (total + gridDim.y - 1) / gridDim.y;
+    const long e0 = (long)blockIdx.y * chunk;
+    const long e1 = min(total, e0 + chunk);
+    float s = 0.f;
+    for (long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+        const long n = e / HW;
+        const long i = e - n * HW;
+        s += x[((size_t)n * C + c) * HW + i];
+    }
+    s = og_block_sum(s, red);
+    if (threadIdx.x == 0 && e0 < e1) atomicAdd(&out[c], s);
+}
+
+static inline int norm_splits(int G, long per_group) {
+    // aim for >= 4 workgroups per CU overall, >= 1024 elements per workgroup
+    long want = (256L * 4 + G - 1) / G;
+    long maxs = (per_group + 1023) / 1024;
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    if (want > 1024) want = 1024;
+    return (int)want;
+}
+
+extern "C" {
+
+// Forward: statistics + apply.  Workspaces: sums [2G] (zeroed here), mean [G], rstd [G].
+// per_channel = 1 BatchNorm (G = C), 0 InstanceNorm (G = N*C).  gamma/beta/running_* may be
+// null.  mode: 0 none, 1 LeakyReLU(0.2), 2 GLU (y has C/2 channels).  residual may be null.
+int objgan_norm_forward(const float* x, float* y, const float* residual,
+                        const float* gamma, const float* beta,
+                        float* running_mean, float* running_var,
+                        float* sums, float* mean, float* rstd,
+                        int N, int C, int HW, int per_channel, int mode,
+                        float eps, float momentum, void* stream) {
+    if (mode == OG_NORM_GLU && (C & 1)) return OG_BAD_ARGS;
+    if (N <= 0 || C <= 0 || HW <= 0) return OG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    NormGeom gm{N, C, HW, per_channel};
+    const int G = per_channel ? C : N * C;
+    const long per_group = per_channel ? (long)N * HW : HW;
+    hipMemsetAsync(sums, 0, sizeof(float) * 2 * G, s);
+    dim3 grid(G, norm_splits(G, per_group));
+    hipLaunchKernelGGL(norm_stats_kernel, grid, dim3(256), 0, s, x, sums, gm);
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3(og_cdiv(G, 256)), dim3(256), 0, s, x, sums, mean,
+                       rstd, running_mean, running_var, gm, G, eps, momentum);
+    const long total = (long)N * (mode == OG_NORM_GLU ? C / 2 : C) * HW;
+    hipLaunchKernelGGL(norm_apply_kernel, dim3(og_stream_grid(total, 256)), dim3(256), 0, s, x, mean,
+                       rstd, gamma, beta, residual, y, gm, mode);
+    return og_launch_status();
+}
+
+// Backward.  dy has the shape of y (C/2 channels for GLU).  bsums [2G] workspace (zeroed
+// here).  dgamma/dbeta may be null.  (The residual gradient is dy itself.)
+int objgan_norm_backward(const float* x, const float* dy, const float* mean, const float* rstd,
+                         const float* gamma, const float* beta, float* bsums,
+                         float* dx, float* dgamma, float* dbeta,
+                         int N, int C, int HW, int per_channel, int mode, void* stream) {
+    if (mode == OG_NORM_GLU && (C & 1)) return OG_BAD_ARGS;
+    if (N <= 0 || C <= 0 || HW <= 0) return OG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    NormGeom gm{N, C, HW, per_channel};
+    const int G = per_channel ? C : N * C;
+    const long per_group = per_channel ? (long)N * HW : HW;
+    hipMemsetAsync(bsums, 0, sizeof(float) * 2 * G, s);
+    dim3 grid(G, norm_splits(G, per_group));
+    hipLaunchKernelGGL(norm_bwd_stats_kernel, grid, dim3(256), 0, s, x, dy, mean, rstd, gamma, beta,
+                       bsums, gm, mode);
+    const long total = (long)N * C * HW;
+    hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(og_stream_grid(total, 256)), dim3(256), 0, s, x,
+                       dy, mean, rstd, gamma, beta, bsums, dx, gm, mode);
+    if (dgamma && per_channel)
+        hipLaunchKernelGGL(norm_affine_grad_kernel, dim3(og_cdiv(C, 256)), dim3(256), 0, s, bsums,
+                           dgamma, dbeta, C);
+    return og_launch_status();
+}
+
+int objgan_act_backward(const float* dy, const float* y, float* dz, long total, int kind,
+                        void* stream) {
+    if (kind < 1 || kind > 3) return OG_BAD_ARGS;
+    if (total <= 0) return OG_OK;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(og_stream_grid(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, dy, y, dz, total, kind);
+    return og_launch_status();
+}
+
+// out [C] is zeroed here, then out[c] = sum over n, i of x[n, c, i]
+int objgan_channel_sum(const float* x, float* out, int N, int C, int HW, void* stream) {
+    if (N <= 0 || C <= 0 || HW <= 0) return OG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipMemsetAsync(out, 0, sizeof(float) * C, s);
+    dim3 grid(C, norm_splits(C, (long)N * HW));
+    hipLaunchKernelGGL(channel_sum_kernel, grid, dim3(256), 0, s, x, out, N, C, HW);
+    return og_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,145 @@
+"""Hot-path helpers of the image generator (the subset of reference
+image_generation/miscc/utils.py that the G+D training step calls: :309-329, :365-413,
+:445-522).  Visualisation and IS/FID utilities of the reference file are outside the hot-path
+scope and are not provided.
+"""
+import random
+from copy import deepcopy
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from miscc.config import cfg
+from objgan_hip import ops
+
+
+# ---- ROI blob helpers (host/numpy API of the reference, kept for callers that use it) ----------
+def _project_im_rois(im_rois, scales):
+    """R x 4 boxes -> (scaled boxes, batch index column); the batch index of row r is
+    r // BOXES_NUM (reference utils.py:365-385)."""
+    im_rois = im_rois.astype(float, copy=False)
+    per_img = cfg.ROI.BOXES_NUM
+    levels = np.repeat(np.arange(im_rois.shape[0] // per_img).astype(int), per_img).reshape(-1, 1)
+    return im_rois * scales[levels], levels
+
+
+def _get_rois_blob(im_rois, im_scale_factors):
+    """R x 4 boxes -> R x 5 float32 rows [batch_idx, x1, y1, x2, y2] (reference utils.py:387-399)."""
+    rois, levels = _project_im_rois(im_rois, im_scale_factors)
+    return np.hstack((levels, rois)).astype(np.float32, copy=False)
+
+
+# ---- masked max over box slots -------------------------------------------------------------------
+def pprocess_bt_attns(fmaps, ih, iw, bt_mask):
+    """out[b, c, p] = max_r fmaps[b, c, r] * bt_mask[b, r, (c,) p]  (reference utils.py:401-413).
+
+    fmaps  : batch x num x max_num_rois x 1
+    bt_mask: batch x max_num_rois x num x ih x iw (the reference's repeated form; an expanded
+             view costs nothing) or batch x max_num_rois x ih x iw.
+    One fused kernel: the batch x rois x num x ih x iw product is never materialised."""
+    return ops.masked_max(fmaps, bt_mask, ih, iw)
+
+
+# ---- class-permuted layout maps ("wrong shape" negatives) ------------------------------------------
+def permute_seg(seg_conditions, rois, num_rois):
+    """Shuffle the class channels present in each sample's layout map (reference utils.py:445-462).
+    Uses python's `random` exactly like the reference, so a seeded run draws the same permutations.
+    Returns (new_seg_conditions, valid_mask) with valid_mask the list of changed sample indices."""
+    new_seg = seg_conditions.clone()
+    rois_np = rois.detach().cpu().numpy() if isinstance(rois, torch.Tensor) else np.asarray(rois)
+    nr = num_rois.detach().cpu().numpy().tolist() if isinstance(num_rois, torch.Tensor) else list(num_rois)
+    valid_mask = []
+    for b in range(seg_conditions.size(0)):
+        n = int(nr[b])
+        if n == 0:
+            continue
+        present = [int(c) for c in np.unique(rois_np[b, :n, 4])]
+        shuffled = deepcopy(present)
+        random.shuffle(shuffled)
+        if present != shuffled:
+            valid_mask.append(b)
+            new_seg[b, present] = seg_conditions[b, shuffled]
+    return new_seg, valid_mask
+
+
+def feat_select(pooled_feat, raw_bt_c_codes, fm_rois, num_rois, is_large_scale=False):
+    """Keep the pooled ROI features of real boxes of the requested scale (reference
+    utils.py:465-499): drop boxes with w < 1.25 and h < 1.25; small-scale keeps max(w, h) < 16,
+    large-scale keeps >= 16.  Returns (features [K, C, h, w], classes [K] int64 (cpu),
+    bt_c_codes [K, idf]); empty lists when nothing survives."""
+    rois_np = fm_rois.detach().cpu().numpy()
+    nr = num_rois.detach().cpu().numpy().tolist() if isinstance(num_rois, torch.Tensor) else list(num_rois)
+    thr = cfg.ROI.ROI_SIZE_THRS
+    sel_b, sel_r, classes = [], [], []
+    for b in range(len(nr)):
+        keep = []
+        for r in range(int(nr[b])):
+            w, h = rois_np[b, r, 2], rois_np[b, r, 3]
+            if w < 1.25 and h < 1.25:
+                continue
+            big = max(w, h) >= thr
+            if big != bool(is_large_scale):
+                continue
+            keep.append(r)
+        if keep:
+            sel_b += [b] * len(keep)
+            sel_r += keep
+            classes.append(rois_np[b, keep, 4].astype(int))
+    if not sel_b:
+        return [], [], []
+    dev = pooled_feat.device
+    ib = torch.as_tensor(sel_b, dtype=torch.long, device=dev)
+    ir = torch.as_tensor(sel_r, dtype=torch.long, device=dev)
+    x_code_rois = pooled_feat[ib, ir]
+    # NB reference quirk (SURVEY.md trap 6): raw_bt_c_codes is indexed with the batch index of the
+    # tensors passed in, also when those are a `valid_mask` subset of the batch.
+    bt_c_codes = raw_bt_c_codes[ib.to(raw_bt_c_codes.device), ir.to(raw_bt_c_codes.device)]
+    classes = torch.from_numpy(np.concatenate(classes))
+    return x_code_rois, classes, bt_c_codes
+
+
+def form_clabels_feat(clabels_emb, rois, num_rois):
+    """Per-box class-label embeddings: batch x emb x max_num_roi x 1 (reference utils.py:502-522)."""
+    rois_np = rois.detach().cpu().numpy()
+    nr = num_rois.detach().cpu().numpy().tolist()
+    B = rois_np.shape[0]
+    max_num_roi = int(np.amax(nr))
+    feat = torch.zeros((B, max_num_roi, clabels_emb.size(1)), dtype=clabels_emb.dtype,
+                       device=clabels_emb.device)
+    for i in range(B):
+        n = int(nr[i])
+        if n == 0:
+            continue
+        cats = torch.as_tensor(rois_np[i, :n, 4].astype(np.int64), device=clabels_emb.device)
+        feat[i, :n] = clabels_emb[cats]
+    return feat.transpose(1, 2).unsqueeze(3)
+
+
+# ---- parameter utilities -------------------------------------------------------------------------
+def weights_init(m):
+    """orthogonal(gain 1) for conv / linear weights, N(1, 0.02) for BatchNorm weights, zero biases
+    (reference utils.py:309-319)."""
+    if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+        nn.init.orthogonal_(m.weight.data, 1.0)
+    elif isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+        m.weight.data.normal_(1.0, 0.02)
+        m.bias.data.fill_(0)
+    elif isinstance(m, nn.Linear):
+        nn.init.orthogonal_(m.weight.data, 1.0)
+        if m.bias is not None:
+            m.bias.data.fill_(0.0)
+
+
+def copy_G_params(model):
+    return deepcopy(list(p.data for p in model.parameters()))
+
+
+def load_params(model, new_param):
+    for p, new_p in zip(model.parameters(), new_param):
+        p.data.copy_(new_p)
+
+
+def mkdir_p(path):
+    import os
+    os.makedirs(path, exist_ok=True)

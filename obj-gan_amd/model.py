@@ -1,0 +1,601 @@
+"""Generator / discriminator networks of the Obj-GAN image generator on MI355X kernels.
+
+Drop-in for the training-path part of the reference module of the same name (reference
+image_generation/model.py:19-81, 452-795, 986-1312): same class names, constructor arguments,
+forward signatures, return tuples and state-dict keys (`h_net1_sent.fc.0.weight`,
+`h_net2_main.residual.0.block.1.weight`, `img_code.3.running_mean`, `COND_DNET.jointConv.0.weight`
+...), so reference checkpoints and the reference trainer/loss code load and run unchanged.
+
+How it differs from the reference: the nn.Conv2d / nn.BatchNorm / nn.Linear objects below are
+only PARAMETER HOLDERS (they keep the state-dict layout and the reference initialisation working);
+their own forward() is never used.  Each block's forward walks its holders and launches the fused
+gfx950 kernels of objgan_hip.ops instead:
+
+  upBlock        nearest-x2 gather fused into the MFMA conv  ->  BatchNorm(batch stats)+GLU pass
+  HmapResBlock   reflect-pad gather fused into the conv -> InstanceNorm+GLU -> conv -> InstanceNorm+residual
+  G_HMAP / shp_code   reflect conv(+bias) -> InstanceNorm+LeakyReLU -> stride-2 conv with LeakyReLU epilogue
+  D encoders     4x4/s2 conv with LeakyReLU epilogue, conv -> BatchNorm+LeakyReLU pass
+  attention      GlobalAttention.py (fused kernels), masked max without 5-D temporaries
+  object Ds      fused bilinear lift to 512^2, ROIAlign kernel, 4x4 conv with LeakyReLU epilogue
+
+The frozen encoders (RNN_ENCODER, CNN_ENCODER, INCEPTION_V3) are outside this hot-path scope
+(SURVEY.md section 8f); `encoders.py` holds plain-PyTorch stand-ins for them.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from miscc.config import cfg
+from miscc.utils import pprocess_bt_attns
+from GlobalAttention import GlobalAttentionGeneral as ATT_NET
+from GlobalAttention import GlobalBUAttentionGeneral as BT_ATT_NET
+from models.roi_align.modules.roi_align import RoIAlignAvg
+from objgan_hip import ops
+
+
+# ---------------------------------------------------------------------------------------------
+# small helpers shared by the blocks
+# ---------------------------------------------------------------------------------------------
+def _bn_act(x, bn, mode):
+    """BatchNorm (train: batch statistics + running-stat update) fused with GLU / LeakyReLU."""
+    if not bn.training:
+        raise NotImplementedError("eval-mode BatchNorm is not part of the training hot path")
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return ops.norm_act(x, bn.weight, bn.bias, None, bn.running_mean, bn.running_var,
+                        per_channel=True, mode=mode, eps=bn.eps, momentum=bn.momentum)
+
+
+def _in_act(x, inorm, mode, residual=None):
+    """InstanceNorm2d(affine=False) fused with GLU / LeakyReLU / residual add."""
+    return ops.norm_act(x, None, None, residual, None, None, per_channel=False, mode=mode,
+                        eps=inorm.eps)
+
+
+class GLU(nn.Module):
+    """x[:, :C/2] * sigmoid(x[:, C/2:]) -- only reached stand-alone after CA_NET's fc; everywhere
+    else it is fused into the normalisation pass."""
+
+    def __init__(self):
+        super(GLU, self).__init__()
+
+    def forward(self, x):
+        nc = x.size(1)
+        assert nc % 2 == 0, 'channels dont divide 2!'
+        nc = nc // 2
+        return x[:, :nc] * torch.sigmoid(x[:, nc:])
+
+
+def conv1x1(in_planes, out_planes, bias=False):
+    return nn.Conv2d(in_planes, out_planes, kernel_size=1, stride=1, padding=0, bias=bias)
+
+
+def conv3x3(in_planes, out_planes):
+    return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=1, padding=1, bias=False)
+
+
+class _UpBlock(nn.Sequential):
+    """[Upsample x2 nearest, conv3x3(in, 2*out), norm(2*out), GLU]: spatial size x2."""
+
+    def forward(self, x):
+        conv, norm = self[1], self[2]
+        y = ops.conv2d(x, conv.weight, None, 1, 1, "zeros", upsample=True)
+        if isinstance(norm, nn.InstanceNorm2d):
+            return _in_act(y, norm, "glu")
+        return _bn_act(y, norm, "glu")
+
+
+def upBlock(in_planes, out_planes, norm=nn.BatchNorm2d):
+    return _UpBlock(nn.Upsample(scale_factor=2, mode='nearest'),
+                    conv3x3(in_planes, out_planes * 2),
+                    norm(out_planes * 2),
+                    GLU())
+
+
+class _ActSeq(nn.Sequential):
+    """[Conv2d, (norm,) LeakyReLU(0.2)] -- conv with the activation in its epilogue, or
+    conv -> fused norm+LeakyReLU when a norm layer is present."""
+
+    def forward(self, x):
+        conv = self[0]
+        pad = conv.padding[0]
+        if len(self) == 2:
+            return ops.conv2d(x, conv.weight, conv.bias, conv.stride[0], pad, "zeros", act="lrelu")
+        y = ops.conv2d(x, conv.weight, conv.bias, conv.stride[0], pad, "zeros")
+        norm = self[1]
+        if isinstance(norm, nn.InstanceNorm2d):
+            return _in_act(y, norm, "lrelu")
+        return _bn_act(y, norm, "lrelu")
+
+
+def downBlock_G(in_planes, out_planes, kernel_size=3, stride=2, padding=1, norm=None):
+    layers = [nn.Conv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride,
+                        padding=padding, bias=False)]
+    if norm is not None:
+        layers.append(norm(out_planes))
+    layers.append(nn.LeakyReLU(0.2, inplace=True))
+    return _ActSeq(*layers)
+
+
+class _ReflStem(nn.Sequential):
+    """[ReflectionPad2d(1), Conv2d(k3, p0, bias), InstanceNorm2d, LeakyReLU(0.2)]."""
+
+    def forward(self, x):
+        conv, inorm = self[1], self[2]
+        y = ops.conv2d(x, conv.weight, conv.bias, 1, 1, "reflect")
+        return _in_act(y, inorm, "lrelu")
+
+
+def _shape_stem(ncf, ngf):
+    return _ReflStem(nn.ReflectionPad2d(1),
+                          nn.Conv2d(ncf, ngf, kernel_size=3, padding=0),
+                          nn.InstanceNorm2d(ngf),
+                          nn.LeakyReLU(0.2, inplace=True))
+
+
+class _ResBody(nn.Sequential):
+    """[pad, conv c->2c, IN, GLU, pad, conv c->c, IN] of HmapResBlock; forward(x) returns the
+    block output INCLUDING the residual (fused into the last normalisation pass)."""
+
+    def forward(self, x):
+        y = ops.conv2d(x, self[1].weight, None, 1, 1, "reflect")
+        y = _in_act(y, self[2], "glu")
+        y = ops.conv2d(y, self[5].weight, None, 1, 1, "reflect")
+        return _in_act(y, self[6], None, residual=x)
+
+
+class HmapResBlock(nn.Module):
+    def __init__(self, channel_num):
+        super(HmapResBlock, self).__init__()
+        self.block = _ResBody(
+            nn.ReflectionPad2d(1),
+            nn.Conv2d(channel_num, channel_num * 2, kernel_size=3, stride=1, padding=0, bias=False),
+            nn.InstanceNorm2d(channel_num * 2),
+            GLU(),
+            nn.ReflectionPad2d(1),
+            nn.Conv2d(channel_num, channel_num, kernel_size=3, stride=1, padding=0, bias=False),
+            nn.InstanceNorm2d(channel_num))
+
+    def forward(self, x):
+        return self.block(x)
+
+
+# ---------------------------------------------------------------------------------------------
+# generator
+# ---------------------------------------------------------------------------------------------
+class CA_NET(nn.Module):
+    """Conditioning augmentation (reference model.py:455-483).  `fixed_eps` (optional attribute)
+    injects the reparametrisation noise for parity tests; otherwise it is drawn on the device."""
+
+    def __init__(self):
+        super(CA_NET, self).__init__()
+        self.t_dim = cfg.TEXT.EMBEDDING_DIM
+        self.c_dim = cfg.GAN.CONDITION_DIM
+        self.fc = nn.Linear(self.t_dim, self.c_dim * 4, bias=True)
+        self.relu = GLU()
+        self.fixed_eps = None
+
+    def encode(self, text_embedding):
+        x = self.relu(ops.linear(text_embedding, self.fc.weight, self.fc.bias))
+        return x[:, :self.c_dim], x[:, self.c_dim:]
+
+    def reparametrize(self, mu, logvar):
+        std = (logvar * 0.5).exp()
+        eps = self.fixed_eps if self.fixed_eps is not None else torch.randn_like(std)
+        return eps * std + mu
+
+    def forward(self, text_embedding):
+        mu, logvar = self.encode(text_embedding)
+        return self.reparametrize(mu, logvar), mu, logvar
+
+
+class _FcGlu(nn.Sequential):
+    """[Linear(no bias), BatchNorm1d, GLU]."""
+
+    def forward(self, x):
+        y = ops.linear(x, self[0].weight, None)
+        y = _bn_act(y.reshape(y.shape[0], y.shape[1], 1, 1), self[1], "glu")
+        return y.reshape(y.shape[0], y.shape[1])
+
+
+class INIT_STAGE_G(nn.Module):
+    def __init__(self, ngf, ncf):
+        super(INIT_STAGE_G, self).__init__()
+        self.gf_dim = ngf
+        self.in_dim = cfg.GAN.Z_DIM + ncf
+        self.define_module()
+
+    def define_module(self):
+        nz, ngf = self.in_dim, self.gf_dim
+        self.fc = _FcGlu(nn.Linear(nz, ngf * 8 * 8 * 2, bias=False),
+                           nn.BatchNorm1d(ngf * 8 * 8 * 2),
+                           GLU())
+        self.upsample1 = upBlock(ngf, ngf // 2)
+        self.upsample2 = upBlock(ngf // 2, ngf // 4)
+
+    def forward(self, z_code, c_code):
+        out = self.fc(torch.cat((c_code, z_code), 1))
+        out = out.view(-1, self.gf_dim, 8, 8)
+        return self.upsample2(self.upsample1(out))
+
+
+def _max_rois(num_rois):
+    if isinstance(num_rois, torch.Tensor):
+        return int(num_rois.max().item()) if num_rois.numel() else 0
+    return int(np.amax(num_rois)) if len(num_rois) else 0
+
+
+class _BottomUpMixin(object):
+    """Object ("bottom-up") branch shared by the stage bodies: label/word attention over the
+    box slots, then the box-mask-gated max that paints slot vectors onto the feature grid."""
+
+    def _bottom_up(self, word_embs, glove_word_embs, slabels_feat, mask, bt_mask, max_num_roi,
+                   ih, iw, want_att):
+        slabels_feat = slabels_feat[:, :, :max_num_roi]
+        self.bt_att.applyMask(mask)
+        raw_bt_c_code, raw_bt_att = self.bt_att(slabels_feat, glove_word_embs, word_embs)
+        bt_mask = bt_mask[:, :max_num_roi]
+        bt_c_code = ops.masked_max(raw_bt_c_code, bt_mask, ih, iw)
+        bt_slabels_code = ops.masked_max(slabels_feat, bt_mask, ih, iw)
+        bt_att = ops.masked_max(raw_bt_att, bt_mask, ih, iw) if want_att else None
+        return raw_bt_c_code, bt_c_code, bt_att, bt_slabels_code
+
+
+class INIT_STAGE_G_MAIN(nn.Module, _BottomUpMixin):
+    def __init__(self, ngf, nef, nef2):
+        super(INIT_STAGE_G_MAIN, self).__init__()
+        self.gf_dim = ngf
+        self.ef_dim = nef
+        self.ef_dim2 = nef2
+        self.define_module()
+
+    def _make_layer(self, block, channel_num):
+        return nn.Sequential(*[block(channel_num) for _ in range(cfg.GAN.GLB_R_NUM)])
+
+    def define_module(self):
+        ngf, nef, nef2 = self.gf_dim, self.ef_dim, self.ef_dim2
+        self.bt_att = BT_ATT_NET(ngf, nef)
+        self.residual = self._make_layer(HmapResBlock, ngf * 3 + nef2)
+        self.upsample = upBlock(ngf * 3 + nef2, ngf)
+
+    def forward(self, h_code_hmap, h_code1_sent, c_code, word_embs, glove_word_embs, slabels_feat,
+                mask, rois, num_rois, bt_mask, glb_max_num_roi, max_num_roi=None):
+        ih, iw = h_code_hmap.size(2), h_code_hmap.size(3)
+        if max_num_roi is None:
+            max_num_roi = _max_rois(num_rois)
+        if max_num_roi > 0:
+            _, bt_c_code, _, bt_slabels_code = self._bottom_up(
+                word_embs, glove_word_embs, slabels_feat, mask, bt_mask, max_num_roi, ih, iw, False)
+        else:
+            # the reference raises here (`att` undefined, model.py:572); same contract
+            raise RuntimeError("INIT_STAGE_G_MAIN needs at least one box in the batch")
+        out_code = torch.cat((h_code_hmap, h_code1_sent, bt_c_code, bt_slabels_code), 1)
+        return self.upsample(self.residual(out_code))
+
+
+class G_HMAP(nn.Module):
+    """Layout-map encoder (reference model.py:589-617): B x ncf x S x S -> B x 2ngf x S/2 x S/2."""
+
+    def __init__(self, ngf, ncf):
+        super(G_HMAP, self).__init__()
+        self.gf_dim = ngf
+        self.in_dim = ncf
+        self.define_module()
+
+    def define_module(self):
+        ncf, ngf = self.in_dim, self.gf_dim
+        self.conv3x3 = _shape_stem(ncf, ngf)
+        self.downsample1 = downBlock_G(ngf, ngf * 2)
+
+    def forward(self, hmap):
+        return self.downsample1(self.conv3x3(hmap))
+
+
+class NEXT_STAGE_G_MAIN(nn.Module, _BottomUpMixin):
+    def __init__(self, ngf, nef, nef2):
+        super(NEXT_STAGE_G_MAIN, self).__init__()
+        self.gf_dim = ngf
+        self.ef_dim = nef
+        self.ef_dim2 = nef2
+        self.define_module()
+
+    def _make_layer(self, block, channel_num):
+        return nn.Sequential(*[block(channel_num) for _ in range(cfg.GAN.LOCAL_R_NUM)])
+
+    def define_module(self):
+        ngf, nef, nef2 = self.gf_dim, self.ef_dim, self.ef_dim2
+        self.att = ATT_NET(ngf, nef)
+        self.bt_att = BT_ATT_NET(ngf, nef)
+        self.residual = self._make_layer(HmapResBlock, ngf * 3 + nef2)
+        self.upsample = upBlock(ngf * 3 + nef2, ngf)
+
+    def forward(self, h_code, h_code_hmap, c_code, word_embs, glove_word_embs, slabels_feat, mask,
+                rois, num_rois, bt_mask, glb_max_num_roi, max_num_roi=None):
+        idf, ih, iw = h_code.size(1), h_code.size(2), h_code.size(3)
+        self.att.applyMask(mask)
+        c_code, att = self.att(h_code, word_embs)
+        if max_num_roi is None:
+            max_num_roi = _max_rois(num_rois)
+        B = c_code.size(0)
+        raw_bt_c_code = torch.zeros((B, idf, glb_max_num_roi, 1), dtype=c_code.dtype,
+                                    device=c_code.device)
+        if max_num_roi > 0:
+            raw, bt_c_code, bt_att, bt_slabels_code = self._bottom_up(
+                word_embs, glove_word_embs, slabels_feat, mask, bt_mask, max_num_roi, ih, iw, True)
+            raw_bt_c_code[:, :, :max_num_roi] = raw
+        else:
+            bt_c_code = torch.zeros_like(c_code)
+            bt_att = torch.zeros_like(att)
+            bt_slabels_code = torch.zeros((B, self.ef_dim2, ih, iw), dtype=c_code.dtype,
+                                          device=c_code.device)
+        h_c_code = torch.cat((h_code + h_code_hmap, c_code, bt_c_code, bt_slabels_code), 1)
+        out_code = self.upsample(self.residual(h_c_code))
+        raw_bt_c_code = raw_bt_c_code.transpose(1, 2).squeeze(-1)
+        return out_code, raw_bt_c_code, att, bt_att
+
+
+class _ToRGB(nn.Sequential):
+    def forward(self, x):
+        return ops.conv2d(x, self[0].weight, None, 1, 1, "zeros", act="tanh")
+
+
+class GET_IMAGE_G(nn.Module):
+    def __init__(self, ngf):
+        super(GET_IMAGE_G, self).__init__()
+        self.gf_dim = ngf
+        self.img = _ToRGB(conv3x3(ngf, 3), nn.Tanh())
+
+    def forward(self, h_code):
+        return self.img(h_code)
+
+
+class G_NET(nn.Module):
+    """Three-stage generator (reference model.py:722-795)."""
+
+    def __init__(self, num_classes):
+        super(G_NET, self).__init__()
+        ngf = cfg.GAN.GF_DIM
+        nef = cfg.TEXT.EMBEDDING_DIM
+        nef2 = cfg.TEXT.GLOVE_EMBEDDING_DIM
+        ncf = cfg.GAN.CONDITION_DIM
+        self.ca_net = CA_NET()
+        self.num_classes = num_classes
+        if cfg.TREE.BRANCH_NUM > 0:
+            self.h_net1_sent = INIT_STAGE_G(ngf * 4, ncf)
+            self.h_net1_hmap = G_HMAP(ngf // 2, num_classes)
+            self.h_net1_main = INIT_STAGE_G_MAIN(ngf, nef, nef2)
+            self.img_net1 = GET_IMAGE_G(ngf)
+        if cfg.TREE.BRANCH_NUM > 1:
+            self.h_net2_hmap = G_HMAP(ngf // 2, num_classes)
+            self.h_net2_main = NEXT_STAGE_G_MAIN(ngf, nef, nef2)
+            self.img_net2 = GET_IMAGE_G(ngf)
+        if cfg.TREE.BRANCH_NUM > 2:
+            self.h_net3_hmap = G_HMAP(ngf // 2, num_classes)
+            self.h_net3_main = NEXT_STAGE_G_MAIN(ngf, nef, nef2)
+            self.img_net3 = GET_IMAGE_G(ngf)
+
+    def forward(self, z_code, sent_emb, word_embs, glove_word_embs, slabels_feat, mask, hmaps, rois,
+                fm_rois, num_rois, bt_masks, fm_bt_masks, glb_max_num_roi):
+        fake_imgs, bt_c_codes, att_maps, bt_att_maps = [], [], [], []
+        c_code, mu, logvar = self.ca_net(sent_emb)
+        # one device->host read of the box counts per forward (the reference does one per stage)
+        max_num_roi = _max_rois(num_rois)
+
+        if cfg.TREE.BRANCH_NUM > 0:
+            h_code1_hmap = self.h_net1_hmap(hmaps[0])
+            h_code1_sent = self.h_net1_sent(z_code, c_code)
+            h_code1 = self.h_net1_main(h_code1_hmap, h_code1_sent, c_code, word_embs,
+                                       glove_word_embs, slabels_feat, mask, fm_rois, num_rois,
+                                       fm_bt_masks, glb_max_num_roi, max_num_roi=max_num_roi)
+            fake_imgs.append(self.img_net1(h_code1))
+        if cfg.TREE.BRANCH_NUM > 1:
+            h_code2_hmap = self.h_net2_hmap(hmaps[1])
+            h_code2, bt_c_code2, att1, bt_att1 = self.h_net2_main(
+                h_code1, h_code2_hmap, c_code, word_embs, glove_word_embs, slabels_feat, mask,
+                rois[0], num_rois, bt_masks[0], glb_max_num_roi, max_num_roi=max_num_roi)
+            fake_imgs.append(self.img_net2(h_code2))
+            bt_c_codes.append(bt_c_code2)
+            if att1 is not None:
+                att_maps.append(att1)
+            if bt_att1 is not None:
+                bt_att_maps.append(bt_att1)
+        if cfg.TREE.BRANCH_NUM > 2:
+            h_code3_hmap = self.h_net3_hmap(hmaps[2])
+            h_code3, bt_c_code3, att2, bt_att2 = self.h_net3_main(
+                h_code2, h_code3_hmap, c_code, word_embs, glove_word_embs, slabels_feat, mask,
+                rois[1], num_rois, bt_masks[1], glb_max_num_roi, max_num_roi=max_num_roi)
+            fake_imgs.append(self.img_net3(h_code3))
+            bt_c_codes.append(bt_c_code3)
+            if att2 is not None:
+                att_maps.append(att2)
+            if bt_att2 is not None:
+                bt_att_maps.append(bt_att2)
+        return fake_imgs, bt_c_codes, att_maps, bt_att_maps, mu, logvar
+
+
+# ---------------------------------------------------------------------------------------------
+# discriminators
+# ---------------------------------------------------------------------------------------------
+class _JointBlock(nn.Sequential):
+    """[conv3x3, BatchNorm2d, LeakyReLU(0.2)]."""
+
+    def forward(self, x):
+        conv, bn = self[0], self[1]
+        y = ops.conv2d(x, conv.weight, None, 1, 1, "zeros")
+        return _bn_act(y, bn, "lrelu")
+
+
+def Block3x3_leakRelu(in_planes, out_planes):
+    return _JointBlock(conv3x3(in_planes, out_planes),
+                        nn.BatchNorm2d(out_planes),
+                        nn.LeakyReLU(0.2, inplace=True))
+
+
+class _Encoder(nn.Sequential):
+    """[conv4x4 s2, LReLU, (conv4x4 s2, BN, LReLU) x (n-1)]: spatial size / 2^n."""
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            conv = mods[i]
+            if isinstance(mods[i + 1], nn.BatchNorm2d):
+                y = ops.conv2d(x, conv.weight, None, 2, 1, "zeros")
+                x = _bn_act(y, mods[i + 1], "lrelu")
+                i += 3
+            else:
+                x = ops.conv2d(x, conv.weight, None, 2, 1, "zeros", act="lrelu")
+                i += 2
+        return x
+
+
+def encode_image_by_ntimes(ngf, ndf, n_layer):
+    layers = [nn.Conv2d(3 + ngf, ndf, 4, 2, 1, bias=False), nn.LeakyReLU(0.2, inplace=True)]
+    for n in range(1, n_layer):
+        c_prev = ndf * min(2 ** (n - 1), 8)
+        c_next = ndf * min(2 ** n, 8)
+        layers += [nn.Conv2d(c_prev, c_next, 4, 2, 1, bias=False),
+                   nn.BatchNorm2d(c_next),
+                   nn.LeakyReLU(0.2, inplace=True)]
+    return _Encoder(*layers)
+
+
+class _ProbHead(nn.Sequential):
+    """[Conv2d(c, 1, k4, s2, bias), Sigmoid] -> probabilities."""
+
+    def forward(self, x):
+        conv = self[0]
+        return ops.conv2d(x, conv.weight, conv.bias, 2, 0, "zeros", act="sigmoid")
+
+
+class D_GET_LOGITS(nn.Module):
+    def __init__(self, ndf, nef, bcondition=False):
+        super(D_GET_LOGITS, self).__init__()
+        self.df_dim = ndf
+        self.ef_dim = nef
+        self.layer_num = cfg.GAN.LAYER_D_NUM
+        self.bcondition = bcondition
+        width = ndf * pow(2, self.layer_num - 1)
+        if self.bcondition:
+            self.jointConv = Block3x3_leakRelu(width + nef, width)
+        self.outlogits = _ProbHead(nn.Conv2d(width, 1, kernel_size=4, stride=2), nn.Sigmoid())
+
+    def forward(self, h_code, c_code=None):
+        if self.bcondition and c_code is not None:
+            c_code = c_code.view(-1, self.ef_dim, 1, 1).expand(-1, -1, h_code.size(2), h_code.size(3))
+            h_c_code = self.jointConv(torch.cat((h_code, c_code), 1))
+        else:
+            h_c_code = h_code
+        return self.outlogits(h_c_code)
+
+
+class _PatD(nn.Module):
+    """Patch discriminator body + (un)conditional heads (reference model.py:1053-1106); the
+    heads are invoked by the loss code on the returned features."""
+
+    def __init__(self, b_jcu=True):
+        super(_PatD, self).__init__()
+        ndf = cfg.GAN.DF_DIM
+        nef = cfg.TEXT.EMBEDDING_DIM
+        self.img_code = encode_image_by_ntimes(0, ndf, cfg.GAN.LAYER_D_NUM)
+        self.UNCOND_DNET = D_GET_LOGITS(ndf, nef, bcondition=False) if b_jcu else None
+        self.COND_DNET = D_GET_LOGITS(ndf, nef, bcondition=True)
+
+    def forward(self, x_var):
+        return self.img_code(x_var)
+
+
+class PAT_D_NET64(_PatD):
+    pass
+
+
+class PAT_D_NET128(_PatD):
+    pass
+
+
+class PAT_D_NET256(_PatD):
+    pass
+
+
+class _ShpD(nn.Module):
+    """Shape discriminator (reference model.py:1111-1179): image + encoded layout map."""
+
+    def __init__(self, num_classes):
+        super(_ShpD, self).__init__()
+        ndf = cfg.GAN.DF_DIM
+        nef = cfg.TEXT.EMBEDDING_DIM
+        ngf = cfg.GAN.GF_DIM // 4
+        self.img_code = encode_image_by_ntimes(ngf, ndf, cfg.GAN.LAYER_D_NUM)
+        self.shp_code = _shape_stem(num_classes, ngf)
+        self.UNCOND_DNET = D_GET_LOGITS(ndf, nef, bcondition=False)
+
+    def forward(self, x_var, s_var):
+        return self.img_code(torch.cat([x_var, self.shp_code(s_var)], dim=1))
+
+
+class SHP_D_NET64(_ShpD):
+    pass
+
+
+class SHP_D_NET128(_ShpD):
+    pass
+
+
+class SHP_D_NET256(_ShpD):
+    pass
+
+
+def _rois_blob(fm_rois, boxes_num):
+    """[x, y, w, h] box slots -> ROIAlign rows [batch_idx, x1, y1, x2, y2] (float32), on the
+    device.  Mirrors the reference host code (model.py:1213-1214, 1237-1240 and
+    miscc/utils.py:365-399): the corner add is done in float64 and rounded to float32 once; the
+    batch index of row r is r // BOXES_NUM; ALL slots are pooled, padded ones included."""
+    B = fm_rois.shape[0]
+    box = fm_rois[:, :, :4].to(torch.float64)
+    x1y1 = box[:, :, 0:2]
+    x2y2 = x1y1 + box[:, :, 2:4]
+    idx = torch.arange(B, device=fm_rois.device, dtype=torch.float64).view(B, 1, 1).expand(B, box.shape[1], 1)
+    blob = torch.cat((idx, x1y1, x2y2), dim=2).reshape(B * box.shape[1], 5)
+    return blob.to(torch.float32).contiguous()
+
+
+class _ObjD(nn.Module):
+    """ROIAlign-based object discriminator (reference model.py:1184-1312)."""
+
+    n_layer = 3
+
+    def __init__(self, num_classes, b_jcu=True):
+        super(_ObjD, self).__init__()
+        ndf = cfg.GAN.DF_DIM
+        nef = cfg.TEXT.GLOVE_EMBEDDING_DIM + cfg.GAN.GF_DIM
+        ngf = cfg.GAN.GF_DIM // 4
+        self.roi_size = cfg.ROI.ROI_BASE_SIZE
+        self.im_scales = np.array([1])
+        n_layer = self.n_layer
+        self.img_code = encode_image_by_ntimes(ngf, ndf, n_layer)
+        self.shp_code = _shape_stem(num_classes, ngf)
+        self.roi_code = _ActSeq(
+            nn.Conv2d(ndf * min(2 ** (n_layer - 1), 8), ndf * 4, kernel_size=4, stride=1, padding=1),
+            nn.LeakyReLU(0.2, True))
+        # NB (reference quirk kept, SURVEY.md trap 2): spatial_scale 1/16 is applied to boxes that
+        # are already in feature-map coordinates.
+        self.RoIAlignAvg = RoIAlignAvg(self.roi_size, self.roi_size, 1.0 / 16.0)
+        self.UNCOND_DNET = D_GET_LOGITS(ndf // 2, nef, bcondition=False) if b_jcu else None
+        self.COND_DNET = D_GET_LOGITS(ndf // 2, nef, bcondition=True)
+
+    def forward(self, x_var, s_var, fm_rois, num_rois, img_size=512):
+        x_var = ops.bilinear_resize(x_var, img_size, img_size)
+        s_var = ops.bilinear_resize(s_var, img_size, img_size)
+        x_code = self.img_code(torch.cat([x_var, self.shp_code(s_var)], dim=1))
+        batch_size = fm_rois.shape[0]
+        rois = _rois_blob(fm_rois, cfg.ROI.BOXES_NUM)
+        pooled = self.roi_code(self.RoIAlignAvg(x_code, rois))
+        return pooled.view(batch_size, cfg.ROI.BOXES_NUM, pooled.size(1), pooled.size(2), pooled.size(3))
+
+
+class OBJ_SS_D_NET(_ObjD):
+    n_layer = 3
+
+
+class OBJ_LS_D_NET(_ObjD):
+    n_layer = 4

@@ -1,0 +1,97 @@
+"""ctypes binding of libobjgan_hip.so (the C-ABI declared in include/objgan_hip.h).
+
+The reference binds its native op with cffi through torch.utils.ffi (reference
+image_generation/models/roi_align/_ext/roi_align/__init__.py:1-15); torch.utils.ffi no longer
+exists and cffi is not installed here, so the zero-dependency equivalent -- ctypes -- is used.
+There is NO fallback: if the shared library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+from . import build as _build
+
+_c_int = ctypes.c_int
+_c_long = ctypes.c_long
+_c_float = ctypes.c_float
+_ptr = ctypes.c_void_p
+
+# name -> argtypes  (every function returns int: 1 ok, 0 bad args, <0 -hipError)
+SIGNATURES = {
+    "objgan_roi_align_forward": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _ptr],
+    "objgan_roi_align_backward": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _ptr],
+    "objgan_avgpool2s1_forward": [_ptr, _ptr, _c_long, _c_int, _c_int, _ptr],
+    "objgan_avgpool2s1_backward": [_ptr, _ptr, _c_long, _c_int, _c_int, _ptr],
+    "objgan_conv_igemm": [_ptr, _ptr, _ptr, _ptr, _ptr,
+                          _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                          _c_int, _c_int, _c_int, _c_int,
+                          _c_int, _ptr, _ptr, _ptr,
+                          _c_int, _c_int, _c_int,
+                          _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                          _c_int, _ptr],
+    "objgan_conv_wgrad": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                          _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr],
+    "objgan_norm_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                            _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _ptr],
+    "objgan_norm_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                             _c_int, _c_int, _c_int, _c_int, _c_int, _ptr],
+    "objgan_act_backward": [_ptr, _ptr, _ptr, _c_long, _c_int, _ptr],
+    "objgan_channel_sum": [_ptr, _ptr, _c_int, _c_int, _c_int, _ptr],
+    "objgan_attn_general_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr],
+    "objgan_attn_general_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr],
+    "objgan_attn_bu_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _ptr],
+    "objgan_attn_bu_backward": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr],
+    "objgan_masked_max_forward": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_long, _c_long, _c_long, _ptr],
+    "objgan_masked_max_backward": [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_long, _c_long, _c_long, _ptr],
+    "objgan_softmax_strided_forward": [_ptr, _ptr, _c_long, _c_int, _c_long, _c_float, _ptr, _c_int, _ptr, _ptr],
+    "objgan_softmax_strided_backward": [_ptr, _ptr, _ptr, _c_long, _c_int, _c_long, _c_float, _ptr],
+    "objgan_bilinear_forward": [_ptr, _ptr, _c_long, _c_int, _c_int, _c_int, _c_int, _ptr],
+    "objgan_bilinear_backward": [_ptr, _ptr, _c_long, _c_int, _c_int, _c_int, _c_int, _ptr],
+    "objgan_sum2x2": [_ptr, _ptr, _c_long, _c_int, _c_int, _ptr],
+    "objgan_reflect_fold": [_ptr, _ptr, _c_long, _c_int, _c_int, _ptr],
+    "objgan_adam_step": [_ptr, _ptr, _ptr, _ptr, _c_long, _c_float, _c_float, _c_float, _c_float, _c_int, _ptr],
+    "objgan_ema_update": [_ptr, _ptr, _c_long, _c_float, _c_float, _ptr],
+}
+LONG_RETURN = {"objgan_conv_packed_floats": [_c_int, _c_int]}
+
+_LIB = None
+
+
+class ObjganHipError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load(build_if_missing=True):
+    """Load (building first if the .so is absent and hipcc is available). Never falls back."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise ObjganHipError("libobjgan_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _build.build(verbose=False)
+    lib = ctypes.CDLL(path)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is missing: loud by design
+        fn.argtypes = argtypes
+        fn.restype = _c_int
+    for name, argtypes in LONG_RETURN.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _c_long
+    _LIB = lib
+    return lib
+
+
+def call(name, *args):
+    """Call an entry point and turn the reference-style return code into an exception."""
+    rc = getattr(load(), name)(*args)
+    if rc == 1:
+        return
+    if rc == 0:
+        raise ObjganHipError("%s: invalid arguments (returned 0)" % name)
+    raise ObjganHipError("%s: HIP launch failed (hipError %d)" % (name, -rc))

@@ -1,0 +1,79 @@
+"""Build libobjgan_hip.so (gfx950) from obj-gan_amd/csrc/*.hip with hipcc.
+
+Replaces the reference's nvcc + torch.utils.ffi build (reference
+image_generation/make.sh:1-57, models/roi_align/build.py:27-35).  hipcc cross-compiles for
+gfx950 without a GPU, so this runs in the CPU-only build container; the .so is kept in-tree
+(git-ignored) so that it travels to the GPU box with the source snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(HERE), "csrc")
+LIB_PATH = os.path.join(HERE, "libobjgan_hip.so")
+OBJ_DIR = os.path.join(CSRC, "build")
+
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
+# ROIAlign index math must be bit-exact with the reference C loop: no FMA contraction.
+PER_FILE_FLAGS = {"roi_align.hip": ["-ffp-contract=off"]}
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build libobjgan_hip.so")
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    lib_m = os.path.getmtime(LIB_PATH)
+    for f in os.listdir(CSRC):
+        p = os.path.join(CSRC, f)
+        if os.path.isfile(p) and os.path.getmtime(p) > lib_m:
+            return True
+    return False
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = _hipcc()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    objs = []
+    procs = []
+    for src in sources():
+        obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        objs.append(obj)
+        srcp = os.path.join(CSRC, src)
+        deps = [srcp, os.path.join(CSRC, "common.h")]
+        if (not force and os.path.exists(obj)
+                and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in deps)):
+            continue
+        cmd = [hipcc] + BASE_FLAGS + PER_FILE_FLAGS.get(src, []) + ["-c", srcp, "-o", obj]
+        if verbose:
+            print("[objgan_hip.build]", " ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, cwd="/tmp" if os.path.isdir("/tmp") else None,
+                                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out.decode(errors="replace"))
+            raise RuntimeError("hipcc failed on %s" % src)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print("[objgan_hip.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd, cwd="/tmp" if os.path.isdir("/tmp") else None)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

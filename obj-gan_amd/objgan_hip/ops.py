@@ -1,0 +1,508 @@
+"""torch.autograd bindings of the gfx950 kernels (host side of the C-ABI in include/objgan_hip.h).
+
+PyTorch is used here for device memory, streams and the autograd tape only: every
+operator below launches hand-written HIP kernels through ctypes.  There is no CPU or
+eager-PyTorch fallback -- a CPU tensor (or a missing libobjgan_hip.so) raises.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+
+_F32 = torch.float32
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.ObjganHipError(
+                "objgan_hip operators run on the MI355X only (got a %s tensor); there is no CPU path"
+                % t.device)
+        if t.dtype != _F32:
+            raise _lib.ObjganHipError("objgan_hip operators are fp32 (got %s)" % t.dtype)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _iarr(vals):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+# ----------------------------------------------------------------------------------------------
+# convolution
+# ----------------------------------------------------------------------------------------------
+_ACT = {None: 0, "none": 0, "lrelu": 1, "tanh": 2, "sigmoid": 3}
+
+
+def _packed_scratch(M, K, device):
+    n = _lib.load().objgan_conv_packed_floats(int(M), int(K))
+    return torch.empty(n, dtype=_F32, device=device)
+
+
+def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, transpose,
+           dh, dw, src_tap, PH, PW, stride, OHf, OWf, osh, osw, ooh, oow, act):
+    Tg = len(dh)
+    M = Cin if transpose else Cout
+    wt = _packed_scratch(M, C * Tg, x.device)
+    _lib.call("objgan_conv_igemm", _p(x), _p(w), _p(bias), _p(y), _p(wt),
+              N, C, H, W, int(upsample), int(pad_mode), Cout, Cin, Torig, int(transpose),
+              Tg, _iarr(dh), _iarr(dw), _iarr(src_tap), PH, PW, stride,
+              OHf, OWf, osh, osw, ooh, oow, act, _stream())
+
+
+def _pad_taps(dh, dw, st):
+    """Pad a tap list to the next supported GEMM tap count (1, 4, 9, 16) with zero taps."""
+    n = len(dh)
+    for tg in (1, 4, 9, 16):
+        if n <= tg:
+            k = tg - n
+            return dh + [0] * k, dw + [0] * k, st + [-1] * k
+    raise _lib.ObjganHipError("more than 16 taps")
+
+
+def conv_out_size(L, k, s, p):
+    return (L + 2 * p - k) // s + 1
+
+
+class _Conv2dFn(torch.autograd.Function):
+    """conv2d with the gather-side fusions of the hot path.
+
+    pad_mode 'zeros' : nn.Conv2d(padding=pad)            (reference model.py:36-39, 1002, 1010)
+    pad_mode 'reflect': nn.ReflectionPad2d(pad) + nn.Conv2d(padding=0)  (model.py:66-75, 599-601)
+    upsample          : nn.Upsample(scale_factor=2, mode='nearest') in front (model.py:43-49)
+    act               : LeakyReLU(0.2) / tanh / sigmoid fused in the epilogue
+    """
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, pad_mode, upsample, act):
+        _chk(x, w, bias)
+        x = _c(x)
+        w = _c(w)
+        N, Cin, H, W = x.shape
+        Cout, Cin2, KH, KW = w.shape
+        if Cin2 != Cin or KH != KW:
+            raise _lib.ObjganHipError("conv2d: bad weight shape %s for input %s" % (tuple(w.shape), tuple(x.shape)))
+        k = KH
+        LH, LW = (2 * H, 2 * W) if upsample else (H, W)
+        OH, OW = conv_out_size(LH, k, stride, pad), conv_out_size(LW, k, stride, pad)
+        refl = 1 if pad_mode == "reflect" else 0
+        if refl and pad != 1:
+            raise _lib.ObjganHipError("reflect padding is implemented for pad=1")
+        y = torch.empty((N, Cout, OH, OW), dtype=_F32, device=x.device)
+        dh = [kh - pad for kh in range(k) for kw in range(k)]
+        dw = [kw - pad for kh in range(k) for kw in range(k)]
+        st = list(range(k * k))
+        _igemm(x, w, bias, y, N, Cin, H, W, upsample, refl, Cout, Cin, k * k, 0,
+               dh, dw, st, OH, OW, stride, OH, OW, 1, 1, 0, 0, _ACT[act])
+        ctx.cfg = (stride, pad, refl, bool(upsample), act, k)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w, y if act not in (None, "none") else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, refl, upsample, act, k = ctx.cfg
+        N, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        dy = _c(dy)
+        _chk(dy)
+        OH, OW = dy.shape[2], dy.shape[3]
+        if act not in (None, "none"):
+            g = torch.empty_like(dy)
+            _lib.call("objgan_act_backward", _p(dy), _p(y), _p(g), dy.numel(), _ACT[act], _stream())
+        else:
+            g = dy
+        dx = dw_ = db = None
+        LH, LW = (2 * H, 2 * W) if upsample else (H, W)
+        if ctx.needs_input_grad[0]:
+            if stride == 1:
+                pe = 0 if refl else pad            # reflect: gradient w.r.t. the padded tensor first
+                TH, TW = (LH + 2 * pad, LW + 2 * pad) if refl else (LH, LW)
+                dh = [pe - kh for kh in range(k) for kw in range(k)]
+                dw = [pe - kw for kh in range(k) for kw in range(k)]
+                st = list(range(k * k))
+                dxl = torch.empty((N, Cin, TH, TW), dtype=_F32, device=x.device)
+                _igemm(g, w, None, dxl, N, Cout, OH, OW, 0, 0, Cout, Cin, k * k, 1,
+                       dh, dw, st, TH, TW, 1, TH, TW, 1, 1, 0, 0, 0)
+                if refl:
+                    folded = torch.empty((N, Cin, LH, LW), dtype=_F32, device=x.device)
+                    _lib.call("objgan_reflect_fold", _p(dxl), _p(folded), N * Cin, LH, LW, _stream())
+                    dxl = folded
+            elif stride == 2:
+                if refl:
+                    raise _lib.ObjganHipError("stride-2 reflect conv is not on the hot path")
+                dxl = torch.empty((N, Cin, LH, LW), dtype=_F32, device=x.device)
+                for ph in range(2):
+                    khs = [kh for kh in range(k) if (ph + pad - kh) % 2 == 0]
+                    PHg = (LH - ph + 1) // 2
+                    for pw in range(2):
+                        kws = [kw for kw in range(k) if (pw + pad - kw) % 2 == 0]
+                        PWg = (LW - pw + 1) // 2
+                        if PHg <= 0 or PWg <= 0:
+                            continue
+                        dh = [(ph + pad - kh) // 2 for kh in khs for kw in kws]
+                        dw = [(pw + pad - kw) // 2 for kh in khs for kw in kws]
+                        st = [kh * k + kw for kh in khs for kw in kws]
+                        if not st:      # no tap reaches this phase: gradient is zero there
+                            dh, dw, st = [0], [0], [-1]
+                        dh, dw, st = _pad_taps(dh, dw, st)
+                        _igemm(g, w, None, dxl, N, Cout, OH, OW, 0, 0, Cout, Cin, k * k, 1,
+                               dh, dw, st, PHg, PWg, 1, LH, LW, 2, 2, ph, pw, 0)
+            else:
+                raise _lib.ObjganHipError("conv2d backward: stride %d not supported" % stride)
+            if upsample:
+                dx = torch.empty((N, Cin, H, W), dtype=_F32, device=x.device)
+                _lib.call("objgan_sum2x2", _p(dxl), _p(dx), N * Cin, H, W, _stream())
+            else:
+                dx = dxl
+        if ctx.needs_input_grad[1]:
+            dw_ = torch.zeros_like(w)
+            _lib.call("objgan_conv_wgrad", _p(x), _p(g), _p(dw_), N, Cin, H, W, int(upsample), refl,
+                      Cout, OH, OW, k, stride, pad, _stream())
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(Cout, dtype=_F32, device=x.device)
+            _lib.call("objgan_channel_sum", _p(g), _p(db), N, Cout, OH * OW, _stream())
+        return dx, dw_, db, None, None, None, None, None
+
+
+def conv2d(x, w, bias=None, stride=1, pad=0, pad_mode="zeros", upsample=False, act=None):
+    return _Conv2dFn.apply(x, w, bias, stride, pad, pad_mode, upsample, act)
+
+
+def linear(x, w, bias=None, act=None):
+    """nn.Linear as a 1x1 convolution over a [N, C, 1, 1] view (reference model.py:462, 494)."""
+    y = conv2d(x.reshape(x.shape[0], x.shape[1], 1, 1), w.reshape(w.shape[0], w.shape[1], 1, 1),
+               bias, 1, 0, "zeros", False, act)
+    return y.reshape(x.shape[0], w.shape[0])
+
+
+# ----------------------------------------------------------------------------------------------
+# normalisation (+ GLU / LeakyReLU / residual)
+# ----------------------------------------------------------------------------------------------
+_NORM_MODE = {None: 0, "none": 0, "lrelu": 1, "glu": 2}
+
+
+class _NormActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, per_channel, mode, eps,
+                momentum):
+        _chk(x, gamma, beta, residual, running_mean, running_var)
+        x = _c(x)
+        N, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (N * C) if x.numel() else 0
+        Co = C // 2 if mode == "glu" else C
+        y = torch.empty((N, Co) + tuple(x.shape[2:]), dtype=_F32, device=x.device)
+        G = C if per_channel else N * C
+        ws = torch.empty(4 * G, dtype=_F32, device=x.device)
+        sums, mean, rstd = ws[:2 * G], ws[2 * G:3 * G], ws[3 * G:]
+        residual = _c(residual) if residual is not None else None
+        _lib.call("objgan_norm_forward", _p(x), _p(y), _p(residual), _p(gamma), _p(beta),
+                  _p(running_mean), _p(running_var), _p(sums), _p(mean), _p(rstd),
+                  N, C, HW, int(per_channel), _NORM_MODE[mode], float(eps), float(momentum), _stream())
+        ctx.cfg = (N, C, HW, int(per_channel), _NORM_MODE[mode])
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, mean, rstd, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, gamma, beta = ctx.saved_tensors
+        N, C, HW, per_channel, mode = ctx.cfg
+        dy = _c(dy)
+        _chk(dy)
+        G = C if per_channel else N * C
+        bsums = torch.empty(2 * G, dtype=_F32, device=x.device)
+        dx = torch.empty_like(x)
+        dgamma = dbeta = None
+        if gamma is not None:
+            dgamma = torch.empty_like(gamma)
+            dbeta = torch.empty_like(beta)
+        _lib.call("objgan_norm_backward", _p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta),
+                  _p(bsums), _p(dx), _p(dgamma), _p(dbeta), N, C, HW, per_channel, mode, _stream())
+        dres = dy if ctx.has_res else None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
+
+
+def norm_act(x, gamma=None, beta=None, residual=None, running_mean=None, running_var=None,
+             per_channel=False, mode=None, eps=1e-5, momentum=0.1):
+    """BatchNorm (per_channel=True, batch statistics) or InstanceNorm (per_channel=False)
+    fused with GLU / LeakyReLU(0.2) and an optional residual add."""
+    return _NormActFn.apply(x, gamma, beta, residual, running_mean, running_var, per_channel, mode,
+                            eps, momentum)
+
+
+# ----------------------------------------------------------------------------------------------
+# attention
+# ----------------------------------------------------------------------------------------------
+def _mask_u8(mask):
+    if mask is None:
+        return None
+    if not mask.is_cuda:
+        raise _lib.ObjganHipError("attention mask must live on the GPU")
+    return _c(mask.to(torch.uint8))
+
+
+class _AttnGeneralFn(torch.autograd.Function):
+    """weightedContext, attn = GlobalAttentionGeneral core (reference GlobalAttention.py:95-120)
+    given the projected context sourceT [B, idf, L]."""
+
+    @staticmethod
+    def forward(ctx, x, src, mask_u8):
+        _chk(x, src)
+        x = _c(x)
+        src = _c(src)
+        B, idf = x.shape[0], x.shape[1]
+        Q = x.shape[2] * x.shape[3]
+        L = src.shape[2]
+        wc = torch.empty_like(x)
+        attn = torch.empty((B, L, x.shape[2], x.shape[3]), dtype=_F32, device=x.device)
+        _lib.call("objgan_attn_general_forward", _p(x), _p(src), _p(mask_u8), _p(wc), _p(attn),
+                  B, idf, Q, L, _stream())
+        ctx.save_for_backward(x, src, attn)
+        return wc, attn
+
+    @staticmethod
+    def backward(ctx, dwc, dattn):
+        x, src, attn = ctx.saved_tensors
+        B, idf = x.shape[0], x.shape[1]
+        Q = x.shape[2] * x.shape[3]
+        L = src.shape[2]
+        dwc = _c(dwc)
+        dattn = _c(dattn) if dattn is not None else None
+        dx = torch.empty_like(x)
+        dsrc = torch.zeros_like(src)
+        _lib.call("objgan_attn_general_backward", _p(x), _p(src), _p(attn), _p(dwc), _p(dattn),
+                  _p(dx), _p(dsrc), B, idf, Q, L, _stream())
+        return dx, dsrc, None
+
+
+def attn_general(x, src, mask=None):
+    return _AttnGeneralFn.apply(x, src, _mask_u8(mask))
+
+
+class _AttnBUFn(torch.autograd.Function):
+    """GlobalBUAttentionGeneral core (reference GlobalAttention.py:153-179): scores from the
+    label features and GloVe words, context from the projected word embeddings `src`."""
+
+    @staticmethod
+    def forward(ctx, tgt, ctx1, src, mask_u8, normalize, eps):
+        _chk(tgt, ctx1, src)
+        if tgt.requires_grad or ctx1.requires_grad:
+            raise _lib.ObjganHipError(
+                "attn_bu: gradients w.r.t. the label / GloVe features are not implemented "
+                "(they are constants on the training hot path)")
+        tgt, ctx1, src = _c(tgt), _c(ctx1), _c(src)
+        B, d2, R = tgt.shape[0], tgt.shape[1], tgt.shape[2] * tgt.shape[3]
+        idf, L = src.shape[1], src.shape[2]
+        wc = torch.empty((B, idf, tgt.shape[2], tgt.shape[3]), dtype=_F32, device=tgt.device)
+        attn = torch.empty((B, L, tgt.shape[2], tgt.shape[3]), dtype=_F32, device=tgt.device)
+        _lib.call("objgan_attn_bu_forward", _p(tgt), _p(ctx1), _p(src), _p(mask_u8), _p(wc), _p(attn),
+                  B, d2, idf, R, L, int(normalize), float(eps), _stream())
+        ctx.save_for_backward(attn)
+        ctx.dims = (B, idf, R, L)
+        ctx.mark_non_differentiable(attn)
+        return wc, attn
+
+    @staticmethod
+    def backward(ctx, dwc, dattn):
+        (attn,) = ctx.saved_tensors
+        B, idf, R, L = ctx.dims
+        dwc = _c(dwc)
+        dsrc = torch.empty((B, idf, L), dtype=_F32, device=dwc.device)
+        _lib.call("objgan_attn_bu_backward", _p(dwc), _p(attn), _p(dsrc), B, idf, R, L, _stream())
+        return None, None, dsrc, None, None, None
+
+
+def attn_bu(tgt, ctx1, src, mask=None, normalize=True, eps=1e-8):
+    return _AttnBUFn.apply(tgt, ctx1, src, _mask_u8(mask), normalize, eps)
+
+
+class _MaskedMaxFn(torch.autograd.Function):
+    """out[b, c, p] = max_r f[b, c, r] * m[b, r, (c,) p]  (reference miscc/utils.py:401-413)."""
+
+    @staticmethod
+    def forward(ctx, f, m, ih, iw):
+        _chk(f, m)
+        B, num, R = f.shape[0], f.shape[1], f.shape[2]
+        f2 = _c(f.reshape(B, num, R))
+        P = ih * iw
+        if m.dim() == 4:                       # [B, R, ih, iw]: one mask for every channel
+            if not (m.stride(3) == 1 and m.stride(2) == iw):
+                m = _c(m)                      # (a [:, :R] slice keeps its strides: no copy)
+            sb, sr, sc = m.stride(0), m.stride(1), 0
+        elif m.dim() == 5:                     # [B, R, num, ih, iw] (the reference's repeated form)
+            if m.stride(2) == 0 and m.stride(4) == 1 and m.stride(3) == iw:
+                sb, sr, sc = m.stride(0), m.stride(1), 0
+            else:
+                m = _c(m)
+                sb, sr, sc = R * num * P, num * P, P
+        else:
+            raise _lib.ObjganHipError("masked_max: mask must be 4-D or 5-D")
+        out = torch.empty((B, num, ih, iw), dtype=_F32, device=f.device)
+        _lib.call("objgan_masked_max_forward", _p(f2), _p(m), _p(out), B, num, R, P, sb, sr, sc, _stream())
+        ctx.save_for_backward(f2, m)
+        ctx.geom = (B, num, R, P, sb, sr, sc, tuple(f.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        f2, m = ctx.saved_tensors
+        B, num, R, P, sb, sr, sc, fshape = ctx.geom
+        dout = _c(dout)
+        df = torch.zeros((B, num, R), dtype=_F32, device=f2.device)
+        _lib.call("objgan_masked_max_backward", _p(f2), _p(m), _p(dout), _p(df), B, num, R, P,
+                  sb, sr, sc, _stream())
+        return df.reshape(fshape), None, None, None
+
+
+def masked_max(f, m, ih, iw):
+    return _MaskedMaxFn.apply(f, m, ih, iw)
+
+
+class _SoftmaxStridedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dim, scale, lens, rowvalid):
+        _chk(x)
+        x = _c(x)
+        d = dim % x.dim()
+        outer = int(math.prod(x.shape[:d]))
+        n = x.shape[d]
+        inner = int(math.prod(x.shape[d + 1:]))
+        y = torch.empty_like(x)
+        _lib.call("objgan_softmax_strided_forward", _p(x), _p(y), outer, n, inner, float(scale),
+                  _p(lens), 0 if lens is None else lens.numel(), _p(rowvalid), _stream())
+        ctx.save_for_backward(y)
+        ctx.geom = (outer, n, inner, float(scale))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        outer, n, inner, scale = ctx.geom
+        dy = _c(dy)
+        dx = torch.empty_like(y)
+        _lib.call("objgan_softmax_strided_backward", _p(y), _p(dy), _p(dx), outer, n, inner, scale, _stream())
+        return dx, None, None, None, None
+
+
+def softmax_strided(x, dim, scale=1.0, lens=None, rowvalid=None):
+    """softmax(scale * x) along `dim`; `lens` (int32, per outer row modulo len(lens)) truncates the
+    softmax span, `rowvalid` (uint8 per outer row) zeroes whole rows."""
+    return _SoftmaxStridedFn.apply(x, dim, scale, lens, rowvalid)
+
+
+# ----------------------------------------------------------------------------------------------
+# ROIAlign, pooling, resize
+# ----------------------------------------------------------------------------------------------
+class RoIAlignFunction(torch.autograd.Function):
+    """reference image_generation/models/roi_align/functions/roi_align.py:7-51 (new-style)."""
+
+    @staticmethod
+    def forward(ctx, features, rois, aligned_height, aligned_width, spatial_scale):
+        _chk(features, rois)
+        features = _c(features)
+        rois = _c(rois)
+        B, C, H, W = features.shape
+        num_rois = rois.shape[0]
+        roi_cols = rois.shape[1] if rois.dim() == 2 else 0
+        out = torch.zeros((num_rois, C, aligned_height, aligned_width), dtype=_F32, device=features.device)
+        _lib.call("objgan_roi_align_forward", _p(features), _p(rois), _p(out), num_rois, roi_cols,
+                  C, H, W, aligned_height, aligned_width, float(spatial_scale), _stream())
+        ctx.save_for_backward(rois)
+        ctx.geom = (B, C, H, W, aligned_height, aligned_width, float(spatial_scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (rois,) = ctx.saved_tensors
+        B, C, H, W, ah, aw, scale = ctx.geom
+        grad_output = _c(grad_output)
+        _chk(grad_output)
+        grad_input = torch.zeros((B, C, H, W), dtype=_F32, device=grad_output.device)
+        _lib.call("objgan_roi_align_backward", _p(grad_output), _p(rois), _p(grad_input), B,
+                  rois.shape[0], rois.shape[1], C, H, W, ah, aw, scale, _stream())
+        return grad_input, None, None, None, None
+
+
+def roi_align(features, rois, aligned_height, aligned_width, spatial_scale):
+    return RoIAlignFunction.apply(features, rois, int(aligned_height), int(aligned_width), float(spatial_scale))
+
+
+class _AvgPool2s1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        x = _c(x)
+        ih, iw = x.shape[-2], x.shape[-1]
+        planes = x.numel() // (ih * iw) if x.numel() else 0
+        y = torch.empty(tuple(x.shape[:-2]) + (ih - 1, iw - 1), dtype=_F32, device=x.device)
+        _lib.call("objgan_avgpool2s1_forward", _p(x), _p(y), planes, ih, iw, _stream())
+        ctx.geom = (tuple(x.shape), planes, ih, iw)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        shape, planes, ih, iw = ctx.geom
+        dy = _c(dy)
+        dx = torch.empty(shape, dtype=_F32, device=dy.device)
+        _lib.call("objgan_avgpool2s1_backward", _p(dy), _p(dx), planes, ih, iw, _stream())
+        return dx
+
+
+def avgpool2s1(x):
+    return _AvgPool2s1Fn.apply(x)
+
+
+class _BilinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, oh, ow):
+        _chk(x)
+        x = _c(x)
+        ih, iw = x.shape[-2], x.shape[-1]
+        planes = x.numel() // (ih * iw) if x.numel() else 0
+        y = torch.empty(tuple(x.shape[:-2]) + (oh, ow), dtype=_F32, device=x.device)
+        _lib.call("objgan_bilinear_forward", _p(x), _p(y), planes, ih, iw, oh, ow, _stream())
+        ctx.geom = (tuple(x.shape), planes, ih, iw, oh, ow)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        shape, planes, ih, iw, oh, ow = ctx.geom
+        dy = _c(dy)
+        dx = torch.empty(shape, dtype=_F32, device=dy.device)
+        _lib.call("objgan_bilinear_backward", _p(dy), _p(dx), planes, ih, iw, oh, ow, _stream())
+        return dx, None, None
+
+
+def bilinear_resize(x, oh, ow):
+    """F.interpolate(x, size=(oh, ow), mode='bilinear', align_corners=True)."""
+    return _BilinearFn.apply(x, int(oh), int(ow))
+
+
+# ----------------------------------------------------------------------------------------------
+# optimiser on flat arenas
+# ----------------------------------------------------------------------------------------------
+def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step):
+    _chk(p, g, m, v)
+    _lib.call("objgan_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1),
+              float(beta2), float(eps), int(step), _stream())
+
+
+def ema_update_(avg, p, decay):
+    _chk(avg, p)
+    _lib.call("objgan_ema_update", _p(avg), _p(p), p.numel(), float(decay), float(1.0 - decay), _stream())

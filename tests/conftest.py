@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "obj-gan_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def dev():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def rel_l2(a, b):
+    import torch
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    den = torch.linalg.vector_norm(b)
+    if den == 0:
+        return float(torch.linalg.vector_norm(a - b))
+    return float(torch.linalg.vector_norm(a - b) / den)
