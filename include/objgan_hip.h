@@ -116,8 +116,10 @@ int objgan_bilinear_backward(const float* dy, float* dx, long planes, int ih, in
                              void* stream);
 int objgan_sum2x2(const float* dy, float* dx, long planes, int h, int w, void* stream);
 int objgan_reflect_fold(const float* dxp, float* dx, long planes, int h, int w, void* stream);
+/* torch.optim.Adam update over flat arenas; the gradient is pre-multiplied by grad_scale
+ * (1/world_size under data parallelism: the RCCL all-reduce is a plain sum). */
 int objgan_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
-                     float beta2, float eps, int step, void* stream);
+                     float beta2, float eps, int step, float grad_scale, void* stream);
 int objgan_ema_update(float* avg, const float* p, long n, float decay, float one_minus_decay,
                       void* stream);
 

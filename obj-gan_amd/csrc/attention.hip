@@ -52,13 +52,16 @@ __global__ __launch_bounds__(256) void attn_general_fwd_kernel(
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) sc[l] = fmaf(xc, s_src[c][l], sc[l]);
     }
-    // mask row of the reference's mis-tiled repeat
-    const unsigned char* mrow = mask ? mask + (size_t)(((long)b * Q + q) % B) * L : nullptr;
+    // mask row of the reference's mis-tiled repeat, gathered into one bit per word
+    unsigned deadbits = (L >= 32) ? 0u : ~((1u << L) - 1u);         // padded words l >= L
+    if (mask) {
+        const unsigned char* mrow = mask + (size_t)(((long)b * Q + q) % B) * L;
+        for (int l = 0; l < L; ++l) deadbits |= (mrow[l] != 0 ? 1u : 0u) << l;
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) {
-        const bool dead = (l >= L) || (mrow && mrow[l < L ? l : 0]);
-        sc[l] = dead ? -INFINITY : sc[l];
+        sc[l] = ((deadbits >> l) & 1u) ? -INFINITY : sc[l];
         mx = fmaxf(mx, sc[l]);
     }
     float sum = 0.f;

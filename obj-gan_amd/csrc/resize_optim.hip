@@ -137,11 +137,12 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restri
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    long n, float lr, float beta1, float beta2,
-                                                   float eps, float bc1, float bc2_sqrt) {
+                                                   float eps, float bc1, float bc2_sqrt,
+                                                   float grad_scale) {
     const float step_size = lr / bc1;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long)gridDim.x * blockDim.x) {
-        const float gi = g[i];
+        const float gi = g[i] * grad_scale;   // 1/world_size folds the DDP average in here
         const float mi = m[i] + (gi - m[i]) * (1.f - beta1);        // exp_avg.lerp_(grad, 1-beta1)
         const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;    // mul_(beta2).addcmul_
         m[i] = mi;
@@ -203,13 +204,13 @@ int objgan_reflect_fold(const float* dxp, float* dx, long planes, int h, int w, 
 }
 
 int objgan_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
-                     float beta2, float eps, int step, void* stream) {
+                     float beta2, float eps, int step, float grad_scale, void* stream) {
     if (n <= 0) return OG_OK;
     if (step < 1) return OG_BAD_ARGS;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3(og_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                       p, g, m, v, n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
+                       p, g, m, v, n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
     return og_launch_status();
 }
 

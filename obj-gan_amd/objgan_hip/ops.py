@@ -497,10 +497,12 @@ def bilinear_resize(x, oh, ow):
 # ----------------------------------------------------------------------------------------------
 # optimiser on flat arenas
 # ----------------------------------------------------------------------------------------------
-def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step):
+def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, n=None):
+    """In-place Adam over flat arenas (first n elements; g may carry trailing bookkeeping slots)."""
     _chk(p, g, m, v)
-    _lib.call("objgan_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1),
-              float(beta2), float(eps), int(step), _stream())
+    n = p.numel() if n is None else int(n)
+    _lib.call("objgan_adam_step", _p(p), _p(g), _p(m), _p(v), n, float(lr), float(beta1),
+              float(beta2), float(eps), int(step), float(grad_scale), _stream())
 
 
 def ema_update_(avg, p, decay):

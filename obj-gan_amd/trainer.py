@@ -1,0 +1,368 @@
+"""G+D training driver of the image generator on MI355X.
+
+Same entry points as the reference (reference image_generation/trainer.py:30-510):
+`condGANTrainer(output_dir, data_loader, dataset)` with `build_models`, `define_optimizers`,
+`prepare_labels`, `save_model`, `train`.  The per-iteration body of the reference's loop
+(trainer.py:357-472) is `train_step`, usable on its own (bench.py, tests).
+
+MI355X-first differences (results-preserving unless noted):
+  * every network's parameters, gradients and Adam moments live in flat fp32 arenas
+    (`ParamArena`): one fused Adam launch per network, one fused EMA launch, and -- under
+    data parallelism -- ONE RCCL all-reduce per network on the flat gradient arena;
+  * data parallelism is one process per GPU over torch.distributed (backend "nccl" = RCCL over
+    xGMI) instead of the reference's single-process nn.DataParallel (trainer.py:136-152): each
+    rank runs the reference step on its own minibatch shard (per-rank BatchNorm statistics and
+    DAMSM negatives, exactly like a DataParallel replica would for BN), gradients are averaged.
+    The all-reduce of discriminator i is asynchronous and overlaps the forward/backward of
+    discriminator i+1; Adam for the discriminators runs once their reductions have landed;
+  * discriminator weights are frozen (requires_grad=False) during the generator step: the
+    reference computes and discards those weight gradients (trainer.py:449; SURVEY.md trap 7);
+  * one device->host read of num_rois per step instead of one per stage; log strings are only
+    formatted on print steps (the reference calls .item() on every loss every step).
+"""
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from miscc.config import cfg
+from miscc.utils import mkdir_p, weights_init, form_clabels_feat
+from miscc.losses import patD_loss, shpD_loss, objD_loss, G_loss, KL_loss
+from model import (G_NET, PAT_D_NET64, PAT_D_NET128, PAT_D_NET256, SHP_D_NET64, SHP_D_NET128,
+                   SHP_D_NET256, OBJ_SS_D_NET, OBJ_LS_D_NET)
+from objgan_hip import ops
+
+
+# ---------------------------------------------------------------------------------------------
+# flat parameter / gradient / moment arenas
+# ---------------------------------------------------------------------------------------------
+class ParamArena(object):
+    """Re-homes a module's parameters into one flat fp32 buffer (and their .grad into another).
+
+    grad has one extra trailing element: the "this rank contributed" flag used to keep the
+    conditional object-discriminator updates consistent across ranks."""
+
+    def __init__(self, module):
+        self.module = module
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.n = n
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n + 1, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.step_count = 0
+        self._views = []
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + k].view_as(p)
+            gview = self.grad[off:off + k].view_as(p)
+            p.grad = gview
+            self._views.append(gview)
+            off += k
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, gv in zip(self.params, self._views):
+            p.grad = gv
+
+    def sync_grads(self):
+        """Make sure every gradient lives in the arena (callers may have used
+        module.zero_grad(set_to_none=True) or assigned .grad themselves)."""
+        for p, gv in zip(self.params, self._views):
+            if p.grad is None:
+                gv.zero_()
+                p.grad = gv
+            elif p.grad.data_ptr() != gv.data_ptr():
+                gv.copy_(p.grad)
+                p.grad = gv
+
+    def set_requires_grad(self, flag):
+        for p in self.params:
+            p.requires_grad_(flag)
+
+
+class ArenaAdam(object):
+    """torch.optim.Adam(params, lr, betas) semantics on a ParamArena: one fused launch."""
+
+    def __init__(self, arena, lr, betas=(0.5, 0.999), eps=1e-8):
+        self.arena = arena
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.param_groups = [{"params": arena.params, "lr": lr, "betas": betas, "eps": eps}]
+
+    def zero_grad(self):
+        self.arena.zero_grad()
+
+    def step(self, grad_scale=1.0):
+        a = self.arena
+        a.sync_grads()
+        a.step_count += 1
+        ops.adam_step_(a.flat, a.grad, a.exp_avg, a.exp_avg_sq, self.param_groups[0]["lr"],
+                       self.betas[0], self.betas[1], self.eps, a.step_count, grad_scale=grad_scale,
+                       n=a.n)
+
+    def state_dict(self):
+        return {"step": self.arena.step_count, "exp_avg": self.arena.exp_avg,
+                "exp_avg_sq": self.arena.exp_avg_sq}
+
+
+def _dist_on():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+# ---------------------------------------------------------------------------------------------
+# trainer
+# ---------------------------------------------------------------------------------------------
+class condGANTrainer(object):
+    def __init__(self, output_dir, data_loader, dataset, device=None):
+        if cfg.TRAIN.FLAG and output_dir:
+            self.model_dir = os.path.join(output_dir, 'Model')
+            self.image_dir = os.path.join(output_dir, 'Image')
+            self.score_dir = os.path.join(output_dir, 'Score')
+            for d in (self.model_dir, self.image_dir, self.score_dir):
+                mkdir_p(d)
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.batch_size = cfg.TRAIN.BATCH_SIZE
+        self.max_epoch = cfg.TRAIN.MAX_EPOCH
+        self.snapshot_interval = cfg.TRAIN.SNAPSHOT_INTERVAL
+        self.print_interval = cfg.TRAIN.PRINT_INTERVAL
+        self.data_loader = data_loader
+        self.dataset = dataset
+        self.num_batches = len(data_loader) if data_loader is not None else 0
+        self.num_classes = getattr(dataset, "num_classes", None) or len(getattr(dataset, "cats_index_dict", range(80)))
+        self.text_encoder = getattr(dataset, "text_encoder", None)
+        self.image_encoder = getattr(dataset, "image_encoder", None)
+        self.inception_model = getattr(dataset, "inception_model", None)
+        self.rank = dist.get_rank() if _dist_on() else 0
+        self.world = dist.get_world_size() if _dist_on() else 1
+        self.is_stream = torch.cuda.Stream(device=self.device) if self.inception_model is not None else None
+
+    # ---- model / optimizer construction ---------------------------------------------------------
+    def build_models(self):
+        """-> [text_encoder, image_encoder, netG, netsPatD, netsShpD, netObjSSD, netObjLSD, epoch]
+        (reference trainer.py:75-195).  The frozen encoders come from the dataset object (they
+        are outside the kernel scope of this round); checkpoints named like the reference's
+        (netG_epoch_%d.pth, netPatD%d.pth, ...) are loaded when cfg.TRAIN.NET_G is set."""
+        nc = self.num_classes
+        netG = G_NET(nc)
+        netsPatD, netsShpD = [], []
+        pat_cls = (PAT_D_NET64, PAT_D_NET128, PAT_D_NET256)
+        shp_cls = (SHP_D_NET64, SHP_D_NET128, SHP_D_NET256)
+        for i in range(cfg.TREE.BRANCH_NUM):
+            netsPatD.append(pat_cls[i]())
+            netsShpD.append(shp_cls[i](nc))
+        netObjSSD, netObjLSD = OBJ_SS_D_NET(nc), OBJ_LS_D_NET(nc)
+        nets = [netG] + netsPatD + netsShpD + [netObjSSD, netObjLSD]
+        for net in nets:
+            net.apply(weights_init)
+        epoch = 0
+        if cfg.TRAIN.NET_G != '':
+            sd = torch.load(cfg.TRAIN.NET_G, map_location="cpu")
+            netG.load_state_dict(sd)
+            name = cfg.TRAIN.NET_G
+            epoch = int(name[name.rfind('_') + 1:name.rfind('.')]) + 1
+            base = name[:name.rfind('/')]
+            for i, d in enumerate(netsPatD):
+                d.load_state_dict(torch.load('%s/netPatD%d.pth' % (base, i), map_location="cpu"))
+            for i, d in enumerate(netsShpD):
+                d.load_state_dict(torch.load('%s/netShpD%d.pth' % (base, i), map_location="cpu"))
+            netObjSSD.load_state_dict(torch.load('%s/netObjSSD.pth' % base, map_location="cpu"))
+            netObjLSD.load_state_dict(torch.load('%s/netObjLSD.pth' % base, map_location="cpu"))
+        for net in nets:
+            net.to(self.device).train()
+        if self.world > 1:      # identical replicas: rank 0's weights everywhere
+            for net in nets:
+                for t in list(net.parameters()) + list(net.buffers()):
+                    dist.broadcast(t.data, src=0)
+        return [self.text_encoder, self.image_encoder, netG, netsPatD, netsShpD, netObjSSD,
+                netObjLSD, epoch]
+
+    def define_optimizers(self, netG, netsPatD, netsShpD, netObjSSD, netObjLSD):
+        d_lr, g_lr = cfg.TRAIN.DISCRIMINATOR_LR, cfg.TRAIN.GENERATOR_LR
+        optimizersPatD = [ArenaAdam(ParamArena(d), d_lr) for d in netsPatD]
+        optimizersShpD = [ArenaAdam(ParamArena(d), d_lr) for d in netsShpD]
+        optimizerObjSSD = ArenaAdam(ParamArena(netObjSSD), d_lr)
+        optimizerObjLSD = ArenaAdam(ParamArena(netObjLSD), d_lr)
+        optimizerG = ArenaAdam(ParamArena(netG), g_lr)
+        return optimizerG, optimizersPatD, optimizersShpD, optimizerObjSSD, optimizerObjLSD
+
+    def prepare_labels(self):
+        return torch.arange(self.batch_size, dtype=torch.long, device=self.device)
+
+    def setup(self):
+        """Build networks, arenas, the EMA copy and the per-run constants."""
+        (self.text_encoder, self.image_encoder, self.netG, self.netsPatD, self.netsShpD,
+         self.netObjSSD, self.netObjLSD, self.start_epoch) = self.build_models()
+        (self.optimizerG, self.optimizersPatD, self.optimizersShpD, self.optimizerObjSSD,
+         self.optimizerObjLSD) = self.define_optimizers(self.netG, self.netsPatD, self.netsShpD,
+                                                        self.netObjSSD, self.netObjLSD)
+        self.avg_param_G = self.optimizerG.arena.flat.clone()      # EMA of G, flat
+        self.match_labels = self.prepare_labels()
+        self.noise = torch.empty(self.batch_size, cfg.GAN.Z_DIM, device=self.device)
+        self.gen_iterations = 0
+        return self
+
+    def _d_optimizers(self):
+        return self.optimizersPatD + self.optimizersShpD + [self.optimizerObjSSD, self.optimizerObjLSD]
+
+    # ---- gradient exchange ------------------------------------------------------------------------
+    def _reduce_async(self, opt):
+        """One RCCL all-reduce (sum) of a network's flat gradient arena; averaging is folded
+        into the Adam kernel's grad_scale."""
+        if self.world == 1:
+            return None
+        opt.arena.sync_grads()
+        return dist.all_reduce(opt.arena.grad, op=dist.ReduceOp.SUM, async_op=True)
+
+    # ---- one iteration (reference trainer.py:357-472) -----------------------------------------------
+    def train_step(self, batch, noise=None, want_logs=False):
+        """batch: dict with imgs[3], hmaps[3], rois[3], fm_rois, num_rois, bt_masks[2], fm_bt_masks,
+        words_embs, sent_emb, glove_words_embs, mask, clabels_emb, cap_lens, class_ids (see
+        synth_batch.py).  Returns a dict of loss tensors (no host sync unless want_logs)."""
+        b = batch
+        imgs, hmaps, rois = b["imgs"], b["hmaps"], b["rois"]
+        fm_rois, num_rois = b["fm_rois"], b["num_rois"]
+        words_embs, sent_emb = b["words_embs"], b["sent_emb"]
+        clabels_emb = b["clabels_emb"]
+        inv_world = 1.0 / self.world
+        out = {}
+
+        # (1) text-side inputs
+        clabels_feat = form_clabels_feat(clabels_emb, rois[0], num_rois)
+        # (2) generate fake images
+        if noise is None:
+            self.noise.normal_(0, 1)
+            noise = self.noise
+        glb_max_num_roi = int(torch.max(num_rois))
+        fake_imgs, bt_c_codes, _, _, mu, logvar = self.netG(
+            noise, sent_emb, words_embs, b["glove_words_embs"], clabels_feat, b["mask"], hmaps, rois,
+            fm_rois, num_rois, b["bt_masks"], b["fm_bt_masks"], glb_max_num_roi)
+        bt_c_codes = [c.detach() for c in bt_c_codes]
+
+        pending = []
+        # (3-1) patch discriminators
+        for i, opt in enumerate(self.optimizersPatD):
+            opt.zero_grad()
+            err = patD_loss(self.netsPatD[i], imgs[i], fake_imgs[i], sent_emb)
+            err.backward()
+            pending.append((opt, self._reduce_async(opt), True))
+            out["errPatD%d" % i] = err.detach()
+        # (3-2) shape discriminators
+        for i, opt in enumerate(self.optimizersShpD):
+            opt.zero_grad()
+            err = shpD_loss(self.netsShpD[i], imgs[i], fake_imgs[i], hmaps[i], rois[i], num_rois)
+            err.backward()
+            pending.append((opt, self._reduce_async(opt), True))
+            out["errShpD%d" % i] = err.detach()
+        # (3-3/3-4) object discriminators; the reference updates only `if float(err) > 0`, i.e.
+        # when at least one box of the wanted scale exists (BCE of a sigmoid is > 0 otherwise)
+        for name, net, opt, r, large in (("errObjSSD", self.netObjSSD, self.optimizerObjSSD, rois[0], False),
+                                          ("errObjLSD", self.netObjLSD, self.optimizerObjLSD, fm_rois, True)):
+            opt.zero_grad()
+            err = objD_loss(net, imgs[-1], fake_imgs[-1], hmaps[-1], clabels_emb, bt_c_codes[-1], r,
+                            num_rois, is_large_scale=large)
+            active = torch.is_tensor(err)
+            if active:
+                err.backward()
+                opt.arena.grad[-1] = 1.0            # "this rank has a gradient" flag
+                out[name] = err.detach()
+            pending.append((opt, self._reduce_async(opt), active))
+
+        # discriminator Adam steps (after their reductions; they overlapped the later Ds)
+        for opt, handle, active in pending:
+            if handle is not None:
+                handle.wait()
+                active = bool(opt.arena.grad[-1].item() > 0)     # any rank active -> all ranks step
+            if active:
+                opt.step(grad_scale=inv_world)
+
+        # (4) generator: maximise log(D(G(z))) + DAMSM + KL, discriminators frozen
+        d_opts = self._d_optimizers()
+        for opt in d_opts:
+            opt.arena.set_requires_grad(False)
+        self.optimizerG.zero_grad()
+        errG_total, G_logs = G_loss(self.netsPatD, self.netsShpD, self.netObjSSD, self.netObjLSD,
+                                    self.image_encoder, fake_imgs, hmaps, words_embs, sent_emb,
+                                    clabels_emb, bt_c_codes[-1], self.match_labels, b["cap_lens"],
+                                    b["class_ids"], rois[0], fm_rois, num_rois) \
+            if want_logs else _g_loss_quiet(self, fake_imgs, hmaps, words_embs, sent_emb, clabels_emb,
+                                            bt_c_codes[-1], b, rois, fm_rois, num_rois)
+        kl = KL_loss(mu, logvar)
+        errG_total = errG_total + kl
+        errG_total.backward()
+        for opt in d_opts:
+            opt.arena.set_requires_grad(True)
+        h = self._reduce_async(self.optimizerG)
+        if h is not None:
+            h.wait()
+        self.optimizerG.step(grad_scale=inv_world)
+        ops.ema_update_(self.avg_param_G, self.optimizerG.arena.flat, 0.999)
+        out["errG"] = errG_total.detach()
+        out["kl"] = kl.detach()
+        out["fake_imgs"] = [f.detach() for f in fake_imgs]
+        if want_logs:
+            out["G_logs"] = G_logs
+
+        # (5) Inception-score monitor on a side stream (no data dependence on the update)
+        if self.inception_model is not None:
+            self.is_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.is_stream), torch.no_grad():
+                out["is_pred"] = self.inception_model(out["fake_imgs"][-1])
+        self.gen_iterations += 1
+        return out
+
+    # ---- checkpoints (reference trainer.py:251-273) ---------------------------------------------------
+    def save_model(self, netG, avg_param_G, netsPatD, netsShpD, netObjSSD, netObjLSD, epoch):
+        if self.rank != 0:
+            return
+        arena = self.optimizerG.arena
+        backup = arena.flat.clone()
+        arena.flat.copy_(avg_param_G)                 # G is saved with the EMA weights swapped in
+        torch.save(netG.state_dict(), '%s/netG_epoch_%d.pth' % (self.model_dir, epoch))
+        arena.flat.copy_(backup)
+        for i, d in enumerate(netsPatD):
+            torch.save(d.state_dict(), '%s/netPatD%d.pth' % (self.model_dir, i))
+        for i, d in enumerate(netsShpD):
+            torch.save(d.state_dict(), '%s/netShpD%d.pth' % (self.model_dir, i))
+        torch.save(netObjSSD.state_dict(), '%s/netObjSSD.pth' % self.model_dir)
+        torch.save(netObjLSD.state_dict(), '%s/netObjLSD.pth' % self.model_dir)
+
+    # ---- epoch loop -------------------------------------------------------------------------------------
+    def train(self):
+        self.setup()
+        for epoch in range(self.start_epoch, self.max_epoch):
+            start_t = time.time()
+            predictions = []
+            for step, batch in enumerate(self.data_loader):
+                log_now = (self.gen_iterations + 1) % self.print_interval == 0
+                out = self.train_step(batch, want_logs=log_now)
+                if "is_pred" in out:
+                    predictions.append(out["is_pred"])
+                if log_now and self.rank == 0:
+                    msg = ' '.join('%s: %.2f' % (k, float(v)) for k, v in out.items()
+                                   if torch.is_tensor(v) and v.dim() == 0)
+                    print('[%d/%d][%d] %s %s' % (epoch, self.max_epoch, self.gen_iterations, msg,
+                                                 out.get("G_logs", "")))
+            if self.rank == 0:
+                print('[%d/%d] time: %.2fs' % (epoch, self.max_epoch, time.time() - start_t))
+            if epoch % self.snapshot_interval == 0:
+                self.save_model(self.netG, self.avg_param_G, self.netsPatD, self.netsShpD,
+                                self.netObjSSD, self.netObjLSD, epoch)
+        self.save_model(self.netG, self.avg_param_G, self.netsPatD, self.netsShpD, self.netObjSSD,
+                        self.netObjLSD, self.max_epoch)
+
+
+def _g_loss_quiet(tr, fake_imgs, hmaps, words_embs, sent_emb, clabels_emb, bt_c, b, rois, fm_rois,
+                  num_rois):
+    """G_loss without building the log string (no .item() host syncs on non-print steps)."""
+    import miscc.losses as L
+    total, _ = L.G_loss(tr.netsPatD, tr.netsShpD, tr.netObjSSD, tr.netObjLSD, tr.image_encoder,
+                        fake_imgs, hmaps, words_embs, sent_emb, clabels_emb, bt_c, tr.match_labels,
+                        b["cap_lens"], b["class_ids"], rois[0], fm_rois, num_rois, quiet=True)
+    return total, ''

@@ -1,0 +1,253 @@
+"""CPU tests (no GPU): the oracle is pinned against the reference and its golden vectors, the
+C-ABI library loads and exports every declared symbol, and the host-side logic behaves."""
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, rel_l2
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _golden():
+    return torch.load(os.path.join(GOLD, "step_b2.pt"), weights_only=False)
+
+
+def _seeded_sd(keys_like, seed):
+    """state dict filled BY KEY exactly like oracle.ref_harness.seeded_state_ (needs the module's
+    keys/shapes: taken from the product modules, whose state-dict layout equals the reference's)."""
+    from oracle import ref_harness as rh
+    rh.seeded_state_(keys_like, seed)
+    return {k: v.clone() for k, v in keys_like.state_dict().items()}
+
+
+def _oracle_nets(g):
+    """oracle state dicts for every network, seeded like tests/golden/make_golden.py"""
+    import model as M
+    s = g["seeds"]
+    sds = {"G": _seeded_sd(M.G_NET(80), s["G"]),
+           "pat": [_seeded_sd(c(), s["pat"] + i) for i, c in enumerate((M.PAT_D_NET64, M.PAT_D_NET128, M.PAT_D_NET256))],
+           "shp": [_seeded_sd(c(80), s["shp"] + i) for i, c in enumerate((M.SHP_D_NET64, M.SHP_D_NET128, M.SHP_D_NET256))],
+           "objss": _seeded_sd(M.OBJ_SS_D_NET(80), s["objss"]),
+           "objls": _seeded_sd(M.OBJ_LS_D_NET(80), s["objls"])}
+    return sds
+
+
+def _req(sd):
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running_" not in k:
+            v.requires_grad_(True)
+    return sd
+
+
+def test_roi_oracle_matches_reference_golden_vectors():
+    from oracle import roi
+    z = np.load(os.path.join(GOLD, "roi_align_ref.npz"))
+    got = roi.forward(z["feat"], z["rois"], 6, 6, 1 / 16.0)
+    assert np.array_equal(got.view(np.uint32), z["out"].view(np.uint32))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference tree not present")
+def test_roi_oracle_bit_exact_with_reference_c_loop():
+    from oracle import roi
+    roi.build()
+    rng = np.random.RandomState(3)
+    for trial in range(12):
+        H, W = rng.randint(4, 40), rng.randint(4, 40)
+        feat = rng.randn(3, 4, H, W).astype(np.float32)
+        rois = np.zeros((24, 5), np.float32)
+        rois[:, 0] = rng.randint(0, 3, 24)
+        sc = [1 / 16., 1.0, 0.5][trial % 3]
+        xy = rng.uniform(-5, W / sc, (24, 2)); wh = rng.uniform(0, W / sc, (24, 2))
+        rois[:, 1:3] = xy; rois[:, 3:5] = xy + wh
+        if trial % 2 == 0:
+            rois[:, 1:] = np.round(rois[:, 1:])
+        ah, aw = [(6, 6), (2, 2), (7, 5)][trial % 3]
+        a = roi.forward(feat, rois, ah, aw, sc)
+        b = roi.reference_forward(feat, rois, ah, aw, sc)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), trial
+
+
+def test_roi_backward_oracle_is_adjoint_of_forward():
+    """the restated CUDA backward is the transpose of the (linear in features) forward"""
+    from oracle import roi
+    rng = np.random.RandomState(9)
+    feat = rng.randn(2, 3, 16, 16).astype(np.float32)
+    rois = np.array([[0, 3, 4, 100, 90], [1, 0, 0, 255, 255], [1, 17.5, 30.25, 60, 80]], np.float32)
+    g = rng.randn(3, 3, 6, 6).astype(np.float32)
+    lhs = float((roi.forward(feat, rois, 6, 6, 1 / 16.) * g).sum())
+    rhs = float((roi.backward(g, rois, feat.shape, 1 / 16.) * feat).sum())
+    assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
+
+
+def test_oracle_generator_matches_reference_golden():
+    from oracle import torch_model as tm
+    import synth_batch
+    g = _golden()
+    b = synth_batch.make_batch(g["B"], seed=g["seeds"]["batch"])
+    sds = _oracle_nets(g)
+    cl = tm.form_clabels_feat(b["clabels_emb"], b["rois"][0], b["num_rois"])
+    with torch.no_grad():
+        fake, bt, atts, bt_atts, mu, logvar = tm.g_net(
+            sds["G"], b["noise"], b["sent_emb"], b["words_embs"], b["glove_words_embs"], cl, b["mask"],
+            b["hmaps"], b["rois"], b["fm_rois"], b["num_rois"], b["bt_masks"], b["fm_bt_masks"],
+            int(b["num_rois"].max()), b["ca_eps"])
+    assert rel_l2(fake[0], g["fake64"]) < 1e-5
+    assert rel_l2(fake[1], g["fake128"]) < 1e-5
+    assert rel_l2(fake[2][:, :, ::2, ::2], g["fake256_s2"]) < 1e-5
+    assert rel_l2(bt[1], g["bt_c_codes"][1]) < 1e-5
+    assert rel_l2(atts[1][:, :, ::4, ::4], g["att128_s4"]) < 1e-5
+    assert rel_l2(bt_atts[0][:, :, ::2, ::2], g["bt_att64_s2"]) < 1e-5
+    assert rel_l2(mu, g["mu"]) < 1e-6
+
+
+def test_oracle_losses_match_reference_golden():
+    from oracle import torch_model as tm
+    import synth_batch
+    import encoders
+    from oracle import ref_harness as rh
+    g = _golden()
+    s = g["seeds"]
+    b = synth_batch.make_batch(g["B"], seed=s["batch"])
+    sds = _oracle_nets(g)
+    for k in ("pat", "shp"):
+        sds[k] = [_req(x) for x in sds[k]]
+    _req(sds["objss"]); _req(sds["objls"]); _req(sds["G"])
+    cl = tm.form_clabels_feat(b["clabels_emb"], b["rois"][0], b["num_rois"])
+    fake, bt, _, _, mu, logvar = tm.g_net(sds["G"], b["noise"], b["sent_emb"], b["words_embs"],
+                                          b["glove_words_embs"], cl, b["mask"], b["hmaps"], b["rois"],
+                                          b["fm_rois"], b["num_rois"], b["bt_masks"], b["fm_bt_masks"],
+                                          int(b["num_rois"].max()), b["ca_eps"])
+    btd = [c.detach() for c in bt]
+
+    def gnorms(sd):
+        return {k: (v.grad.norm().item() if v.grad is not None else 0.0) for k, v in sd.items() if v.requires_grad}
+
+    def check_grads(sd, want, tol=2e-3):
+        got = gnorms(sd)
+        for k, w in want.items():
+            assert abs(got[k] - w) <= tol * max(w, 1e-6) + 1e-7, (k, got[k], w)
+
+    for i in range(3):
+        e = tm.pat_d_loss(sds["pat"][i], b["imgs"][i], fake[i], b["sent_emb"])
+        e.backward()
+        assert abs(e.item() - g["errPatD%d" % i]) < 1e-5
+        check_grads(sds["pat"][i], g["gradPatD%d" % i])
+    for i in range(3):
+        random.seed(100 + i)
+        e = tm.shp_d_loss(sds["shp"][i], b["imgs"][i], fake[i], b["hmaps"][i], b["rois"][i], b["num_rois"])
+        e.backward()
+        assert abs(e.item() - g["errShpD%d" % i]) < 1e-5
+        check_grads(sds["shp"][i], g["gradShpD%d" % i])
+    random.seed(200)
+    e = tm.obj_d_loss(sds["objss"], 3, b["imgs"][-1], fake[-1], b["hmaps"][-1], b["clabels_emb"], btd[-1],
+                      b["rois"][0], b["num_rois"], False)
+    e.backward()
+    assert abs(e.item() - g["errObjSSD"]) < 1e-5
+    check_grads(sds["objss"], g["gradObjSSD"])
+    random.seed(201)
+    e = tm.obj_d_loss(sds["objls"], 4, b["imgs"][-1], fake[-1], b["hmaps"][-1], b["clabels_emb"], btd[-1],
+                      b["fm_rois"], b["num_rois"], True)
+    e.backward()
+    assert abs(e.item() - g["errObjLSD"]) < 1e-5
+    check_grads(sds["objls"], g["gradObjLSD"])
+
+    enc = encoders.CNN_ENCODER(256, encoders.seeded_init_(encoders.inception_v3(), s["inception"]))
+    rh.seeded_state_(enc.emb_features, s["enc_proj"]); rh.seeded_state_(enc.emb_cnn_code, s["enc_proj"] + 1)
+    enc.eval()
+    for k in ("pat", "shp"):
+        for sd in sds[k]:
+            for v in sd.values():
+                v.grad = None
+    labels = torch.arange(g["B"])
+    total, parts = tm.g_loss(sds, enc, fake, b["hmaps"], b["words_embs"], b["sent_emb"], b["clabels_emb"],
+                             btd[-1], labels, b["cap_lens"], b["class_ids"], b["rois"], b["fm_rois"],
+                             b["num_rois"])
+    kl = tm.kl_loss(mu, logvar)
+    (total + kl).backward()
+    assert abs((total + kl).item() - g["errG"]) < 1e-3 * g["errG"]
+    assert abs(kl.item() - g["kl"]) < 1e-6
+    assert abs(parts["w_loss"].item() / 100 - g["w_loss"]) < 1e-4
+    assert abs(parts["s_loss"].item() / 100 - g["s_loss"]) < 1e-4
+    check_grads(sds["G"], g["gradG"], tol=5e-3)
+    assert rel_l2(sds["G"]["img_net3.img.0.weight"].grad, g["gradG_img3_w"]) < 1e-3
+    assert rel_l2(sds["G"]["h_net3_main.att.conv_context.weight"].grad, g["gradG_att_ctx_w"]) < 1e-3
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    """include/objgan_hip.h <-> libobjgan_hip.so <-> ctypes table agree (no compute calls)."""
+    from objgan_hip import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "objgan_hip.h")).read()
+    declared = set(re.findall(r"\b(objgan_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    table = set(_lib.SIGNATURES) | set(_lib.LONG_RETURN)
+    assert declared == table, declared ^ table
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.objgan_conv_packed_floats(388, 1746) == 512 * 1760
+
+
+def test_state_dict_keys_match_reference_contract():
+    import model as M
+    keys = set(M.G_NET(80).state_dict().keys())
+    for k in ("ca_net.fc.weight", "h_net1_sent.fc.0.weight", "h_net1_sent.fc.1.running_mean",
+              "h_net1_sent.upsample1.1.weight", "h_net1_sent.upsample2.2.bias",
+              "h_net1_hmap.conv3x3.1.bias", "h_net2_hmap.downsample1.0.weight",
+              "h_net1_main.bt_att.conv_context.weight", "h_net3_main.att.conv_context.weight",
+              "h_net2_main.residual.2.block.1.weight", "h_net1_main.residual.6.block.5.weight",
+              "h_net3_main.upsample.1.weight", "img_net3.img.0.weight"):
+        assert k in keys, k
+    assert sum(p.numel() for p in M.G_NET(80).parameters()) == 19344452
+    d = M.OBJ_LS_D_NET(80).state_dict()
+    for k in ("img_code.0.weight", "img_code.9.running_var", "shp_code.1.bias", "roi_code.0.weight",
+              "COND_DNET.jointConv.0.weight", "COND_DNET.outlogits.0.bias", "UNCOND_DNET.outlogits.0.weight"):
+        assert k in d, k
+    assert sum(p.numel() for p in M.PAT_D_NET256().parameters()) == 13304450
+    assert sum(p.numel() for p in M.SHP_D_NET64(80).parameters()) == 6239821
+    assert sum(p.numel() for p in M.OBJ_SS_D_NET(80).parameters()) == 5545934
+    assert sum(p.numel() for p in M.OBJ_LS_D_NET(80).parameters()) == 12625358
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference tree not present")
+def test_reference_and_product_state_dicts_are_identical_in_layout():
+    from oracle import ref_harness as rh
+    import model as M
+    ref = rh.load_reference(3, 2)
+    for mine, theirs in ((M.G_NET(80), ref.model.G_NET(80)), (M.PAT_D_NET64(), ref.model.PAT_D_NET64()),
+                         (M.SHP_D_NET256(80), ref.model.SHP_D_NET256(80)),
+                         (M.OBJ_SS_D_NET(80), ref.model.OBJ_SS_D_NET(80)),
+                         (M.OBJ_LS_D_NET(80), ref.model.OBJ_LS_D_NET(80))):
+        a = {k: tuple(v.shape) for k, v in mine.state_dict().items()}
+        b = {k: tuple(v.shape) for k, v in theirs.state_dict().items()}
+        assert a == b
+
+
+def test_product_path_refuses_to_run_without_gpu():
+    from objgan_hip import ops, ObjganHipError
+    with pytest.raises(ObjganHipError):
+        ops.roi_align(torch.zeros(1, 2, 8, 8), torch.zeros(1, 5), 6, 6, 1.0)
+    with pytest.raises(ObjganHipError):
+        ops.norm_act(torch.zeros(1, 2, 4, 4))
+
+
+def test_feat_select_and_permute_seg_host_logic():
+    from miscc.utils import feat_select, permute_seg
+    from oracle import torch_model as tm
+    import synth_batch
+    b = synth_batch.make_batch(4, seed=3)
+    pooled = torch.randn(4, 10, 8, 4, 4)
+    raw = torch.randn(4, 10, 48)
+    for large in (False, True):
+        f1, c1, b1 = feat_select(pooled, raw, b["fm_rois"], b["num_rois"], large)
+        f2, c2, b2 = tm.feat_select(pooled, raw, b["fm_rois"], b["num_rois"], large)
+        assert torch.equal(f1, f2) and torch.equal(c1, c2) and torch.equal(b1, b2)
+    random.seed(5)
+    s1, v1 = permute_seg(b["hmaps"][0], b["rois"][0], b["num_rois"])
+    random.seed(5)
+    s2, v2 = tm.permute_seg(b["hmaps"][0], b["rois"][0], b["num_rois"])
+    assert v1 == v2 and torch.equal(s1, s2)
