@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""Benchmark of the Obj-GAN image_generation G+D training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one full iteration of the reference's training loop (reference
+image_generation/trainer.py:357-472) on one synthetic COCO-shaped minibatch: three-stage G_NET
+forward at 256x256, the three patch and three shape discriminators, the two ROIAlign object
+discriminators, generator loss with DAMSM + KL, nine Adam updates and the generator EMA (and the
+per-step Inception-score monitor on a side stream, as in the reference).  Per-GPU batch 16; under
+`--gpus N` (launched by torch.distributed.run, one rank per GPU, RCCL) every rank steps its own
+batch and gradients are all-reduced: weak scaling, value = N * 16 * steps / time.
+
+One JSON line is printed by rank 0: the contract fields plus
+  roofline      the dominant kernel (MFMA implicit-GEMM conv, 128x128 tile, 3x3 taps): algorithmic
+                flops of its launches / their hipEvent-measured duration, against the fp32 MFMA peak
+  cpu_baseline  the CPU oracle (oracle/torch_model.py, a port of the reference path) timed on this
+                host's cores on a bounded sample (one step at batch 4)
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "obj-gan_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch                                    # noqa: E402
+import torch.distributed as dist                # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3                   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+CAT_NAMES = (["igemm_T%d_%s" % (t, c) for t in (1, 4, 9, 16) for c in ("128x128", "64x256", "32x256")] +
+             ["wgrad_k%d_%s" % (k, c) for k in (1, 3, 4) for c in ("128x128", "64x256", "32x256")])
+
+
+def build_trainer(device, batch_size, seed, with_is_monitor=True):
+    import encoders
+    import trainer as T
+    from miscc.config import cfg
+    cfg.TREE.BRANCH_NUM = 3
+    cfg.TRAIN.BATCH_SIZE = batch_size
+    cfg.TRAIN.NET_G = ''
+    torch.manual_seed(seed)                     # same initial weights on every rank
+
+    class SynthDataset(object):
+        num_classes = 80
+    ds = SynthDataset()
+    trunk = encoders.seeded_init_(encoders.inception_v3(), 1)
+    ds.image_encoder = encoders.CNN_ENCODER(256, trunk).to(device).eval()
+    for p in ds.image_encoder.parameters():
+        p.requires_grad_(False)
+    if with_is_monitor:
+        ds.inception_model = encoders.INCEPTION_V3(trunk).to(device).eval()
+    tr = T.condGANTrainer('', None, ds, device=device)
+    tr.batch_size = batch_size
+    tr.setup()
+    return tr
+
+
+def cpu_baseline(sample_batch=4, seed=1234):
+    """The oracle (CPU port of the reference step) on the host cores: one step at a small batch."""
+    import model as M
+    import encoders
+    import synth_batch
+    from miscc.config import cfg
+    from miscc.utils import weights_init
+    from oracle import torch_model as tm
+    cfg.TREE.BRANCH_NUM = 3
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(seed)
+
+    def sd_of(m):
+        m.apply(weights_init)
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        for k, v in sd.items():
+            if v.dtype.is_floating_point and "running_" not in k:
+                v.requires_grad_(True)
+        return sd
+    sds = {"G": sd_of(M.G_NET(80)),
+           "pat": [sd_of(c()) for c in (M.PAT_D_NET64, M.PAT_D_NET128, M.PAT_D_NET256)],
+           "shp": [sd_of(c(80)) for c in (M.SHP_D_NET64, M.SHP_D_NET128, M.SHP_D_NET256)],
+           "objss": sd_of(M.OBJ_SS_D_NET(80)), "objls": sd_of(M.OBJ_LS_D_NET(80))}
+    adam = lambda sd: torch.optim.Adam(tm.params_of(sd), lr=2e-4, betas=(0.5, 0.999))   # noqa: E731
+    opts = {"G": adam(sds["G"]), "pat": [adam(s) for s in sds["pat"]], "shp": [adam(s) for s in sds["shp"]],
+            "objss": adam(sds["objss"]), "objls": adam(sds["objls"])}
+    ema = [p.detach().clone() for p in tm.params_of(sds["G"])]
+    enc = encoders.CNN_ENCODER(256, encoders.seeded_init_(encoders.inception_v3(), 1)).eval()
+    batch = synth_batch.make_batch(sample_batch, seed=seed)
+    t0 = time.time()
+    tm.train_step(sds, opts, ema, batch, image_encoder=enc)
+    dt = time.time() - t0
+    return {"value": round(sample_batch / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "1 full G+D step at batch %d (same networks, 256x256), %.1f s" % (sample_batch, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-is-monitor", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    import synth_batch
+    from objgan_hip import _lib
+    tr = build_trainer(device, args.batch, seed=1234, with_is_monitor=not args.no_is_monitor)
+    batch = synth_batch.make_batch(args.batch, seed=1234 + rank, device=device)   # per-rank data shard
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.train_step(batch)
+    lib = _lib.load()
+    timing = (rank == 0) and not args.no_kernel_timing
+    barrier()
+    if timing:
+        lib.objgan_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.train_step(batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    if timing:
+        lib.objgan_prof_enable(0)
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        n_img = args.batch * world * args.steps
+        res = {
+            "metric": "G+D train-step images/sec at 256x256, batch 16 per GPU",
+            "value": round(n_img / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp32", "data": "synthetic",
+            "config": {"workload": "stage3_256x256_full_GD_step: G_NET(3 stages)+PatD x3+ShpD x3+"
+                                   "ObjSSD+ObjLSD(ROIAlign)+DAMSM+KL+Adam x9+EMA"
+                                   + ("" if args.no_is_monitor else "+IS-monitor"),
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                       "parallelism": "dp%d" % world},
+        }
+        if timing:
+            ms = (ctypes.c_double * 32)()
+            fl = (ctypes.c_double * 32)()
+            cnt = (ctypes.c_long * 32)()
+            lib.objgan_prof_collect(ms, fl, cnt)
+            cats = [(CAT_NAMES[i], ms[i], fl[i], cnt[i]) for i in range(len(CAT_NAMES)) if cnt[i] > 0]
+            cats.sort(key=lambda c: -c[1])
+            if cats:
+                name, tms, tfl, n = cats[0]
+                ach = tfl / (tms * 1e-3) / 1e12
+                res["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2),
+                                   "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                                   "launches": int(n), "avg_launch_ms": round(tms / n, 4),
+                                   "share_of_step": round(tms / (1000.0 * dt), 4)}
+                res["kernel_breakdown"] = [
+                    {"kernel": c[0], "ms_per_step": round(c[1] / args.steps, 3),
+                     "tflops": round(c[2] / (c[1] * 1e-3) / 1e12, 2), "launches_per_step": c[3] // args.steps}
+                    for c in cats[:8]]
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -123,6 +123,10 @@ int objgan_adam_step(float* p, const float* g, float* m, float* v, long n, float
 int objgan_ema_update(float* avg, const float* p, long n, float decay, float one_minus_decay,
                       void* stream);
 
+/* ---- measurement aid (bench.py roofline leg): hipEvent-bracketed conv launches ------------------ */
+int objgan_prof_enable(int on);
+int objgan_prof_collect(double* ms, double* flops, long* count);   /* arrays of 32 categories */
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,7 @@
 // consecutive lanes on consecutive pixels (coalesced along W).  Workgroup ids are
 // remapped so that the M-tiles sharing one pixel tile run on the same XCD (shared L2).
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -442,6 +443,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     }
 }
 
+// ---- optional per-launch timing (bench.py's roofline leg) -------------------------------------
+// When enabled, every conv launch is bracketed by hipEvents on its own stream and tagged with a
+// category (kind, taps / ksize, tile config) and its ALGORITHMIC flops 2*M*K*Npix.  Off by default;
+// the only mutable global state of the library, touched by the host thread only.
+#define OG_PROF_CATS 32
+#define OG_PROF_MAX 16384
+struct ProfRec { hipEvent_t a, b; int cat; double flops; };
+static int g_prof_on = 0;
+static ProfRec* g_prof = nullptr;
+static int g_prof_n = 0;
+static int g_prof_made = 0;
+
+static inline int prof_cat(int wgrad, int t_or_k, int cfg) {
+    int ti = wgrad ? (t_or_k == 1 ? 0 : (t_or_k == 3 ? 1 : 2)) : (t_or_k == 1 ? 0 : (t_or_k == 4 ? 1 : (t_or_k == 9 ? 2 : 3)));
+    return (wgrad ? 12 : 0) + ti * 3 + cfg;
+}
+static inline ProfRec* prof_begin(int cat, double flops, hipStream_t s) {
+    if (!g_prof_on || g_prof_n >= OG_PROF_MAX) return nullptr;
+    if (!g_prof) g_prof = (ProfRec*)calloc(OG_PROF_MAX, sizeof(ProfRec));
+    ProfRec* r = &g_prof[g_prof_n];
+    if (g_prof_n >= g_prof_made) {
+        if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) return nullptr;
+        g_prof_made = g_prof_n + 1;
+    }
+    g_prof_n++;
+    r->cat = cat; r->flops = flops;
+    (void)hipEventRecord(r->a, s);
+    return r;
+}
+static inline void prof_end(ProfRec* r, hipStream_t s) { if (r) (void)hipEventRecord(r->b, s); }
+
 // ---- host side ---------------------------------------------------------------------------
 template <int T>
 static int launch_igemm_T(const IgemmArgs& a, int cfg, hipStream_t s) {
@@ -487,7 +519,10 @@ static int run_igemm(IgemmArgs a, int T, hipStream_t s) {
     const int np = og_row_parts(a.M, parts);
     for (int i = 0; i < np; ++i) {
         a.m_begin = parts[i].m_begin; a.m_end = parts[i].m_end;
+        const double fl = 2.0 * (a.m_end - a.m_begin) * (double)a.K * ((double)a.N * a.PH * a.PW);
+        ProfRec* pr = prof_begin(prof_cat(0, T, parts[i].cfg), fl, s);
         int rc = launch_igemm(a, T, parts[i].cfg, s);
+        prof_end(pr, s);
         if (rc != OG_OK) return rc;
     }
     return OG_OK;
@@ -586,11 +621,35 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
         if (cfg == 0) hipLaunchKernelGGL((conv_wgrad_kernel<KS, 2, 2>), grid, dim3(256), 0, s, a);       \
         else if (cfg == 1) hipLaunchKernelGGL((conv_wgrad_kernel<KS, 1, 2>), grid, dim3(256), 0, s, a);  \
         else hipLaunchKernelGGL((conv_wgrad_kernel<KS, 1, 1>), grid, dim3(256), 0, s, a);
+        ProfRec* pr = prof_begin(prof_cat(1, ksize, cfg),
+                                 2.0 * (a.m_end - a.m_begin) * (double)a.ncol * (double)Npix, s);
         if (ksize == 1) { OG_WG(1) } else if (ksize == 3) { OG_WG(3) } else { OG_WG(4) }
+        prof_end(pr, s);
 #undef OG_WG
         int rc = og_launch_status();
         if (rc != OG_OK) return rc;
     }
+    return OG_OK;
+}
+
+// ---- profiling control (see the note above the host section) ---------------------------------
+int objgan_prof_enable(int on) {
+    g_prof_on = on ? 1 : 0;
+    if (on) g_prof_n = 0;
+    return OG_OK;
+}
+
+// Sums the recorded launches per category (the caller must have synchronised the device).
+// ms, flops, count: arrays of 32.  Categories: igemm (taps 1/4/9/16) x (tile 128x128, 64x256,
+// 32x256) = 0..11, wgrad (ksize 1/3/4) x tile = 12..20.
+int objgan_prof_collect(double* ms, double* flops, long* count) {
+    for (int i = 0; i < OG_PROF_CATS; ++i) { ms[i] = 0; flops[i] = 0; count[i] = 0; }
+    for (int i = 0; i < g_prof_n; ++i) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b) != hipSuccess) continue;
+        ms[g_prof[i].cat] += t; flops[g_prof[i].cat] += g_prof[i].flops; count[g_prof[i].cat] += 1;
+    }
+    g_prof_n = 0;
     return OG_OK;
 }
 

@@ -50,6 +50,8 @@ SIGNATURES = {
     "objgan_reflect_fold": [_ptr, _ptr, _c_long, _c_int, _c_int, _ptr],
     "objgan_adam_step": [_ptr, _ptr, _ptr, _ptr, _c_long, _c_float, _c_float, _c_float, _c_float, _c_int, _c_float, _ptr],
     "objgan_ema_update": [_ptr, _ptr, _c_long, _c_float, _c_float, _ptr],
+    "objgan_prof_enable": [_c_int],
+    "objgan_prof_collect": [_ptr, _ptr, _ptr],
 }
 LONG_RETURN = {"objgan_conv_packed_floats": [_c_int, _c_int]}
 
