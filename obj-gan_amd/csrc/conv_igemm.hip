@@ -53,6 +53,7 @@ struct IgemmArgs {
     int pad_mode;        // 0 = zeros outside [0,LH)x[0,LW), 1 = reflect
     int upsample;        // 1 = source index = logical index >> 1
     int act;
+    int ksplit_steps;    // > 0: split-K -- blockIdx.y owns this many BK steps, epilogue = atomicAdd
     int tap[OG_MAX_TAPS];   // (dw << 16) | (dh & 0xffff): one scalar load per (uniform) tap
 };
 
@@ -188,16 +189,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = a.Kpad / BK;
-    load_a(0);
-    load_b(0);
+    const int nk_all = a.Kpad / BK;
+    const int kt0 = a.ksplit_steps > 0 ? blockIdx.y * a.ksplit_steps : 0;
+    const int nk = a.ksplit_steps > 0 ? min(nk_all, kt0 + a.ksplit_steps) : nk_all;
+    load_a(kt0 * BK);
+    load_b(kt0 * BK);
     store_tiles(0);
     __syncthreads();
 
     const int lrow = lane >> 5;          // k sub-index of the 32x32x2 MFMA operand
     const int lcol = lane & 31;
     int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk; ++kt) {
         const bool more = (kt + 1) < nk;
         if (more) { load_a((kt + 1) * BK); load_b((kt + 1) * BK); }
 #pragma unroll
@@ -238,9 +241,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
                 if (m < a.m_end) {
                     float v = acc[i][j][r];
-                    if (a.bias) v += a.bias[m];
-                    v = og_act(v, a.act);
-                    yb[(size_t)m * a.OHf * a.OWf] = v;
+                    if (a.ksplit_steps > 0) {
+                        atomicAdd(&yb[(size_t)m * a.OHf * a.OWf], v);   // bias/act: follow-up pass
+                    } else {
+                        if (a.bias) v += a.bias[m];
+                        v = og_act(v, a.act);
+                        yb[(size_t)m * a.OHf * a.OWf] = v;
+                    }
                 }
             }
         }
@@ -278,6 +285,17 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
             }
         }
         a.wt[i] = v;
+    }
+}
+
+// y[n, m, i] = act(y[n, m, i] + bias[m]) -- epilogue of the split-K path
+__global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias,
+                                                       long total, int M, int HW, int act) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long)gridDim.x * blockDim.x) {
+        float v = y[e];
+        if (bias) v += bias[(e / HW) % M];
+        y[e] = og_act(v, act);
     }
 }
 
@@ -475,20 +493,22 @@ static inline ProfRec* prof_begin(int cat, double flops, hipStream_t s) {
 static inline void prof_end(ProfRec* r, hipStream_t s) { if (r) (void)hipEventRecord(r->b, s); }
 
 // ---- host side ---------------------------------------------------------------------------
-template <int T>
-static int launch_igemm_T(const IgemmArgs& a, int cfg, hipStream_t s) {
+static inline int igemm_tiles(const IgemmArgs& a, int cfg) {
     const int Npix = a.N * a.PH * a.PW;
     const int rows = a.m_end - a.m_begin;
-    if (cfg == 0) {   // BM 128 x BN 128
-        const int g = og_cdiv(rows, 128) * og_cdiv(Npix, 128);
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 2, 2>), dim3(g), dim3(256), 0, s, a);
-    } else if (cfg == 1) {   // BM 64 x BN 256
-        const int g = og_cdiv(rows, 64) * og_cdiv(Npix, 256);
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 1, 2>), dim3(g), dim3(256), 0, s, a);
-    } else {   // BM 32 x BN 256
-        const int g = og_cdiv(rows, 32) * og_cdiv(Npix, 256);
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 1, 1>), dim3(g), dim3(256), 0, s, a);
-    }
+    if (cfg == 0) return og_cdiv(rows, 128) * og_cdiv(Npix, 128);
+    if (cfg == 1) return og_cdiv(rows, 64) * og_cdiv(Npix, 256);
+    return og_cdiv(rows, 32) * og_cdiv(Npix, 256);
+}
+
+template <int T>
+static int launch_igemm_T(const IgemmArgs& a, int cfg, hipStream_t s) {
+    const int g = igemm_tiles(a, cfg);
+    const int splits = a.ksplit_steps > 0 ? og_cdiv(a.Kpad / 16, a.ksplit_steps) : 1;
+    dim3 grid(g, splits);
+    if (cfg == 0) hipLaunchKernelGGL((conv_igemm_kernel<T, 2, 2>), grid, dim3(256), 0, s, a);
+    else if (cfg == 1) hipLaunchKernelGGL((conv_igemm_kernel<T, 1, 2>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<T, 1, 1>), grid, dim3(256), 0, s, a);
     return og_launch_status();
 }
 
@@ -514,9 +534,35 @@ static int og_row_parts(int M, RowPart* parts) {
     return n;
 }
 
-static int run_igemm(IgemmArgs a, int T, hipStream_t s) {
+// Small-grid / long-K launches (discriminator heads at 4x4..16x16, `outlogits` with one output
+// channel and K = 12288) would run on a handful of CUs for hundreds of serial K steps: they are
+// split along K across gridDim.y, partial tiles are accumulated with fp32 atomics into a zeroed
+// output and bias/activation are applied by a follow-up streaming pass.
+static int run_igemm(IgemmArgs a, int T, hipStream_t s, int y_prezeroed) {
     RowPart parts[3];
     const int np = og_row_parts(a.M, parts);
+    int tiles = 0;
+    for (int i = 0; i < np; ++i) {
+        a.m_begin = parts[i].m_begin; a.m_end = parts[i].m_end;
+        tiles += igemm_tiles(a, parts[i].cfg);
+    }
+    const int nk = a.Kpad / 16;
+    const bool full_cover = (a.osh == 1 && a.osw == 1 && a.PH == a.OHf && a.PW == a.OWf);
+    int splits = 1;
+    if (tiles < 128 && nk >= 16 && (full_cover || y_prezeroed)) {
+        splits = og_cdiv(512, tiles);
+        if (splits > nk / 4) splits = nk / 4;
+    }
+    const float* bias = a.bias;
+    const int act = a.act;
+    if (splits > 1) {
+        a.ksplit_steps = og_cdiv(nk, splits);
+        a.bias = nullptr; a.act = OG_ACT_NONE;
+        if (!y_prezeroed)
+            (void)hipMemsetAsync(a.y, 0, sizeof(float) * (size_t)a.N * a.M * a.OHf * a.OWf, s);
+    } else {
+        a.ksplit_steps = 0;
+    }
     for (int i = 0; i < np; ++i) {
         a.m_begin = parts[i].m_begin; a.m_end = parts[i].m_end;
         const double fl = 2.0 * (a.m_end - a.m_begin) * (double)a.K * ((double)a.N * a.PH * a.PW);
@@ -524,6 +570,12 @@ static int run_igemm(IgemmArgs a, int T, hipStream_t s) {
         int rc = launch_igemm(a, T, parts[i].cfg, s);
         prof_end(pr, s);
         if (rc != OG_OK) return rc;
+    }
+    if (splits > 1 && (bias || act != OG_ACT_NONE) && full_cover) {
+        const long total = (long)a.N * a.M * a.OHf * a.OWf;
+        hipLaunchKernelGGL(bias_act_kernel, dim3(og_stream_grid(total, 256)), dim3(256), 0, s, a.y, bias,
+                           total, a.M, a.OHf * a.OWf, act);
+        return og_launch_status();
     }
     return OG_OK;
 }
@@ -548,7 +600,7 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
                       int Tg, const int* dh, const int* dw, const int* src_tap,
                       int PH, int PW, int stride,
                       int OHf, int OWf, int osh, int osw, int ooh, int oow,
-                      int act, void* stream) {
+                      int act, int y_prezeroed, void* stream) {
     if (Tg != 1 && Tg != 4 && Tg != 9 && Tg != 16) return OG_BAD_ARGS;
     if (Torig < 1 || Torig > OG_MAX_TAPS) return OG_BAD_ARGS;
     const int M = transpose ? Cin : Cout;
@@ -575,11 +627,13 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
     a.PH = PH; a.PW = PW; a.OHf = OHf; a.OWf = OWf;
     a.osh = osh; a.osw = osw; a.ooh = ooh; a.oow = oow;
     a.stride = stride; a.pad_mode = pad_mode; a.upsample = upsample; a.act = act;
+    a.ksplit_steps = 0;
     for (int t = 0; t < OG_MAX_TAPS; ++t) {
         const int h = t < Tg ? dh[t] : 0, w_ = t < Tg ? dw[t] : 0;
         a.tap[t] = (int)(((unsigned)w_ << 16) | ((unsigned)h & 0xffffu));
     }
-    return run_igemm(a, Tg, s);
+    if (!(osh == 1 && osw == 1 && PH == OHf && PW == OWf) && (bias || act)) return OG_BAD_ARGS;
+    return run_igemm(a, Tg, s, y_prezeroed);
 }
 
 // dw must be zero-initialised by the caller (or hold a gradient to accumulate into).

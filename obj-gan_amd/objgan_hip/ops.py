@@ -54,14 +54,14 @@ def _packed_scratch(M, K, device):
 
 
 def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, transpose,
-           dh, dw, src_tap, PH, PW, stride, OHf, OWf, osh, osw, ooh, oow, act):
+           dh, dw, src_tap, PH, PW, stride, OHf, OWf, osh, osw, ooh, oow, act, y_prezeroed=0):
     Tg = len(dh)
     M = Cin if transpose else Cout
     wt = _packed_scratch(M, C * Tg, x.device)
     _lib.call("objgan_conv_igemm", _p(x), _p(w), _p(bias), _p(y), _p(wt),
               N, C, H, W, int(upsample), int(pad_mode), Cout, Cin, Torig, int(transpose),
               Tg, _iarr(dh), _iarr(dw), _iarr(src_tap), PH, PW, stride,
-              OHf, OWf, osh, osw, ooh, oow, act, _stream())
+              OHf, OWf, osh, osw, ooh, oow, act, int(y_prezeroed), _stream())
 
 
 def _pad_taps(dh, dw, st):
@@ -146,7 +146,7 @@ class _Conv2dFn(torch.autograd.Function):
             elif stride == 2:
                 if refl:
                     raise _lib.ObjganHipError("stride-2 reflect conv is not on the hot path")
-                dxl = torch.empty((N, Cin, LH, LW), dtype=_F32, device=x.device)
+                dxl = torch.zeros((N, Cin, LH, LW), dtype=_F32, device=x.device)
                 for ph in range(2):
                     khs = [kh for kh in range(k) if (ph + pad - kh) % 2 == 0]
                     PHg = (LH - ph + 1) // 2
@@ -162,7 +162,7 @@ class _Conv2dFn(torch.autograd.Function):
                             dh, dw, st = [0], [0], [-1]
                         dh, dw, st = _pad_taps(dh, dw, st)
                         _igemm(g, w, None, dxl, N, Cout, OH, OW, 0, 0, Cout, Cin, k * k, 1,
-                               dh, dw, st, PHg, PWg, 1, LH, LW, 2, 2, ph, pw, 0)
+                               dh, dw, st, PHg, PWg, 1, LH, LW, 2, 2, ph, pw, 0, y_prezeroed=1)
             else:
                 raise _lib.ObjganHipError("conv2d backward: stride %d not supported" % stride)
             if upsample:
