@@ -89,12 +89,30 @@ def main():
                             b["clabels_emb"], bt[-1], labels, b["cap_lens"], b["class_ids"], b["rois"][0],
                             b["fm_rois"], b["num_rois"])
     kl = Ls.KL_loss(mu, logvar)
-    (total + kl).backward()
+    (total + kl).backward(retain_graph=True)
     out["errG"] = (total + kl).item(); out["kl"] = kl.item(); out["G_logs"] = logs
     out["gradG"] = grad_summary(G)
     out["gradG_ca_fc_w"] = G.ca_net.fc.weight.grad.clone()
     out["gradG_att_ctx_w"] = G.h_net3_main.att.conv_context.weight.grad.clone()
     out["gradG_img3_w"] = G.img_net3.img[0].weight.grad.clone()
+    # The same with a CONSTANT image encoder (no gradient through Inception).  In fp32 the DAMSM
+    # input-gradient is ill-conditioned (a 1e-7 relative perturbation of the fake image moves it by
+    # 1.6e-3 on the reference's own CPU path), so gradient parity of the generator is pinned on this
+    # variant; the DAMSM branch is pinned separately from fixed region features.
+    G.zero_grad()
+    regions_c, code_c = enc(fake[2].detach())
+    const_enc = lambda x: (regions_c.detach(), code_c.detach())     # noqa: E731
+    total2, _ = Ls.G_loss(pats, shps, objss, objls, const_enc, fake, b["hmaps"], b["words_embs"], b["sent_emb"],
+                          b["clabels_emb"], bt[-1], labels, b["cap_lens"], b["class_ids"], b["rois"][0],
+                          b["fm_rois"], b["num_rois"])
+    (total2 + Ls.KL_loss(mu, logvar)).backward()
+    out["errG_constenc"] = (total2 + kl).item()
+    out["gradG_constenc"] = grad_summary(G)
+    out["gradG_constenc_img3_w"] = G.img_net3.img[0].weight.grad.clone()
+    out["gradG_constenc_att_ctx_w"] = G.h_net3_main.att.conv_context.weight.grad.clone()
+    out["gradG_constenc_ca_fc_w"] = G.ca_net.fc.weight.grad.clone()
+    out["gradG_constenc_res_w"] = G.h_net2_main.residual[1].block[1].weight.grad[::8, ::8].clone()
+    out["regions_s"] = regions_c.detach()[:, ::8].clone()
     # DAMSM pieces on their own
     regions, code = enc(fake[2].detach())
     w0, w1, _, _ = Ls.words_loss(regions, b["words_embs"], labels, b["cap_lens"], b["class_ids"], B)

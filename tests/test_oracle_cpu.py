@@ -168,14 +168,32 @@ def test_oracle_losses_match_reference_golden():
                              btd[-1], labels, b["cap_lens"], b["class_ids"], b["rois"], b["fm_rois"],
                              b["num_rois"])
     kl = tm.kl_loss(mu, logvar)
-    (total + kl).backward()
+    (total + kl).backward(retain_graph=True)
     assert abs((total + kl).item() - g["errG"]) < 1e-3 * g["errG"]
     assert abs(kl.item() - g["kl"]) < 1e-6
     assert abs(parts["w_loss"].item() / 100 - g["w_loss"]) < 1e-4
     assert abs(parts["s_loss"].item() / 100 - g["s_loss"]) < 1e-4
-    check_grads(sds["G"], g["gradG"], tol=5e-3)
-    assert rel_l2(sds["G"]["img_net3.img.0.weight"].grad, g["gradG_img3_w"]) < 1e-3
-    assert rel_l2(sds["G"]["h_net3_main.att.conv_context.weight"].grad, g["gradG_att_ctx_w"]) < 1e-3
+    # through the (ill-conditioned, see tests/test_modules_gpu.py::_ConstEncoder) Inception gradient
+    # only a loose bound holds even between two CPU runs of the same arithmetic
+    check_grads(sds["G"], g["gradG"], tol=5e-2)
+    # constant-encoder variant: tight
+    for v in sds["G"].values():
+        v.grad = None
+    for k in ("pat", "shp"):
+        for sd in sds[k]:
+            for v in sd.values():
+                v.grad = None
+    with torch.no_grad():
+        regions, code = enc(fake[2].detach())
+    assert rel_l2(regions[:, ::8], g["regions_s"]) < 1e-4
+    total2, _ = tm.g_loss(sds, lambda x: (regions, code), fake, b["hmaps"], b["words_embs"], b["sent_emb"],
+                          b["clabels_emb"], btd[-1], labels, b["cap_lens"], b["class_ids"], b["rois"],
+                          b["fm_rois"], b["num_rois"])
+    (total2 + tm.kl_loss(mu, logvar)).backward()
+    check_grads(sds["G"], g["gradG_constenc"], tol=2e-3)
+    assert rel_l2(sds["G"]["img_net3.img.0.weight"].grad, g["gradG_constenc_img3_w"]) < 1e-4
+    assert rel_l2(sds["G"]["h_net3_main.att.conv_context.weight"].grad, g["gradG_constenc_att_ctx_w"]) < 1e-4
+    assert rel_l2(sds["G"]["ca_net.fc.weight"].grad, g["gradG_constenc_ca_fc_w"]) < 1e-4
 
 
 def test_c_abi_library_exports_every_declared_symbol():
