@@ -53,13 +53,13 @@ int objgan_avgpool2s1_backward(const float* grad_out, float* grad_in, long plane
                                void* stream);
 
 /* ---- implicit-GEMM convolution on MFMA (reference model.py conv stacks, via cuDNN) ---------- */
-long objgan_conv_packed_floats(int M, int K);
+long objgan_conv_packed_floats(int M, int C, int T);
 /* y[n,m,a*osh+ooh,b*osw+oow] = act(bias[m] + sum_{c,t} Wp[m][c*Tg+t] * x[n,c,a*s+dh[t],b*s+dw[t]])
  * for (a,b) in PH x PW.  w: [Cout][Cin][Torig]; transpose=0 -> m=cout,c=cin; 1 -> m=cin,c=cout.
- * src_tap[t]: which of the Torig taps GEMM tap t uses (-1 = zero).  Tg in {1,4,9,16}.
+ * src_tap[t]: which of the Torig taps GEMM tap t uses (-1 = zero).  1 <= Tg <= 32.
  * upsample=1: taps address a nearest-x2 upsampled view of x; pad_mode 0 zeros, 1 reflect.
- * act: 0 none, 1 LeakyReLU(0.2), 2 tanh, 3 sigmoid.  wt: scratch of
- * objgan_conv_packed_floats(M, C*Tg) floats.  y_prezeroed=1 tells the library that y already
+ * act: 0 none, 1 LeakyReLU(0.2), 2 tanh, 3 sigmoid, 4 ReLU.  wt: scratch of
+ * objgan_conv_packed_floats(M, C, Tg) floats.  y_prezeroed=1 tells the library that y already
  * holds zeros (lets partial-coverage launches, i.e. stride-2 dgrad phases, use split-K). */
 int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* y, float* wt,
                       int N, int C, int H, int W, int upsample, int pad_mode,

@@ -17,7 +17,10 @@
 //   (the up-sampled / padded tensor never exists in HBM)
 // * epilogue: + bias, LeakyReLU(0.2) / tanh / sigmoid
 //
-// GEMM view: M = output channels, N = pixels (n, a, b), K = C*T.  A workgroup of 4 waves
+// GEMM view: M = output channels, N = pixels (n, a, b), K = T*Cp (TAP-MAJOR: k = t*Cp + c with
+// Cp = C rounded up to the K step of 16, so that one K step of the main loop touches ONE tap:
+// the tap geometry -- bounds / reflect / upsample / offset -- is evaluated once per step and
+// lane, the 8-16 gathered elements of the step differ only by a wave-uniform channel offset).  A workgroup of 4 waves
 // owns a BM x BN tile (BM in {128, 64, 32}); each wave owns TM x 2 MFMA tiles of 32x32,
 // accumulators stay in AGPRs for the whole K loop.  Operands go HBM -> VGPR -> LDS ->
 // VGPR -> MFMA, double-buffered in LDS with one barrier per K step (BK = 16); the global
@@ -31,11 +34,12 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define OG_MAX_TAPS 16
+#define OG_MAX_TAPS 32
 #define OG_ACT_NONE 0
 #define OG_ACT_LRELU 1
 #define OG_ACT_TANH 2
 #define OG_ACT_SIGMOID 3
+#define OG_ACT_RELU 4
 
 struct IgemmArgs {
     const float* x;      // [N, C, H, W] source activations (or dY for dgrad)
@@ -44,7 +48,8 @@ struct IgemmArgs {
     float* y;            // [N, M, OHf, OWf]
     int N, C, H, W;      // physical source dims
     int LH, LW;          // logical source dims seen by the taps (2H x 2W when upsampling)
-    int M, Mpad, K, Kpad;
+    int M, Mpad, K, Kpad;   // K = T*C (algorithmic), Kpad = T*Cp (padded, what the loop walks)
+    int T, Cp;              // taps, channels rounded up to 16
     int m_begin, m_end;  // output-channel rows covered by this launch
     int PH, PW;          // GEMM pixel grid per image
     int OHf, OWf;        // physical output dims
@@ -61,6 +66,7 @@ __device__ __forceinline__ float og_act(float v, int act) {
     if (act == OG_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
     if (act == OG_ACT_TANH) return tanhf(v);
     if (act == OG_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    if (act == OG_ACT_RELU) return fmaxf(v, 0.f);
     return v;
 }
 
@@ -72,7 +78,7 @@ __device__ __forceinline__ int og_xcd_remap(int id, int nwg) {
     return start + j;
 }
 
-template <int T, int WM, int TM>
+template <int WM, int TM>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
     constexpr int WN = 4 / WM;
     constexpr int TN = 2;
@@ -126,34 +132,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
 #pragma unroll
     for (int i = 0; i < NA_PER; ++i) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // Branch-free gather: every lane always issues its load (from a clamped, in-range
-    // address) so the BROWS loads of a step are all in flight together; out-of-image /
-    // out-of-K elements are zeroed by a bit mask when the tile is written to LDS.
+    // Branch-free gather.  One K step = 16 consecutive channels of ONE tap: the tap geometry is
+    // evaluated once per step; every lane always issues its BROWS loads (from a clamped, in-range
+    // address) so they are all in flight together; out-of-image / padded-channel elements are
+    // zeroed by a bit mask when the tile is written to LDS.
     unsigned okmask = 0;
     const int us = a.upsample ? 1 : 0;
-    auto load_b = [&](int k0) {
+    const int steps_per_tap = a.Cp / BK;
+    const bool refl = a.pad_mode == 1;
+    auto load_b = [&](int kt) {
+        const int t = kt / steps_per_tap;                // wave-uniform
+        const int cb = (kt - t * steps_per_tap) * BK;
+        const int tp = a.tap[t];
+        const int ih = ihb + ((tp << 16) >> 16);
+        const int iw = iwb + (tp >> 16);
+        int ihr = ih < 0 ? -ih : ih;
+        int iwr = iw < 0 ? -iw : iw;
+        ihr = ihr >= a.LH ? 2 * (a.LH - 1) - ihr : ihr;
+        iwr = iwr >= a.LW ? 2 * (a.LW - 1) - iwr : iwr;
+        const bool inb = ((unsigned)ih < (unsigned)a.LH) && ((unsigned)iw < (unsigned)a.LW);
+        const bool ok = pix_ok && (refl || inb);
+        const int ihs = (refl ? ihr : ih) >> us;
+        const int iws = (refl ? iwr : iw) >> us;
+        const float* src = xb + (ok ? ihs * a.W + iws : 0);
         okmask = 0;
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) {
-            const int k = k0 + kr0 + KSTEP * i;      // wave-uniform
-            const int kc = min(k, a.K - 1);
-            const int c = kc / T;
-            const int t = kc - c * T;
-            const int tp = a.tap[t];
-            const int ih = ihb + ((tp << 16) >> 16);
-            const int iw = iwb + (tp >> 16);
-            int ihr = ih < 0 ? -ih : ih;
-            int iwr = iw < 0 ? -iw : iw;
-            ihr = ihr >= a.LH ? 2 * (a.LH - 1) - ihr : ihr;
-            iwr = iwr >= a.LW ? 2 * (a.LW - 1) - iwr : iwr;
-            const bool inb = ((unsigned)ih < (unsigned)a.LH) && ((unsigned)iw < (unsigned)a.LW);
-            const bool refl = a.pad_mode == 1;
-            const bool ok = pix_ok && (k < a.K) && (refl || inb);
-            const int ihs = (refl ? ihr : ih) >> us;
-            const int iws = (refl ? iwr : iw) >> us;
-            const int off = ok ? (c * HW + ihs * a.W + iws) : 0;
-            rb[i] = xb[off];
-            okmask |= (ok ? 1u : 0u) << i;
+            const int c = cb + kr0 + KSTEP * i;          // wave-uniform
+            const int cc = min(c, a.C - 1);
+            rb[i] = src[(size_t)cc * HW];
+            okmask |= ((ok && c < a.C) ? 1u : 0u) << i;
         }
     };
     constexpr bool A_FULL = (NA4 % 256) == 0;   // every thread loads NA_PER float4s
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
     const int kt0 = a.ksplit_steps > 0 ? blockIdx.y * a.ksplit_steps : 0;
     const int nk = a.ksplit_steps > 0 ? min(nk_all, kt0 + a.ksplit_steps) : nk_all;
     load_a(kt0 * BK);
-    load_b(kt0 * BK);
+    load_b(kt0);
     store_tiles(0);
     __syncthreads();
 
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
     int cur = 0;
     for (int kt = kt0; kt < nk; ++kt) {
         const bool more = (kt + 1) < nk;
-        if (more) { load_a((kt + 1) * BK); load_b((kt + 1) * BK); }
+        if (more) { load_a((kt + 1) * BK); load_b(kt + 1); }
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             float av[TM], bv[TN];
@@ -255,28 +263,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
 }
 
 // ---- weight packing ------------------------------------------------------------------
-// wt[(ck*Tg + t) * Mpad + cm] = src_tap[t] >= 0 ? w[...] : 0, zero padded to [Kpad][Mpad].
+// wt[(t*Cp + ck) * Mpad + cm] = src_tap[t] >= 0 ? w[...] : 0, zero padded to [T*Cp][Mpad].
 // w is the PyTorch conv weight [Cout][Cin][Torig].  transpose = 0: cm = cout, ck = cin
 // (forward);  transpose = 1: cm = cin, ck = cout (data gradient).
 struct PackArgs {
     const float* w;
     float* wt;
     int Cout, Cin, Torig, Tg;
-    int M, Mpad, K, Kpad;
+    int M, Mpad, Ck, Cp;
     int transpose;
     signed char src_tap[OG_MAX_TAPS];
 };
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
-    const long total = (long)a.Kpad * a.Mpad;
+    const long total = (long)a.Tg * a.Cp * a.Mpad;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long)gridDim.x * blockDim.x) {
         const int m = (int)(i % a.Mpad);
         const int k = (int)(i / a.Mpad);
+        const int t = k / a.Cp;
+        const int ck = k - t * a.Cp;
         float v = 0.f;
-        if (m < a.M && k < a.K) {
-            const int ck = k / a.Tg;
-            const int t = k - ck * a.Tg;
+        if (m < a.M && ck < a.Ck) {
             const int st = a.src_tap[t];
             if (st >= 0) {
                 const int co = a.transpose ? ck : m;
@@ -474,7 +482,7 @@ static int g_prof_n = 0;
 static int g_prof_made = 0;
 
 static inline int prof_cat(int wgrad, int t_or_k, int cfg) {
-    int ti = wgrad ? (t_or_k == 1 ? 0 : (t_or_k == 3 ? 1 : 2)) : (t_or_k == 1 ? 0 : (t_or_k == 4 ? 1 : (t_or_k == 9 ? 2 : 3)));
+    int ti = wgrad ? (t_or_k == 1 ? 0 : (t_or_k == 3 ? 1 : 2)) : (t_or_k <= 1 ? 0 : (t_or_k <= 4 ? 1 : (t_or_k <= 9 ? 2 : 3)));
     return (wgrad ? 12 : 0) + ti * 3 + cfg;
 }
 static inline ProfRec* prof_begin(int cat, double flops, hipStream_t s) {
@@ -501,25 +509,14 @@ static inline int igemm_tiles(const IgemmArgs& a, int cfg) {
     return og_cdiv(rows, 32) * og_cdiv(Npix, 256);
 }
 
-template <int T>
-static int launch_igemm_T(const IgemmArgs& a, int cfg, hipStream_t s) {
+static int launch_igemm(const IgemmArgs& a, int cfg, hipStream_t s) {
     const int g = igemm_tiles(a, cfg);
     const int splits = a.ksplit_steps > 0 ? og_cdiv(a.Kpad / 16, a.ksplit_steps) : 1;
     dim3 grid(g, splits);
-    if (cfg == 0) hipLaunchKernelGGL((conv_igemm_kernel<T, 2, 2>), grid, dim3(256), 0, s, a);
-    else if (cfg == 1) hipLaunchKernelGGL((conv_igemm_kernel<T, 1, 2>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv_igemm_kernel<T, 1, 1>), grid, dim3(256), 0, s, a);
+    if (cfg == 0) hipLaunchKernelGGL((conv_igemm_kernel<2, 2>), grid, dim3(256), 0, s, a);
+    else if (cfg == 1) hipLaunchKernelGGL((conv_igemm_kernel<1, 2>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<1, 1>), grid, dim3(256), 0, s, a);
     return og_launch_status();
-}
-
-static int launch_igemm(const IgemmArgs& a, int T, int cfg, hipStream_t s) {
-    switch (T) {
-        case 1: return launch_igemm_T<1>(a, cfg, s);
-        case 4: return launch_igemm_T<4>(a, cfg, s);
-        case 9: return launch_igemm_T<9>(a, cfg, s);
-        case 16: return launch_igemm_T<16>(a, cfg, s);
-        default: return OG_BAD_ARGS;
-    }
 }
 
 // Rows [0, M) are covered greedily: 128-row tiles, then one 64-row tile, then 32-row tiles
@@ -538,7 +535,7 @@ static int og_row_parts(int M, RowPart* parts) {
 // channel and K = 12288) would run on a handful of CUs for hundreds of serial K steps: they are
 // split along K across gridDim.y, partial tiles are accumulated with fp32 atomics into a zeroed
 // output and bias/activation are applied by a follow-up streaming pass.
-static int run_igemm(IgemmArgs a, int T, hipStream_t s, int y_prezeroed) {
+static int run_igemm(IgemmArgs a, hipStream_t s, int y_prezeroed) {
     RowPart parts[3];
     const int np = og_row_parts(a.M, parts);
     int tiles = 0;
@@ -566,8 +563,8 @@ static int run_igemm(IgemmArgs a, int T, hipStream_t s, int y_prezeroed) {
     for (int i = 0; i < np; ++i) {
         a.m_begin = parts[i].m_begin; a.m_end = parts[i].m_end;
         const double fl = 2.0 * (a.m_end - a.m_begin) * (double)a.K * ((double)a.N * a.PH * a.PW);
-        ProfRec* pr = prof_begin(prof_cat(0, T, parts[i].cfg), fl, s);
-        int rc = launch_igemm(a, T, parts[i].cfg, s);
+        ProfRec* pr = prof_begin(prof_cat(0, a.T, parts[i].cfg), fl, s);
+        int rc = launch_igemm(a, parts[i].cfg, s);
         prof_end(pr, s);
         if (rc != OG_OK) return rc;
     }
@@ -583,10 +580,10 @@ static int run_igemm(IgemmArgs a, int T, hipStream_t s, int y_prezeroed) {
 extern "C" {
 
 // Size (in floats) of the packed-weight scratch for an M x K GEMM.
-long objgan_conv_packed_floats(int M, int K) {
+long objgan_conv_packed_floats(int M, int C, int T) {
     const long Mpad = ((long)M + 127) / 128 * 128;
-    const long Kpad = ((long)K + 15) / 16 * 16;
-    return Mpad * Kpad;
+    const long Cp = ((long)C + 15) / 16 * 16;
+    return Mpad * Cp * T;
 }
 
 // General entry: see the formula at the top of this file.
@@ -601,8 +598,8 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
                       int PH, int PW, int stride,
                       int OHf, int OWf, int osh, int osw, int ooh, int oow,
                       int act, int y_prezeroed, void* stream) {
-    if (Tg != 1 && Tg != 4 && Tg != 9 && Tg != 16) return OG_BAD_ARGS;
-    if (Torig < 1 || Torig > OG_MAX_TAPS) return OG_BAD_ARGS;
+    if (Tg < 1 || Tg > OG_MAX_TAPS) return OG_BAD_ARGS;
+    if (Torig < 1 || Torig > 127) return OG_BAD_ARGS;
     const int M = transpose ? Cin : Cout;
     const int Ck = transpose ? Cout : Cin;
     if (Ck != C) return OG_BAD_ARGS;
@@ -610,10 +607,10 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
     hipStream_t s = (hipStream_t)stream;
     PackArgs p;
     p.w = w; p.wt = wt; p.Cout = Cout; p.Cin = Cin; p.Torig = Torig; p.Tg = Tg;
-    p.M = M; p.Mpad = (M + 127) / 128 * 128; p.K = C * Tg; p.Kpad = (p.K + 15) / 16 * 16;
+    p.M = M; p.Mpad = (M + 127) / 128 * 128; p.Ck = C; p.Cp = (C + 15) / 16 * 16;
     p.transpose = transpose;
     for (int t = 0; t < OG_MAX_TAPS; ++t) p.src_tap[t] = (signed char)(t < Tg ? src_tap[t] : -1);
-    const long ptotal = (long)p.Kpad * p.Mpad;
+    const long ptotal = (long)Tg * p.Cp * p.Mpad;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(og_stream_grid(ptotal, 256)), dim3(256), 0, s, p);
     int rc = og_launch_status();
     if (rc != OG_OK) return rc;
@@ -622,7 +619,7 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
     a.x = x; a.wt = wt; a.bias = bias; a.y = y;
     a.N = N; a.C = C; a.H = H; a.W = W;
     a.LH = upsample ? 2 * H : H; a.LW = upsample ? 2 * W : W;
-    a.M = M; a.Mpad = p.Mpad; a.K = p.K; a.Kpad = p.Kpad;
+    a.M = M; a.Mpad = p.Mpad; a.K = C * Tg; a.Kpad = Tg * p.Cp; a.T = Tg; a.Cp = p.Cp;
     a.m_begin = 0; a.m_end = M;
     a.PH = PH; a.PW = PW; a.OHf = OHf; a.OWf = OWf;
     a.osh = osh; a.osw = osw; a.ooh = ooh; a.oow = oow;
@@ -633,7 +630,7 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
         a.tap[t] = (int)(((unsigned)w_ << 16) | ((unsigned)h & 0xffffu));
     }
     if (!(osh == 1 && osw == 1 && PH == OHf && PW == OWf) && (bias || act)) return OG_BAD_ARGS;
-    return run_igemm(a, Tg, s, y_prezeroed);
+    return run_igemm(a, s, y_prezeroed);
 }
 
 // dw must be zero-initialised by the caller (or hold a gradient to accumulate into).

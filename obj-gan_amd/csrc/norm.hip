@@ -204,7 +204,7 @@ __global__ void norm_affine_grad_kernel(const float* __restrict__ bsums, float* 
 }
 
 // ---- plain activations on conv outputs (forward is fused in the conv epilogue) ----------
-// kind 1: LeakyReLU(0.2) from the OUTPUT y (sign(y) == sign(z));  2: tanh;  3: sigmoid
+// kind 1: LeakyReLU(0.2) from the OUTPUT y (sign(y) == sign(z));  2: tanh;  3: sigmoid;  4: ReLU
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy,
                                                       const float* __restrict__ y,
                                                       float* __restrict__ dz, long total, int kind) {
@@ -214,7 +214,8 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
         float r;
         if (kind == 1) r = d * (o > 0.f ? 1.f : 0.2f);
         else if (kind == 2) r = d * (1.f - o * o);
-        else r = d * o * (1.f - o);
+        else if (kind == 3) r = d * o * (1.f - o);
+        else r = o > 0.f ? d : 0.f;
         dz[e] = r;
     }
 }
@@ -303,7 +304,7 @@ int objgan_norm_backward(const float* x, const float* dy, const float* mean, con
 
 int objgan_act_backward(const float* dy, const float* y, float* dz, long total, int kind,
                         void* stream) {
-    if (kind < 1 || kind > 3) return OG_BAD_ARGS;
+    if (kind < 1 || kind > 4) return OG_BAD_ARGS;
     if (total <= 0) return OG_OK;
     hipLaunchKernelGGL(act_bwd_kernel, dim3(og_stream_grid(total, 256)), dim3(256), 0,
                        (hipStream_t)stream, dy, y, dz, total, kind);

@@ -53,7 +53,7 @@ SIGNATURES = {
     "objgan_prof_enable": [_c_int],
     "objgan_prof_collect": [_ptr, _ptr, _ptr],
 }
-LONG_RETURN = {"objgan_conv_packed_floats": [_c_int, _c_int]}
+LONG_RETURN = {"objgan_conv_packed_floats": [_c_int, _c_int, _c_int]}
 
 _LIB = None
 

@@ -45,11 +45,11 @@ def _iarr(vals):
 # ----------------------------------------------------------------------------------------------
 # convolution
 # ----------------------------------------------------------------------------------------------
-_ACT = {None: 0, "none": 0, "lrelu": 1, "tanh": 2, "sigmoid": 3}
+_ACT = {None: 0, "none": 0, "lrelu": 1, "tanh": 2, "sigmoid": 3, "relu": 4}
 
 
-def _packed_scratch(M, K, device):
-    n = _lib.load().objgan_conv_packed_floats(int(M), int(K))
+def _packed_scratch(M, C, T, device):
+    n = _lib.load().objgan_conv_packed_floats(int(M), int(C), int(T))
     return torch.empty(n, dtype=_F32, device=device)
 
 
@@ -57,7 +57,7 @@ def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, tran
            dh, dw, src_tap, PH, PW, stride, OHf, OWf, osh, osw, ooh, oow, act, y_prezeroed=0):
     Tg = len(dh)
     M = Cin if transpose else Cout
-    wt = _packed_scratch(M, C * Tg, x.device)
+    wt = _packed_scratch(M, C, Tg, x.device)
     _lib.call("objgan_conv_igemm", _p(x), _p(w), _p(bias), _p(y), _p(wt),
               N, C, H, W, int(upsample), int(pad_mode), Cout, Cin, Torig, int(transpose),
               Tg, _iarr(dh), _iarr(dw), _iarr(src_tap), PH, PW, stride,
@@ -65,13 +65,10 @@ def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, tran
 
 
 def _pad_taps(dh, dw, st):
-    """Pad a tap list to the next supported GEMM tap count (1, 4, 9, 16) with zero taps."""
-    n = len(dh)
-    for tg in (1, 4, 9, 16):
-        if n <= tg:
-            k = tg - n
-            return dh + [0] * k, dw + [0] * k, st + [-1] * k
-    raise _lib.ObjganHipError("more than 16 taps")
+    """(kept for callers) the GEMM accepts any tap count up to 32: nothing to pad."""
+    if len(dh) > 32:
+        raise _lib.ObjganHipError("more than 32 taps")
+    return dh, dw, st
 
 
 def conv_out_size(L, k, s, p):
@@ -182,6 +179,77 @@ class _Conv2dFn(torch.autograd.Function):
 
 def conv2d(x, w, bias=None, stride=1, pad=0, pad_mode="zeros", upsample=False, act=None):
     return _Conv2dFn.apply(x, w, bias, stride, pad, pad_mode, upsample, act)
+
+
+class _ConvFrozenFn(torch.autograd.Function):
+    """Convolution with a FROZEN (non-trainable) rectangular filter bank: forward + input gradient
+    only.  Serves the frozen Inception-v3 encoder (1x1, 3x3, 5x5, 1x7, 7x1, 1x3, 3x1 kernels,
+    stride 1 or 2, asymmetric zero padding) on the same MFMA implicit-GEMM kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, ph, pw, act):
+        _chk(x, w, bias)
+        if w.requires_grad or (bias is not None and bias.requires_grad):
+            raise _lib.ObjganHipError("conv2d_frozen: the filter bank must not require gradients")
+        x, w = _c(x), _c(w)
+        N, Cin, H, W = x.shape
+        Cout, Cin2, KH, KW = w.shape
+        if Cin2 != Cin or KH * KW > 32:
+            raise _lib.ObjganHipError("conv2d_frozen: unsupported filter %s" % (tuple(w.shape),))
+        OH = (H + 2 * ph - KH) // stride + 1
+        OW = (W + 2 * pw - KW) // stride + 1
+        y = torch.empty((N, Cout, OH, OW), dtype=_F32, device=x.device)
+        dh = [kh - ph for kh in range(KH) for kw in range(KW)]
+        dw = [kw - pw for kh in range(KH) for kw in range(KW)]
+        _igemm(x, w, bias, y, N, Cin, H, W, 0, 0, Cout, Cin, KH * KW, 0, dh, dw, list(range(KH * KW)),
+               OH, OW, stride, OH, OW, 1, 1, 0, 0, _ACT[act])
+        ctx.cfg = (stride, ph, pw, act, KH, KW, (N, Cin, H, W))
+        ctx.save_for_backward(w, y if act not in (None, "none") else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        w, y = ctx.saved_tensors
+        stride, ph, pw, act, KH, KW, (N, Cin, H, W) = ctx.cfg
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, None, None, None, None
+        Cout = w.shape[0]
+        dy = _c(dy)
+        OH, OW = dy.shape[2], dy.shape[3]
+        if act not in (None, "none"):
+            g = torch.empty_like(dy)
+            _lib.call("objgan_act_backward", _p(dy), _p(y), _p(g), dy.numel(), _ACT[act], _stream())
+        else:
+            g = dy
+        T = KH * KW
+        if stride == 1:
+            dx = torch.empty((N, Cin, H, W), dtype=_F32, device=dy.device)
+            dh = [ph - kh for kh in range(KH) for kw in range(KW)]
+            dw = [pw - kw for kh in range(KH) for kw in range(KW)]
+            _igemm(g, w, None, dx, N, Cout, OH, OW, 0, 0, Cout, Cin, T, 1, dh, dw, list(range(T)),
+                   H, W, 1, H, W, 1, 1, 0, 0, 0)
+        elif stride == 2:
+            dx = torch.zeros((N, Cin, H, W), dtype=_F32, device=dy.device)
+            for a in range(2):
+                khs = [kh for kh in range(KH) if (a + ph - kh) % 2 == 0]
+                PHg = (H - a + 1) // 2
+                for b in range(2):
+                    kws = [kw for kw in range(KW) if (b + pw - kw) % 2 == 0]
+                    PWg = (W - b + 1) // 2
+                    if PHg <= 0 or PWg <= 0 or not khs or not kws:
+                        continue
+                    dh = [(a + ph - kh) // 2 for kh in khs for kw in kws]
+                    dw = [(b + pw - kw) // 2 for kh in khs for kw in kws]
+                    st = [kh * KW + kw for kh in khs for kw in kws]
+                    _igemm(g, w, None, dx, N, Cout, OH, OW, 0, 0, Cout, Cin, T, 1, dh, dw, st,
+                           PHg, PWg, 1, H, W, 2, 2, a, b, 0, y_prezeroed=1)
+        else:
+            raise _lib.ObjganHipError("conv2d_frozen backward: stride %d not supported" % stride)
+        return dx, None, None, None, None, None, None
+
+
+def conv2d_frozen(x, w, bias=None, stride=1, pad=(0, 0), act=None):
+    return _ConvFrozenFn.apply(x, w, bias, int(stride), int(pad[0]), int(pad[1]), act)
 
 
 def linear(x, w, bias=None, act=None):

@@ -98,7 +98,7 @@ def next_stage_main(sd, p, h_code, h_hmap, word_embs, glove, slabels_feat, mask,
     c_code, att = T.attn_general(h_code, src, mask)
     raw, bt_c, bt_att, bt_sl = _bottom_up(sd, p, word_embs, glove, slabels_feat, mask, bt_mask,
                                           max_num_roi, ih, iw)
-    raw_full = torch.zeros(B, idf, glb_max_num_roi, 1)
+    raw_full = torch.zeros(B, idf, glb_max_num_roi, 1, dtype=h_code.dtype)
     raw_full = torch.cat((raw, raw_full[:, :, max_num_roi:]), 2)
     h = torch.cat((h_code + h_hmap, c_code, bt_c, bt_sl), 1)
     for i in range(CFG["LOCAL_R_NUM"]):

@@ -344,3 +344,59 @@ def test_ops_refuse_cpu_tensors():
     from objgan_hip import ops, ObjganHipError
     with pytest.raises(ObjganHipError):
         ops.conv2d(torch.zeros(1, 1, 4, 4), torch.zeros(1, 1, 3, 3), None, 1, 1)
+
+
+FROZEN_CASES = [
+    # Cin, H, W, Cout, KH, KW, stride, ph, pw
+    (12, 17, 17, 20, 1, 7, 1, 0, 3),
+    (12, 17, 17, 20, 7, 1, 1, 3, 0),
+    (9, 19, 19, 33, 5, 5, 1, 2, 2),
+    (8, 35, 35, 16, 3, 3, 2, 0, 0),
+    (6, 16, 15, 10, 1, 3, 1, 0, 1),
+    (3, 41, 41, 32, 3, 3, 2, 0, 0),
+]
+
+
+@pytest.mark.parametrize("case", FROZEN_CASES)
+def test_conv2d_frozen_rectangular(dev, case):
+    """Inception-style convolutions (rectangular taps, stride-2 without padding) with a frozen
+    filter bank: forward + input gradient, bias + ReLU epilogue."""
+    import torch.nn.functional as F
+    ops = _ops()
+    Cin, H, W, Cout, KH, KW, s, ph, pw = case
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, KH, KW, generator=g) / (Cin * KH * KW) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    xr = x.clone().requires_grad_()
+    yr = F.relu(F.conv2d(xr, w, b, stride=s, padding=(ph, pw)))
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = x.to(dev).requires_grad_()
+    yd = ops.conv2d_frozen(xd, w.to(dev), b.to(dev), s, (ph, pw), act="relu")
+    yd.backward(gy.to(dev))
+    torch.cuda.synchronize()
+    assert yd.shape == yr.shape
+    assert rel_l2(yd, yr) < TOL and rel_l2(xd.grad, xr.grad) < TOL
+
+
+def test_inception_encoder_gpu_matches_cpu(dev):
+    import copy
+    import encoders
+    enc = encoders.CNN_ENCODER(256, encoders.seeded_init_(encoders.inception_v3(), 3)).eval()
+    g = torch.Generator().manual_seed(37)
+    x = torch.tanh(torch.randn(2, 3, 64, 64, generator=g))
+    with torch.no_grad():
+        rr, cr = enc(x)
+    encd = copy.deepcopy(enc).to(dev).eval()
+    xd = x.to(dev).requires_grad_()
+    rd, cd = encd(xd)
+    (rd.square().mean() + cd.square().mean()).backward()
+    torch.cuda.synchronize()
+    assert rel_l2(rd, rr) < TOL and rel_l2(cd, cr) < TOL
+    assert torch.isfinite(xd.grad).all() and float(xd.grad.abs().sum()) > 0
+    mon = encoders.INCEPTION_V3(encoders.seeded_init_(encoders.inception_v3(), 3)).eval()
+    with torch.no_grad():
+        pr = mon(x)
+        pd = copy.deepcopy(mon).to(dev)(x.to(dev))
+    assert rel_l2(pd, pr) < TOL
