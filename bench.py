@@ -15,7 +15,8 @@ One JSON line is printed by rank 0: the contract fields plus
   roofline      the dominant kernel (MFMA implicit-GEMM conv, 128x128 tile, 3x3 taps): algorithmic
                 flops of its launches / their hipEvent-measured duration, against the fp32 MFMA peak
   cpu_baseline  the CPU oracle (oracle/torch_model.py, a port of the reference path) timed on this
-                host's cores on a bounded sample (one step at batch 4)
+                host's cores on a bounded sample (one step at batch 2, <= 16 threads,
+                child process with a hard time limit)
 """
 import argparse
 import ctypes
@@ -61,8 +62,8 @@ def build_trainer(device, batch_size, seed, with_is_monitor=True):
     return tr
 
 
-def cpu_baseline(sample_batch=4, seed=1234):
-    """The oracle (CPU port of the reference step) on the host cores: one step at a small batch."""
+def _cpu_baseline_worker(sample_batch, threads, seed=1234):
+    """(child process) the oracle -- CPU port of the reference step -- on `threads` host threads."""
     import model as M
     import encoders
     import synth_batch
@@ -70,8 +71,7 @@ def cpu_baseline(sample_batch=4, seed=1234):
     from miscc.utils import weights_init
     from oracle import torch_model as tm
     cfg.TREE.BRANCH_NUM = 3
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    torch.set_num_threads(threads)
     torch.manual_seed(seed)
 
     def sd_of(m):
@@ -94,11 +94,35 @@ def cpu_baseline(sample_batch=4, seed=1234):
     t0 = time.time()
     tm.train_step(sds, opts, ema, batch, image_encoder=enc)
     dt = time.time() - t0
-    return {"value": round(sample_batch / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "1 full G+D step at batch %d (same networks, 256x256), %.1f s" % (sample_batch, dt)}
+    print("CPU_BASELINE " + json.dumps(
+        {"value": round(sample_batch / dt, 4), "unit": "images/sec", "cores": threads, "kind": "port",
+         "sample": "1 full G+D step at batch %d (same networks, 256x256), %.1f s on %d threads of %d host cores"
+                   % (sample_batch, dt, threads, os.cpu_count() or 1)}), flush=True)
+
+
+def cpu_baseline(sample_batch=2, max_threads=16, timeout_s=240):
+    """The oracle timed on the host cores, on a bounded sample (one step at a small batch), in a
+    child process with a hard time limit so that the default bench run always finishes."""
+    import subprocess
+    threads = max(1, min(max_threads, os.cpu_count() or 1))
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads),
+               HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(sample_batch), str(threads)]
+    try:
+        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                             timeout=timeout_s).stdout.decode(errors="replace")
+        for line in out.splitlines():
+            if line.startswith("CPU_BASELINE "):
+                return json.loads(line[len("CPU_BASELINE "):])
+        note = "worker produced no result"
+    except subprocess.TimeoutExpired:
+        note = "did not finish one batch-%d step within %d s on %d threads" % (sample_batch, timeout_s, threads)
+    return {"value": None, "unit": "images/sec", "cores": threads, "kind": "port", "sample": note}
 
 
 def main():
+    if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-worker":
+        return _cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
