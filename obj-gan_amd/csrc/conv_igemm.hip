@@ -33,6 +33,7 @@
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define OG_MAX_TAPS 32
 #define OG_ACT_NONE 0
@@ -262,6 +263,218 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
     }
 }
 
+// =============================================================================================
+// v2 main loop.  Same GEMM view as above, re-tiled for the CDNA4 issue model:
+//   * workgroup = 4 waves, tile = (32*TM) x 128: every wave owns ONE 32-pixel column group and ALL
+//     TM 32-row groups (TM 32x32 accumulators in AGPRs), so ragged channel counts cost at most one
+//     partly filled 32-row group per block row (194 -> 7 groups, 388 -> 7 + 6) and row groups
+//     beyond M are skipped by a wave-uniform branch;
+//   * LDS tiles are k-contiguous, [row][16 + 4 pad]: a lane's eight k values of a K step are two
+//     ds_read_b128 (conflict-free with the 80-byte row pitch).  The MFMA k pairing is permuted
+//     accordingly -- MFMA kk multiplies k positions {kk, 8 + kk} -- identically for both operands;
+//   * global loads are buffer loads through SGPR resource descriptors: the per-lane offset carries
+//     the pixel, the scalar offset the channel / k position -- no 64-bit address arithmetic in the
+//     loop -- and zero padding / out-of-tile rows come from the hardware range check
+//     (out-of-range offset -> 0), not from selects;
+//   * the tap geometry (bounds, reflection, upsample) is recomputed only when the tap changes.
+// The filter bank is packed [M][Kpad] (k contiguous) for this kernel.
+template <int V> struct OgInt { static constexpr int value = V; };
+#define OG_BUF_FLAGS 0x00020000
+#define OG_OOB 0x7ffffff0u
+
+template <int TM>
+__global__ __launch_bounds__(256) void conv_igemm2_kernel(const IgemmArgs a) {
+    constexpr int BM = 32 * TM;
+    constexpr int BN = 128;
+    constexpr int BK = 16;
+    constexpr int LD = BK + 4;
+    constexpr int NA4 = BM * 4;                      // float4s of one A tile
+    constexpr int NA_PER = (NA4 + 255) / 256;
+    constexpr int TILE = (BM + BN) * LD;
+
+    __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int Npix = a.N * a.PH * a.PW;
+    const int tiles_m = (a.m_end - a.m_begin + BM - 1) / BM;
+    const int tiles_n = (Npix + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    const int wg = og_xcd_remap(blockIdx.x, nwg);
+    const int tile_m = wg % tiles_m;
+    const int tile_n = wg / tiles_m;
+    const int m0 = a.m_begin + tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    const int HW = a.H * a.W;
+    __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.x, 0, (int)((unsigned)a.N * a.C * HW * 4u), OG_BUF_FLAGS);
+    __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.wt, 0, (int)((unsigned)a.M * a.Kpad * 4u), OG_BUF_FLAGS);
+
+    // ---- B gather geometry: thread = (pixel p of the tile, k half g)
+    const int bp = tid & (BN - 1);
+    const int bg = __builtin_amdgcn_readfirstlane(tid >> 7);      // 0: k 0..7, 1: k 8..15
+    const int pix = n0 + bp;
+    const bool pix_ok = pix < Npix;
+    int ihb, iwb;
+    unsigned img_off;
+    {
+        const int ppi = a.PH * a.PW;
+        const int pp = pix_ok ? pix : 0;
+        const int n = pp / ppi;
+        const int rem = pp - n * ppi;
+        const int pa = rem / a.PW;
+        const int pb = rem - pa * a.PW;
+        ihb = pa * a.stride;
+        iwb = pb * a.stride;
+        img_off = (unsigned)n * (unsigned)a.C * (unsigned)HW;
+    }
+    const int us = a.upsample ? 1 : 0;
+    const bool refl = a.pad_mode == 1;
+    unsigned bvoff = OG_OOB;                         // byte offset of (n, c = 0, ih, iw) or out of range
+    auto tap_geometry = [&](int t) {
+        const int tp = a.tap[t];
+        const int ih = ihb + ((tp << 16) >> 16);
+        const int iw = iwb + (tp >> 16);
+        int ihr = ih < 0 ? -ih : ih;
+        int iwr = iw < 0 ? -iw : iw;
+        ihr = ihr >= a.LH ? 2 * (a.LH - 1) - ihr : ihr;
+        iwr = iwr >= a.LW ? 2 * (a.LW - 1) - iwr : iwr;
+        const bool inb = ((unsigned)ih < (unsigned)a.LH) && ((unsigned)iw < (unsigned)a.LW);
+        const bool ok = pix_ok && (refl || inb);
+        const int ihs = (refl ? ihr : ih) >> us;
+        const int iws = (refl ? iwr : iw) >> us;
+        bvoff = ok ? (img_off + (unsigned)(ihs * a.W + iws)) * 4u : OG_OOB;
+    };
+
+    // ---- A (filter bank) geometry: float4 idx -> (row, quarter)
+    unsigned avoff[NA_PER];
+    int alds[NA_PER];
+#pragma unroll
+    for (int i = 0; i < NA_PER; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx >> 2, q = idx & 3;
+        const bool on = idx < NA4 && (m0 + row) < a.m_end;
+        avoff[i] = on ? ((unsigned)(m0 + row) * (unsigned)a.Kpad + q * 4u) * 4u : OG_OOB;
+        alds[i] = (NA4 % 256 == 0 || idx < NA4) ? row * LD + q * 4 : -1;
+    }
+
+    f32x4 ra[NA_PER];
+    float rb[8];
+    int t_ld, cb_ld;                                 // (tap, channel base) of the next K step to load
+    const int spt = a.Cp / BK;
+    auto load_step = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < NA_PER; ++i)
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, avoff[i], kt * (BK * 4), 0));
+        const int cbase = cb_ld + bg * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = min(cbase + i, a.C - 1);   // padded channels: finite data x zero weight
+            rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, bvoff, c * HW * 4, 0));
+        }
+        cb_ld += BK;
+        if (cb_ld >= a.Cp) {                         // wave-uniform: next step starts a new tap
+            cb_ld = 0;
+            t_ld += 1;
+            if (t_ld < a.T) tap_geometry(t_ld);
+        }
+    };
+    auto store_step = [&](int buf) {
+        float* As = lds + buf * TILE;
+        float* Bs = As + BM * LD;
+#pragma unroll
+        for (int i = 0; i < NA_PER; ++i)
+            if (NA4 % 256 == 0 || alds[i] >= 0) *reinterpret_cast<f32x4*>(As + alds[i]) = ra[i];
+        f32x4 v0 = {rb[0], rb[1], rb[2], rb[3]}, v1 = {rb[4], rb[5], rb[6], rb[7]};
+        *reinterpret_cast<f32x4*>(Bs + bp * LD + bg * 8) = v0;
+        *reinterpret_cast<f32x4*>(Bs + bp * LD + bg * 8 + 4) = v1;
+    };
+
+    const int nk_all = a.Kpad / BK;
+    const int kt0 = a.ksplit_steps > 0 ? blockIdx.y * a.ksplit_steps : 0;
+    const int nk = a.ksplit_steps > 0 ? min(nk_all, kt0 + a.ksplit_steps) : nk_all;
+    t_ld = kt0 / spt;
+    cb_ld = (kt0 - t_ld * spt) * BK;
+    tap_geometry(t_ld);
+    load_step(kt0);
+    store_step(0);
+    __syncthreads();
+
+    const int lrow = lane >> 5;
+    const int lcol = lane & 31;
+    const int a_rd = lcol * LD + lrow * 8;                       // + i*32*LD
+    const int b_rd = BM * LD + (wid * 32 + lcol) * LD + lrow * 8;
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    int cur = 0;
+    for (int kt = kt0; kt < nk; ++kt) {
+        const bool more = (kt + 1) < nk;
+        if (more) load_step(kt + 1);
+        const float* T = lds + cur * TILE;
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(T + b_rd);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(T + b_rd + 4);
+        f32x4 a0[TM], a1[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            a0[i] = *reinterpret_cast<const f32x4*>(T + a_rd + i * 32 * LD);
+            a1[i] = *reinterpret_cast<const f32x4*>(T + a_rd + i * 32 * LD + 4);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][kk], b0[kk], acc[i], 0, 0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][kk], b1[kk], acc[i], 0, 0, 0);
+        if (more) store_step(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+    const int p = n0 + wid * 32 + lcol;
+    if (p >= Npix) return;
+    const int ppi = a.PH * a.PW;
+    const int n = p / ppi;
+    const int rem = p - n * ppi;
+    const int pa = rem / a.PW;
+    const int pb = rem - pa * a.PW;
+    const int oh = pa * a.osh + a.ooh;
+    const int ow = pb * a.osw + a.oow;
+    const size_t plane = (size_t)a.OHf * a.OWf;
+    float* yb = a.y + (size_t)n * a.M * plane + (size_t)oh * a.OWf + ow;
+    const bool split = a.ksplit_steps > 0;
+    const bool lrelu = a.act == OG_ACT_LRELU, relu = a.act == OG_ACT_RELU;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+            if (m < a.m_end) {
+                float v = acc[i][r];
+                if (split) {
+                    atomicAdd(&yb[(size_t)m * plane], v);       // bias/act: follow-up pass
+                } else {
+                    if (a.bias) v += a.bias[m];
+                    v = lrelu ? (v > 0.f ? v : 0.2f * v) : (relu ? fmaxf(v, 0.f) : v);   // tanh/sigmoid: follow-up pass
+                    yb[(size_t)m * plane] = v;
+                }
+            }
+        }
+    }
+}
+
 // ---- weight packing ------------------------------------------------------------------
 // wt[(t*Cp + ck) * Mpad + cm] = src_tap[t] >= 0 ? w[...] : 0, zero padded to [T*Cp][Mpad].
 // w is the PyTorch conv weight [Cout][Cin][Torig].  transpose = 0: cm = cout, ck = cin
@@ -272,15 +485,17 @@ struct PackArgs {
     int Cout, Cin, Torig, Tg;
     int M, Mpad, Ck, Cp;
     int transpose;
+    int m_major;         // 0: wt[K][Mpad] (v1 kernels), 1: wt[M][Kpad] (k contiguous, v2 kernel)
     signed char src_tap[OG_MAX_TAPS];
 };
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
-    const long total = (long)a.Tg * a.Cp * a.Mpad;
+    const int Kpad = a.Tg * a.Cp;
+    const long total = a.m_major ? (long)a.M * Kpad : (long)Kpad * a.Mpad;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long)gridDim.x * blockDim.x) {
-        const int m = (int)(i % a.Mpad);
-        const int k = (int)(i / a.Mpad);
+        const int m = a.m_major ? (int)(i / Kpad) : (int)(i % a.Mpad);
+        const int k = a.m_major ? (int)(i % Kpad) : (int)(i / a.Mpad);
         const int t = k / a.Cp;
         const int ck = k - t * a.Cp;
         float v = 0.f;
@@ -469,6 +684,187 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     }
 }
 
+// ---- weight gradient, v2 -----------------------------------------------------------------------
+// Same tiling / LDS layout / buffer-load scheme as conv_igemm2_kernel: tile (32*TM) x 128 columns
+// (column = ci*T + t), K = 16 output pixels per step.  Requires OW % 8 == 0 and (OH*OW) % 16 == 0
+// (every layer of the hot path above 4x4 maps), so that the eight pixels a thread gathers per step
+// lie in one output row and a K step lies in one image: the pixel part of every address is then a
+// SCALAR (n, oh, ow0 .. ow0+7), the per-lane part is the column's (ci, kh, kw) -- dy rows are read
+// as aligned 16-byte pieces with a constant per-lane offset, x elements as dwords whose validity
+// (zero padding) rides on the buffer range check.
+template <int TM>
+__global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, const int KS) {
+    constexpr int BM = 32 * TM;
+    constexpr int BN = 128;
+    constexpr int BK = 16;
+    constexpr int LD = BK + 4;
+    constexpr int NA4 = BM * 4;
+    constexpr int NA_PER = (NA4 + 255) / 256;
+    constexpr int TILE = (BM + BN) * LD;
+
+    __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int T = KS * KS;
+    const int tiles_m = (a.m_end - a.m_begin + BM - 1) / BM;
+    const int tiles_n = (a.ncol + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    const int wg = og_xcd_remap(blockIdx.x, nwg);
+    const int tile_m = wg % tiles_m;
+    const int tile_n = wg / tiles_m;
+    const int m0 = a.m_begin + tile_m * BM;
+    const int c0 = tile_n * BN;
+
+    const int OHW = a.OH * a.OW;
+    const int HW = a.H * a.W;
+    const int Npix = a.N * OHW;
+    const int p_begin = blockIdx.y * a.pix_per_split;
+    const int p_end = min(Npix, p_begin + a.pix_per_split);
+    if (p_begin >= p_end) return;
+
+    __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.x, 0, (int)((unsigned)a.N * a.Cin * HW * 4u), OG_BUF_FLAGS);
+    __amdgpu_buffer_rsrc_t dyres = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.dy, 0, (int)((unsigned)a.N * a.Cout * OHW * 4u), OG_BUF_FLAGS);
+
+    // ---- B (gathered x) geometry: thread = (column of the tile, k half)
+    const int bc = tid & (BN - 1);
+    const int bg = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int col = c0 + bc;
+    const bool col_ok = col < a.ncol;
+    int dh, dw;
+    unsigned ci_off;
+    {
+        const int cc = col_ok ? col : 0;
+        const int ci = cc / T;
+        const int t = cc - ci * T;
+        const int kh = t / KS;
+        dh = kh - a.pad;
+        dw = (t - kh * KS) - a.pad;
+        ci_off = (unsigned)ci * (unsigned)HW;
+    }
+    const int us = a.upsample ? 1 : 0;
+    const bool refl = a.pad_mode == 1;
+
+    // ---- A (dy) geometry: float4 idx -> (row, quarter); constant per-lane offset
+    unsigned avoff[NA_PER];
+    int alds[NA_PER];
+#pragma unroll
+    for (int i = 0; i < NA_PER; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx >> 2, q = idx & 3;
+        const bool on = (NA4 % 256 == 0 || idx < NA4) && (m0 + row) < a.m_end;
+        avoff[i] = on ? ((unsigned)(m0 + row) * (unsigned)OHW + q * 4u) * 4u : OG_OOB;
+        alds[i] = (NA4 % 256 == 0 || idx < NA4) ? row * LD + q * 4 : -1;
+    }
+
+    f32x4 ra[NA_PER];
+    float rb[8];
+    // scalar pixel state of the next K step to load: image n, offset rem in the image, and the
+    // (row, first column) of this wave's eight pixels; advanced incrementally (no divisions)
+    int n_ld = p_begin / OHW;
+    int rem_ld = p_begin - n_ld * OHW;
+    int oh_ld = (rem_ld + bg * 8) / a.OW;
+    int ow_ld = (rem_ld + bg * 8) - oh_ld * a.OW;
+    auto load_step = [&]() {
+        const int n = n_ld, oh = oh_ld, ow0 = ow_ld;
+        const int asoff = (n * a.Cout * OHW + rem_ld) * 4;
+#pragma unroll
+        for (int i = 0; i < NA_PER; ++i)
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyres, avoff[i], asoff, 0));
+        rem_ld += BK;
+        ow_ld += BK;
+        while (ow_ld >= a.OW) { ow_ld -= a.OW; oh_ld += 1; }
+        if (rem_ld >= OHW) {                         // next step starts a new image
+            rem_ld = 0; n_ld += 1;
+            oh_ld = (bg * 8) / a.OW;
+            ow_ld = (bg * 8) - oh_ld * a.OW;
+        }
+        const int ih = oh * a.stride + dh;
+        int ihr = ih < 0 ? -ih : ih;
+        ihr = ihr >= a.LH ? 2 * (a.LH - 1) - ihr : ihr;
+        const bool row_ok = col_ok && (refl || (unsigned)ih < (unsigned)a.LH);
+        const unsigned rbase = (unsigned)n * (unsigned)a.Cin * (unsigned)HW + ci_off
+                             + (unsigned)(((refl ? ihr : ih) >> us) * a.W);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int iw = (ow0 + i) * a.stride + dw;
+            int iwr = iw < 0 ? -iw : iw;
+            iwr = iwr >= a.LW ? 2 * (a.LW - 1) - iwr : iwr;
+            const bool ok = row_ok && (refl || (unsigned)iw < (unsigned)a.LW);
+            const unsigned vo = ok ? (rbase + (unsigned)((refl ? iwr : iw) >> us)) * 4u : OG_OOB;
+            rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, vo, 0, 0));
+        }
+    };
+    auto store_step = [&](int buf) {
+        float* As = lds + buf * TILE;
+        float* Bs = As + BM * LD;
+#pragma unroll
+        for (int i = 0; i < NA_PER; ++i)
+            if (NA4 % 256 == 0 || alds[i] >= 0) *reinterpret_cast<f32x4*>(As + alds[i]) = ra[i];
+        f32x4 v0 = {rb[0], rb[1], rb[2], rb[3]}, v1 = {rb[4], rb[5], rb[6], rb[7]};
+        *reinterpret_cast<f32x4*>(Bs + bc * LD + bg * 8) = v0;
+        *reinterpret_cast<f32x4*>(Bs + bc * LD + bg * 8 + 4) = v1;
+    };
+
+    const int nk = (p_end - p_begin) / BK;
+    load_step();
+    store_step(0);
+    __syncthreads();
+
+    const int lrow = lane >> 5;
+    const int lcol = lane & 31;
+    const int a_rd = lcol * LD + lrow * 8;
+    const int b_rd = BM * LD + (wid * 32 + lcol) * LD + lrow * 8;
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1) < nk;
+        if (more) load_step();
+        const float* Tl = lds + cur * TILE;
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(Tl + b_rd);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(Tl + b_rd + 4);
+        f32x4 a0[TM], a1[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            a0[i] = *reinterpret_cast<const f32x4*>(Tl + a_rd + i * 32 * LD);
+            a1[i] = *reinterpret_cast<const f32x4*>(Tl + a_rd + i * 32 * LD + 4);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][kk], b0[kk], acc[i], 0, 0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][kk], b1[kk], acc[i], 0, 0, 0);
+        if (more) store_step(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    const int ocol = c0 + wid * 32 + lcol;
+    if (ocol >= a.ncol) return;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+            if (m < a.m_end) atomicAdd(a.dw + (size_t)m * a.ncol + ocol, acc[i][r]);
+        }
+    }
+}
+
 // ---- optional per-launch timing (bench.py's roofline leg) -------------------------------------
 // When enabled, every conv launch is bracketed by hipEvents on its own stream and tagged with a
 // category (kind, taps / ksize, tile config) and its ALGORITHMIC flops 2*M*K*Npix.  Off by default;
@@ -577,6 +973,113 @@ static int run_igemm(IgemmArgs a, hipStream_t s, int y_prezeroed) {
     return OG_OK;
 }
 
+// ---- v2 launch plan: block rows of TM 32-row groups (TM <= 8) ---------------------------------
+static int og_igemm_v1() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OG_IGEMM_V1"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v;
+}
+static int og_igemm_tmmax() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OG_IGEMM_TMMAX"); v = e ? atoi(e) : 8; if (v < 1 || v > 8) v = 8; }
+    return v;
+}
+
+// Block-row plan for M = `groups` 32-row groups over `tiles_n` column tiles: block rows of height TM
+// (<= 7: two workgroups per CU) plus one lower block row for the rest (its own launch).  The MFMA
+// time of a launch is ~ ceil(blocks / 256 CUs) * TM, so TM is chosen to minimise the quantised sum;
+// ties go to TM = 4 (three workgroups per CU), then to the taller tile (less re-reading of B).
+static void og_row_plan(int groups, int tiles_n, int tall, int* TM_out, int* full_rows_out, int* rest_out) {
+    int tmmax = og_igemm_tmmax();
+    if (tmmax > 7) tmmax = 7;
+    int bt = 1;
+    if (tall) {                                      // weight gradient: the gather is the expensive
+        const int brows = og_cdiv(groups, tmmax);    // part, amortise it over as many rows as fit
+        bt = og_cdiv(groups, brows);
+    } else {
+        // measured efficiency of the main loop by tile height (B traffic per MFMA falls with TM)
+        static const int pen[8] = {0, 112, 105, 102, 100, 100, 100, 100};
+        long best = -1;
+        for (int tm = 1; tm <= tmmax && tm <= groups; ++tm) {
+            const int full = groups / tm, rest = groups - full * tm;
+            long cost = (long)og_cdiv((long)full * tiles_n, 256) * tm * pen[tm]
+                      + (rest ? (long)og_cdiv(tiles_n, 256) * rest * pen[rest] + 20 : 0);   // + a second launch
+            if (best < 0 || cost < best || (cost == best && tm > bt)) { best = cost; bt = tm; }
+        }
+    }
+    *TM_out = bt; *full_rows_out = groups / bt; *rest_out = groups - (groups / bt) * bt;
+}
+
+static int launch_igemm2(const IgemmArgs& a, int TM, dim3 grid, hipStream_t s) {
+    switch (TM) {
+        case 1: hipLaunchKernelGGL((conv_igemm2_kernel<1>), grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((conv_igemm2_kernel<2>), grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((conv_igemm2_kernel<3>), grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((conv_igemm2_kernel<4>), grid, dim3(256), 0, s, a); break;
+        case 5: hipLaunchKernelGGL((conv_igemm2_kernel<5>), grid, dim3(256), 0, s, a); break;
+        case 6: hipLaunchKernelGGL((conv_igemm2_kernel<6>), grid, dim3(256), 0, s, a); break;
+        case 7: hipLaunchKernelGGL((conv_igemm2_kernel<7>), grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((conv_igemm2_kernel<8>), grid, dim3(256), 0, s, a); break;
+    }
+    return og_launch_status();
+}
+
+// Rows are covered by block rows of TM 32-row groups: `brows - 1` (or all) full-height block rows
+// in one launch, plus one launch with a smaller TM for the remaining groups (388 rows = 13 groups
+// -> 7 + 6; 194 -> 7; 768 -> 3 x 8), so that no block computes an empty row group.
+static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed) {
+    const int groups = og_cdiv(a.M, 32);
+    const int Npix = a.N * a.PH * a.PW;
+    const int tiles_n = og_cdiv(Npix, 128);
+    int TM, full_rows, rest;                             // block rows of height TM + one of height rest
+    og_row_plan(groups, tiles_n, 0, &TM, &full_rows, &rest);
+    const int tiles = (full_rows + (rest ? 1 : 0)) * tiles_n;
+    const int nk = a.Kpad / 16;
+    const bool full_cover = (a.osh == 1 && a.osw == 1 && a.PH == a.OHf && a.PW == a.OWf);
+    int splits = 1;
+    if (tiles < 128 && nk >= 16 && (full_cover || y_prezeroed)) {
+        splits = og_cdiv(512, tiles);
+        if (splits > nk / 4) splits = nk / 4;
+    }
+    const float* bias = a.bias;
+    const int act = a.act;
+    const bool act_later = (act == OG_ACT_TANH || act == OG_ACT_SIGMOID);
+    if (splits > 1) {
+        a.ksplit_steps = og_cdiv(nk, splits);
+        splits = og_cdiv(nk, a.ksplit_steps);
+        a.bias = nullptr; a.act = OG_ACT_NONE;
+        if (!y_prezeroed)
+            (void)hipMemsetAsync(a.y, 0, sizeof(float) * (size_t)a.N * a.M * a.OHf * a.OWf, s);
+    } else {
+        a.ksplit_steps = 0;
+        if (act_later) { a.bias = nullptr; a.act = OG_ACT_NONE; }
+    }
+    int rc = OG_OK;
+    if (full_rows > 0) {
+        a.m_begin = 0; a.m_end = min(a.M, full_rows * TM * 32);
+        ProfRec* pr = prof_begin(prof_cat(0, a.T, TM <= 2 ? 2 : (TM <= 4 ? 1 : 0)),
+                                 2.0 * (a.m_end - a.m_begin) * (double)a.K * (double)Npix, s);
+        rc = launch_igemm2(a, TM, dim3(full_rows * tiles_n, splits), s);
+        prof_end(pr, s);
+        if (rc != OG_OK) return rc;
+    }
+    if (rest > 0) {
+        a.m_begin = full_rows * TM * 32; a.m_end = a.M;
+        ProfRec* pr = prof_begin(prof_cat(0, a.T, rest <= 2 ? 2 : (rest <= 4 ? 1 : 0)),
+                                 2.0 * (a.m_end - a.m_begin) * (double)a.K * (double)Npix, s);
+        rc = launch_igemm2(a, rest, dim3(tiles_n, splits), s);
+        prof_end(pr, s);
+        if (rc != OG_OK) return rc;
+    }
+    if ((splits > 1 || act_later) && (bias || act != OG_ACT_NONE) && full_cover) {
+        const long total = (long)a.N * a.M * a.OHf * a.OWf;
+        hipLaunchKernelGGL(bias_act_kernel, dim3(og_stream_grid(total, 256)), dim3(256), 0, s, a.y, bias,
+                           total, a.M, a.OHf * a.OWf, act);
+        return og_launch_status();
+    }
+    return OG_OK;
+}
+
 extern "C" {
 
 // Size (in floats) of the packed-weight scratch for an M x K GEMM.
@@ -609,6 +1112,8 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
     p.w = w; p.wt = wt; p.Cout = Cout; p.Cin = Cin; p.Torig = Torig; p.Tg = Tg;
     p.M = M; p.Mpad = (M + 127) / 128 * 128; p.Ck = C; p.Cp = (C + 15) / 16 * 16;
     p.transpose = transpose;
+    const bool v2 = !og_igemm_v1() && (double)N * C * H * W * 4.0 < 4.0e9 && (double)M * Tg * p.Cp * 4.0 < 4.0e9;
+    p.m_major = v2 ? 1 : 0;
     for (int t = 0; t < OG_MAX_TAPS; ++t) p.src_tap[t] = (signed char)(t < Tg ? src_tap[t] : -1);
     const long ptotal = (long)Tg * p.Cp * p.Mpad;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(og_stream_grid(ptotal, 256)), dim3(256), 0, s, p);
@@ -630,7 +1135,7 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
         a.tap[t] = (int)(((unsigned)w_ << 16) | ((unsigned)h & 0xffffu));
     }
     if (!(osh == 1 && osw == 1 && PH == OHf && PW == OWf) && (bias || act)) return OG_BAD_ARGS;
-    return run_igemm(a, s, y_prezeroed);
+    return v2 ? run_igemm2(a, s, y_prezeroed) : run_igemm(a, s, y_prezeroed);
 }
 
 // dw must be zero-initialised by the caller (or hold a gradient to accumulate into).
@@ -649,6 +1154,50 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
     a.stride = stride; a.pad = pad; a.pad_mode = pad_mode; a.upsample = upsample;
     a.ncol = Cin * ksize * ksize;
     const int Npix = N * OH * OW;
+
+    const int OHW = OH * OW;
+    const bool v2 = !og_igemm_v1() && (OW % 8 == 0) && (OHW % 16 == 0)
+                    && (double)N * Cin * H * W * 4.0 < 4.0e9 && (double)N * Cout * OHW * 4.0 < 4.0e9;
+    if (v2) {
+        const int groups = og_cdiv(Cout, 32);
+        const int tiles_n = og_cdiv(a.ncol, 128);
+        int TM, full_rows, rest;
+        og_row_plan(groups, tiles_n, 1, &TM, &full_rows, &rest);
+        for (int part = 0; part < 2; ++part) {
+            const int tm = part == 0 ? TM : rest;
+            const int rows = part == 0 ? full_rows : (rest ? 1 : 0);
+            if (rows == 0) continue;
+            a.m_begin = part == 0 ? 0 : full_rows * TM * 32;
+            a.m_end = part == 0 ? (Cout < full_rows * TM * 32 ? Cout : full_rows * TM * 32) : Cout;
+            // split K (pixels) so that this launch fills the resident workgroup slots once
+            // (2 per CU for tall tiles, 3 up to TM = 4) without spilling into a second round
+            const int slots = 256 * (tm <= 4 ? 3 : 2);
+            int splits = slots / (rows * tiles_n);
+            const int max_splits = og_cdiv(Npix, 512);       // >= 32 K steps per split
+            if (splits > max_splits) splits = max_splits;
+            if (splits < 1) splits = 1;
+            int pps = og_cdiv(Npix, splits);
+            pps = (pps + 15) / 16 * 16;
+            splits = og_cdiv(Npix, pps);
+            a.pix_per_split = pps;
+            dim3 grid(rows * tiles_n, splits);
+            ProfRec* pr = prof_begin(prof_cat(1, ksize, tm <= 2 ? 2 : (tm <= 4 ? 1 : 0)),
+                                     2.0 * (a.m_end - a.m_begin) * (double)a.ncol * (double)Npix, s);
+            switch (tm) {
+                case 1: hipLaunchKernelGGL((conv_wgrad2_kernel<1>), grid, dim3(256), 0, s, a, ksize); break;
+                case 2: hipLaunchKernelGGL((conv_wgrad2_kernel<2>), grid, dim3(256), 0, s, a, ksize); break;
+                case 3: hipLaunchKernelGGL((conv_wgrad2_kernel<3>), grid, dim3(256), 0, s, a, ksize); break;
+                case 4: hipLaunchKernelGGL((conv_wgrad2_kernel<4>), grid, dim3(256), 0, s, a, ksize); break;
+                case 5: hipLaunchKernelGGL((conv_wgrad2_kernel<5>), grid, dim3(256), 0, s, a, ksize); break;
+                case 6: hipLaunchKernelGGL((conv_wgrad2_kernel<6>), grid, dim3(256), 0, s, a, ksize); break;
+                default: hipLaunchKernelGGL((conv_wgrad2_kernel<7>), grid, dim3(256), 0, s, a, ksize); break;
+            }
+            prof_end(pr, s);
+            int rc = og_launch_status();
+            if (rc != OG_OK) return rc;
+        }
+        return OG_OK;
+    }
 
     RowPart parts[3];
     const int np = og_row_parts(Cout, parts);
