@@ -60,14 +60,16 @@ long objgan_conv_packed_floats(int M, int C, int T);
  * upsample=1: taps address a nearest-x2 upsampled view of x; pad_mode 0 zeros, 1 reflect.
  * act: 0 none, 1 LeakyReLU(0.2), 2 tanh, 3 sigmoid, 4 ReLU.  wt: scratch of
  * objgan_conv_packed_floats(M, C, Tg) floats.  y_prezeroed=1 tells the library that y already
- * holds zeros (lets partial-coverage launches, i.e. stride-2 dgrad phases, use split-K). */
+ * holds zeros (lets partial-coverage launches, i.e. stride-2 dgrad phases, use split-K).
+ * wt_packed=1: wt still holds the packed bank written by an earlier call with the same w, taps,
+ * transpose flag and input size class (the caller caches it while w is unchanged); 0: pack now. */
 int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* y, float* wt,
                       int N, int C, int H, int W, int upsample, int pad_mode,
                       int Cout, int Cin, int Torig, int transpose,
                       int Tg, const int* dh, const int* dw, const int* src_tap,
                       int PH, int PW, int stride,
                       int OHf, int OWf, int osh, int osw, int ooh, int oow,
-                      int act, int y_prezeroed, void* stream);
+                      int act, int y_prezeroed, int wt_packed, void* stream);
 /* dw[co][ci][kh][kw] += sum dy * x (dw zero-filled / accumulated by the caller); ksize in {1,3,4} */
 int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
                       int N, int Cin, int H, int W, int upsample, int pad_mode,

@@ -475,6 +475,84 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const IgemmArgs a) {
     }
 }
 
+// =============================================================================================
+// Thin outputs (M <= 32 channels: the 80->12 / 80->24 layout-map stems, to-RGB, data gradients
+// down to the 3- / 15-channel discriminator inputs).  A 32-row MFMA tile would spend most of its
+// rows on padding; the fp32 VALU has the same peak rate as the fp32 MFMA, so these run as a direct
+// convolution: one thread = one output pixel with all M accumulators in registers, the filter bank
+// (packed [c][t][MT]) read through the scalar cache into SGPR operands of v_fmac, the T taps of a
+// channel as T coalesced buffer loads whose per-lane offsets (bounds / reflection / upsample) are
+// computed once per thread.  No LDS, no barriers.
+template <int MT, int T>
+__global__ __launch_bounds__(256) void conv_thin_kernel(const IgemmArgs a) {
+    const int Npix = a.N * a.PH * a.PW;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const bool pix_ok = pix < Npix;
+    const int HW = a.H * a.W;
+    const int ppi = a.PH * a.PW;
+    const int pp = pix_ok ? pix : 0;
+    const int n = pp / ppi;
+    const int rem = pp - n * ppi;
+    const int pa = rem / a.PW;
+    const int pb = rem - pa * a.PW;
+    const int ihb = pa * a.stride, iwb = pb * a.stride;
+    const unsigned img_off = (unsigned)n * (unsigned)a.C * (unsigned)HW;
+    const int us = a.upsample ? 1 : 0;
+    const bool refl = a.pad_mode == 1;
+    __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.x, 0, (int)((unsigned)a.N * a.C * HW * 4u), OG_BUF_FLAGS);
+
+    unsigned voff[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int tp = a.tap[t];
+        const int ih = ihb + ((tp << 16) >> 16);
+        const int iw = iwb + (tp >> 16);
+        int ihr = ih < 0 ? -ih : ih;
+        int iwr = iw < 0 ? -iw : iw;
+        ihr = ihr >= a.LH ? 2 * (a.LH - 1) - ihr : ihr;
+        iwr = iwr >= a.LW ? 2 * (a.LW - 1) - iwr : iwr;
+        const bool inb = ((unsigned)ih < (unsigned)a.LH) && ((unsigned)iw < (unsigned)a.LW);
+        const bool ok = pix_ok && (refl || inb);
+        const int ihs = (refl ? ihr : ih) >> us;
+        const int iws = (refl ? iwr : iw) >> us;
+        voff[t] = ok ? (img_off + (unsigned)(ihs * a.W + iws)) * 4u : OG_OOB;
+    }
+
+    float acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+    const float* __restrict__ wp = a.wt;
+    for (int c = 0; c < a.C; ++c) {
+        const int so = c * HW * 4;
+        float xv[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+            xv[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, voff[t], so, 0));
+        const float* __restrict__ wc = wp + (size_t)c * (T * MT);
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = fmaf(wc[t * MT + m], xv[t], acc[m]);
+    }
+
+    if (!pix_ok) return;
+    const int oh = pa * a.osh + a.ooh;
+    const int ow = pb * a.osw + a.oow;
+    const size_t plane = (size_t)a.OHf * a.OWf;
+    float* yb = a.y + (size_t)n * a.M * plane + (size_t)oh * a.OWf + ow;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (m < a.M) {
+            float v = acc[m];
+            if (a.bias) v += a.bias[m];
+            if (MT <= 4) v = og_act(v, a.act);
+            else v = a.act == OG_ACT_LRELU ? (v > 0.f ? v : 0.2f * v) : (a.act == OG_ACT_RELU ? fmaxf(v, 0.f) : v);
+            yb[(size_t)m * plane] = v;
+        }
+    }
+}
+
 // ---- weight packing ------------------------------------------------------------------
 // wt[(t*Cp + ck) * Mpad + cm] = src_tap[t] >= 0 ? w[...] : 0, zero padded to [T*Cp][Mpad].
 // w is the PyTorch conv weight [Cout][Cin][Torig].  transpose = 0: cm = cout, ck = cin
@@ -485,19 +563,29 @@ struct PackArgs {
     int Cout, Cin, Torig, Tg;
     int M, Mpad, Ck, Cp;
     int transpose;
-    int m_major;         // 0: wt[K][Mpad] (v1 kernels), 1: wt[M][Kpad] (k contiguous, v2 kernel)
+    int m_major;         // 0: wt[K][Mpad] (v1 kernels), 1: wt[M][Kpad] (k contiguous, v2 kernel),
+                         // 2: wt[Ck][Tg][Mpad] with Mpad = MT (thin direct kernel)
     signed char src_tap[OG_MAX_TAPS];
 };
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
     const int Kpad = a.Tg * a.Cp;
-    const long total = a.m_major ? (long)a.M * Kpad : (long)Kpad * a.Mpad;
+    const long total = a.m_major == 2 ? (long)a.Ck * a.Tg * a.Mpad
+                                      : (a.m_major ? (long)a.M * Kpad : (long)Kpad * a.Mpad);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long)gridDim.x * blockDim.x) {
-        const int m = a.m_major ? (int)(i / Kpad) : (int)(i % a.Mpad);
-        const int k = a.m_major ? (int)(i % Kpad) : (int)(i / a.Mpad);
-        const int t = k / a.Cp;
-        const int ck = k - t * a.Cp;
+        int m, t, ck;
+        if (a.m_major == 2) {
+            m = (int)(i % a.Mpad);
+            const int r = (int)(i / a.Mpad);
+            t = r % a.Tg;
+            ck = r / a.Tg;
+        } else {
+            m = a.m_major ? (int)(i / Kpad) : (int)(i % a.Mpad);
+            const int k = a.m_major ? (int)(i % Kpad) : (int)(i / a.Mpad);
+            t = k / a.Cp;
+            ck = k - t * a.Cp;
+        }
         float v = 0.f;
         if (m < a.M && ck < a.Ck) {
             const int st = a.src_tap[t];
@@ -1010,6 +1098,30 @@ static void og_row_plan(int groups, int tiles_n, int tall, int* TM_out, int* ful
     *TM_out = bt; *full_rows_out = groups / bt; *rest_out = groups - (groups / bt) * bt;
 }
 
+static int og_nothin() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OG_NO_THIN"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v;
+}
+
+static int run_thin(IgemmArgs a, int MT, hipStream_t s) {
+    const long Npix = (long)a.N * a.PH * a.PW;
+    dim3 grid(og_cdiv(Npix, 256));
+    a.m_begin = 0; a.m_end = a.M; a.ksplit_steps = 0;
+    ProfRec* pr = prof_begin(prof_cat(0, a.T, 2), 2.0 * a.M * (double)a.K * (double)Npix, s);
+#define OG_THIN(MTv, Tv) hipLaunchKernelGGL((conv_thin_kernel<MTv, Tv>), grid, dim3(256), 0, s, a)
+    if (a.T == 9) {
+        switch (MT) { case 4: OG_THIN(4, 9); break; case 12: OG_THIN(12, 9); break; case 16: OG_THIN(16, 9); break;
+                      case 24: OG_THIN(24, 9); break; default: OG_THIN(32, 9); break; }
+    } else {
+        switch (MT) { case 4: OG_THIN(4, 4); break; case 12: OG_THIN(12, 4); break; case 16: OG_THIN(16, 4); break;
+                      case 24: OG_THIN(24, 4); break; default: OG_THIN(32, 4); break; }
+    }
+#undef OG_THIN
+    prof_end(pr, s);
+    return og_launch_status();
+}
+
 static int launch_igemm2(const IgemmArgs& a, int TM, dim3 grid, hipStream_t s) {
     switch (TM) {
         case 1: hipLaunchKernelGGL((conv_igemm2_kernel<1>), grid, dim3(256), 0, s, a); break;
@@ -1100,7 +1212,7 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
                       int Tg, const int* dh, const int* dw, const int* src_tap,
                       int PH, int PW, int stride,
                       int OHf, int OWf, int osh, int osw, int ooh, int oow,
-                      int act, int y_prezeroed, void* stream) {
+                      int act, int y_prezeroed, int wt_packed, void* stream) {
     if (Tg < 1 || Tg > OG_MAX_TAPS) return OG_BAD_ARGS;
     if (Torig < 1 || Torig > 127) return OG_BAD_ARGS;
     const int M = transpose ? Cin : Cout;
@@ -1114,11 +1226,18 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
     p.transpose = transpose;
     const bool v2 = !og_igemm_v1() && (double)N * C * H * W * 4.0 < 4.0e9 && (double)M * Tg * p.Cp * 4.0 < 4.0e9;
     p.m_major = v2 ? 1 : 0;
+    // thin outputs: direct VALU kernel (full-coverage or strided-phase launches alike)
+    const int MT = M <= 4 ? 4 : (M <= 12 ? 12 : (M <= 16 ? 16 : (M <= 24 ? 24 : 32)));
+    const bool thin = v2 && !og_nothin() && M <= 32 && (Tg == 9 || Tg == 4) && (long)N * PH * PW >= 65536
+                      && (MT <= 4 || (act != OG_ACT_TANH && act != OG_ACT_SIGMOID));
+    if (thin) { p.m_major = 2; p.Mpad = MT; }
     for (int t = 0; t < OG_MAX_TAPS; ++t) p.src_tap[t] = (signed char)(t < Tg ? src_tap[t] : -1);
-    const long ptotal = (long)Tg * p.Cp * p.Mpad;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(og_stream_grid(ptotal, 256)), dim3(256), 0, s, p);
-    int rc = og_launch_status();
-    if (rc != OG_OK) return rc;
+    if (!wt_packed) {       // wt_packed: the caller kept wt from an earlier call with the same
+        const long ptotal = (long)Tg * p.Cp * p.Mpad;   // filter bank, taps and geometry class
+        hipLaunchKernelGGL(pack_weights_kernel, dim3(og_stream_grid(ptotal, 256)), dim3(256), 0, s, p);
+        int rc = og_launch_status();
+        if (rc != OG_OK) return rc;
+    }
 
     IgemmArgs a;
     a.x = x; a.wt = wt; a.bias = bias; a.y = y;
@@ -1135,6 +1254,7 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
         a.tap[t] = (int)(((unsigned)w_ << 16) | ((unsigned)h & 0xffffu));
     }
     if (!(osh == 1 && osw == 1 && PH == OHf && PW == OWf) && (bias || act)) return OG_BAD_ARGS;
+    if (thin) return run_thin(a, MT, s);
     return v2 ? run_igemm2(a, s, y_prezeroed) : run_igemm(a, s, y_prezeroed);
 }
 

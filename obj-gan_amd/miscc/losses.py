@@ -151,8 +151,10 @@ def patD_loss(netPatD, real_imgs, fake_imgs, conditions):
 
 def shpD_loss(netShpD, real_imgs, fake_imgs, seg_conditions, rois, num_rois):
     net = _net(netShpD)
-    real_features = netShpD(real_imgs, seg_conditions)
-    fake_features = netShpD(fake_imgs.detach(), seg_conditions)
+    # the encoded layout map is the same tensor in the real and the fake pass: evaluate it once
+    s_code = net.encode_seg(seg_conditions)
+    real_features = netShpD(real_imgs, seg_conditions, s_code=s_code)
+    fake_features = netShpD(fake_imgs.detach(), seg_conditions, s_code=s_code)
     fake_seg, valid = permute_seg(seg_conditions, rois, num_rois)
     errD = _bce(net.UNCOND_DNET(real_features), 1)
     fake_err = _bce(net.UNCOND_DNET(fake_features), 0)
@@ -173,10 +175,11 @@ def _obj_conditions(class_table, classes, bt_c_codes, count=None):
 def objD_loss(netObjD, real_imgs, fake_imgs, seg_conditions, raw_conditions, raw_bt_c_codes,
               fm_rois, num_rois, is_large_scale=False):
     net = _net(netObjD)
-    real_pooled = netObjD(real_imgs, seg_conditions, fm_rois, num_rois)
+    s_code = net.encode_seg(seg_conditions)      # shared by the real and the fake pass
+    real_pooled = netObjD(real_imgs, seg_conditions, fm_rois, num_rois, s_code=s_code)
     real_features, classes, bt_c_codes = feat_select(real_pooled, raw_bt_c_codes, fm_rois, num_rois,
                                                      is_large_scale=is_large_scale)
-    fake_pooled = netObjD(fake_imgs.detach(), seg_conditions, fm_rois, num_rois)
+    fake_pooled = netObjD(fake_imgs.detach(), seg_conditions, fm_rois, num_rois, s_code=s_code)
     fake_features, _, _ = feat_select(fake_pooled, raw_bt_c_codes, fm_rois, num_rois,
                                       is_large_scale=is_large_scale)
     fake_seg, valid = permute_seg(seg_conditions, fm_rois, num_rois)

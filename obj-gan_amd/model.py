@@ -529,8 +529,15 @@ class _ShpD(nn.Module):
         self.shp_code = _shape_stem(num_classes, ngf)
         self.UNCOND_DNET = D_GET_LOGITS(ndf, nef, bcondition=False)
 
-    def forward(self, x_var, s_var):
-        return self.img_code(torch.cat([x_var, self.shp_code(s_var)], dim=1))
+    def encode_seg(self, s_var):
+        """shp_code(s_var): a per-sample function of the layout map only, so the real and the fake
+        pass of one loss evaluation share it (miscc/losses.py); autograd sums both uses."""
+        return self.shp_code(s_var)
+
+    def forward(self, x_var, s_var, s_code=None):
+        if s_code is None:
+            s_code = self.shp_code(s_var)
+        return self.img_code(torch.cat([x_var, s_code], dim=1))
 
 
 class SHP_D_NET64(_ShpD):
@@ -559,6 +566,23 @@ def _rois_blob(fm_rois, boxes_num):
     return blob.to(torch.float32).contiguous()
 
 
+# One-entry memo of the bilinear lift of a layout map (80 channels, 256^2 -> 512^2: 1.3 GB at B=16).
+# The entry holds the source tensor itself, so its address cannot be recycled while cached; an
+# in-place torch edit of the source changes `_version` and misses.
+_LIFT = {"src": None, "ver": -1, "size": 0, "out": None}
+
+
+def _lift_cached(s_var, img_size):
+    if s_var.requires_grad:
+        return ops.bilinear_resize(s_var, img_size, img_size)
+    c = _LIFT
+    if c["src"] is s_var and c["ver"] == s_var._version and c["size"] == img_size:
+        return c["out"]
+    out = ops.bilinear_resize(s_var, img_size, img_size)
+    c["src"], c["ver"], c["size"], c["out"] = s_var, s_var._version, img_size, out
+    return out
+
+
 class _ObjD(nn.Module):
     """ROIAlign-based object discriminator (reference model.py:1184-1312)."""
 
@@ -583,10 +607,18 @@ class _ObjD(nn.Module):
         self.UNCOND_DNET = D_GET_LOGITS(ndf // 2, nef, bcondition=False) if b_jcu else None
         self.COND_DNET = D_GET_LOGITS(ndf // 2, nef, bcondition=True)
 
-    def forward(self, x_var, s_var, fm_rois, num_rois, img_size=512):
+    def encode_seg(self, s_var, img_size=512):
+        """shp_code(lift(s_var)) (reference model.py:1218-1226): depends on the layout map only, so
+        the real and fake passes of one loss evaluation share it; the parameter-free bilinear lift
+        to img_size is shared further -- by both object discriminators and by every pass of a step
+        that sees the same layout tensor."""
+        return self.shp_code(_lift_cached(s_var, img_size))
+
+    def forward(self, x_var, s_var, fm_rois, num_rois, img_size=512, s_code=None):
         x_var = ops.bilinear_resize(x_var, img_size, img_size)
-        s_var = ops.bilinear_resize(s_var, img_size, img_size)
-        x_code = self.img_code(torch.cat([x_var, self.shp_code(s_var)], dim=1))
+        if s_code is None:
+            s_code = self.encode_seg(s_var, img_size)
+        x_code = self.img_code(torch.cat([x_var, s_code], dim=1))
         batch_size = fm_rois.shape[0]
         rois = _rois_blob(fm_rois, cfg.ROI.BOXES_NUM)
         pooled = self.roi_code(self.RoIAlignAvg(x_code, rois))

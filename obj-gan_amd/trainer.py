@@ -57,8 +57,10 @@ class ParamArena(object):
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.step_count = 0
         self._views = []
+        self.epoch = [0]      # bumped by every optimizer step: ops' packed-filter cache keys on it
         off = 0
         for p in self.params:
+            p._og_epoch = self.epoch
             k = p.numel()
             self.flat[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + k].view_as(p)
@@ -103,6 +105,7 @@ class ArenaAdam(object):
         a = self.arena
         a.sync_grads()
         a.step_count += 1
+        a.epoch[0] += 1
         ops.adam_step_(a.flat, a.grad, a.exp_avg, a.exp_avg_sq, self.param_groups[0]["lr"],
                        self.betas[0], self.betas[1], self.eps, a.step_count, grad_scale=grad_scale,
                        n=a.n)
