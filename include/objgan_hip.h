@@ -70,6 +70,14 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
                       int PH, int PW, int stride,
                       int OHf, int OWf, int osh, int osw, int ooh, int oow,
                       int act, int y_prezeroed, int wt_packed, void* stream);
+/* Data gradient of a stride-2 convolution whose four output parity phases have the same number
+ * of taps (k=4, pad 1, even sizes): one launch for all phases.  x = dY [N,Cout,OH,OW],
+ * y = dX [N,Cin,2*PH,2*PW], fully written (no pre-zeroing).  dh/dw/src_tap: 4 x Tg entries, phase
+ * p = (row parity << 1) | column parity.  wt: 4*Cin*Tg*ceil16(Cout) floats; wt_packed as above. */
+int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float* wt,
+                                int N, int Cout, int OH, int OW, int Cin, int Torig,
+                                int Tg, const int* dh, const int* dw, const int* src_tap,
+                                int PH, int PW, int wt_packed, void* stream);
 /* dw[co][ci][kh][kw] += sum dy * x (dw zero-filled / accumulated by the caller); ksize in {1,3,4} */
 int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
                       int N, int Cin, int H, int W, int upsample, int pad_mode,

@@ -60,6 +60,8 @@ struct IgemmArgs {
     int upsample;        // 1 = source index = logical index >> 1
     int act;
     int ksplit_steps;    // > 0: split-K -- blockIdx.y owns this many BK steps, epilogue = atomicAdd
+    int nphase;          // > 1 (v2 kernel only): blockIdx.z = output phase p with its own tap table
+                         // tap[p*8 ..], packed bank wt + p*M*Kpad and output offset (ooh, oow) = (p>>1, p&1)
     int tap[OG_MAX_TAPS];   // (dw << 16) | (dh & 0xffff): one scalar load per (uniform) tap
 };
 
@@ -308,11 +310,13 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const IgemmArgs a) {
     const int m0 = a.m_begin + tile_m * BM;
     const int n0 = tile_n * BN;
 
+    const int phase = a.nphase > 1 ? (int)blockIdx.z : 0;      // wave-uniform
+    const int tapbase = phase * 8;
     const int HW = a.H * a.W;
     __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
         (void*)a.x, 0, (int)((unsigned)a.N * a.C * HW * 4u), OG_BUF_FLAGS);
     __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.wt, 0, (int)((unsigned)a.M * a.Kpad * 4u), OG_BUF_FLAGS);
+        (void*)(a.wt + (size_t)phase * a.M * a.Kpad), 0, (int)((unsigned)a.M * a.Kpad * 4u), OG_BUF_FLAGS);
 
     // ---- B gather geometry: thread = (pixel p of the tile, k half g)
     const int bp = tid & (BN - 1);
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const IgemmArgs a) {
     const bool refl = a.pad_mode == 1;
     unsigned bvoff = OG_OOB;                         // byte offset of (n, c = 0, ih, iw) or out of range
     auto tap_geometry = [&](int t) {
-        const int tp = a.tap[t];
+        const int tp = a.tap[tapbase + t];
         const int ih = ihb + ((tp << 16) >> 16);
         const int iw = iwb + (tp >> 16);
         int ihr = ih < 0 ? -ih : ih;
@@ -450,8 +454,8 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const IgemmArgs a) {
     const int rem = p - n * ppi;
     const int pa = rem / a.PW;
     const int pb = rem - pa * a.PW;
-    const int oh = pa * a.osh + a.ooh;
-    const int ow = pb * a.osw + a.oow;
+    const int oh = pa * a.osh + (a.nphase > 1 ? (phase >> 1) : a.ooh);
+    const int ow = pb * a.osw + (a.nphase > 1 ? (phase & 1) : a.oow);
     const size_t plane = (size_t)a.OHf * a.OWf;
     float* yb = a.y + (size_t)n * a.M * plane + (size_t)oh * a.OWf + ow;
     const bool split = a.ksplit_steps > 0;
@@ -483,72 +487,202 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const IgemmArgs a) {
 // (packed [c][t][MT]) read through the scalar cache into SGPR operands of v_fmac, the T taps of a
 // channel as T coalesced buffer loads whose per-lane offsets (bounds / reflection / upsample) are
 // computed once per thread.  No LDS, no barriers.
-template <int MT, int T>
+template <int MT, int T, int PX>
 __global__ __launch_bounds__(256) void conv_thin_kernel(const IgemmArgs a) {
+    // PX output pixels per thread (256 apart): every SGPR filter operand feeds PX FMAs, which
+    // keeps the scalar cache (shared between CUs) off the critical path.
     const int Npix = a.N * a.PH * a.PW;
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    const bool pix_ok = pix < Npix;
     const int HW = a.H * a.W;
     const int ppi = a.PH * a.PW;
-    const int pp = pix_ok ? pix : 0;
-    const int n = pp / ppi;
-    const int rem = pp - n * ppi;
-    const int pa = rem / a.PW;
-    const int pb = rem - pa * a.PW;
-    const int ihb = pa * a.stride, iwb = pb * a.stride;
-    const unsigned img_off = (unsigned)n * (unsigned)a.C * (unsigned)HW;
     const int us = a.upsample ? 1 : 0;
     const bool refl = a.pad_mode == 1;
     __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
         (void*)a.x, 0, (int)((unsigned)a.N * a.C * HW * 4u), OG_BUF_FLAGS);
 
-    unsigned voff[T];
+    unsigned voff[PX][T];
+    bool pix_ok[PX];
+    int on[PX], oa[PX], ob[PX];
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const int tp = a.tap[t];
-        const int ih = ihb + ((tp << 16) >> 16);
-        const int iw = iwb + (tp >> 16);
-        int ihr = ih < 0 ? -ih : ih;
-        int iwr = iw < 0 ? -iw : iw;
-        ihr = ihr >= a.LH ? 2 * (a.LH - 1) - ihr : ihr;
-        iwr = iwr >= a.LW ? 2 * (a.LW - 1) - iwr : iwr;
-        const bool inb = ((unsigned)ih < (unsigned)a.LH) && ((unsigned)iw < (unsigned)a.LW);
-        const bool ok = pix_ok && (refl || inb);
-        const int ihs = (refl ? ihr : ih) >> us;
-        const int iws = (refl ? iwr : iw) >> us;
-        voff[t] = ok ? (img_off + (unsigned)(ihs * a.W + iws)) * 4u : OG_OOB;
+    for (int j = 0; j < PX; ++j) {
+        const int pix = (blockIdx.x * PX + j) * 256 + threadIdx.x;
+        pix_ok[j] = pix < Npix;
+        const int pp = pix_ok[j] ? pix : 0;
+        const int n = pp / ppi;
+        const int rem = pp - n * ppi;
+        const int pa = rem / a.PW;
+        const int pb = rem - pa * a.PW;
+        on[j] = n; oa[j] = pa; ob[j] = pb;
+        const int ihb = pa * a.stride, iwb = pb * a.stride;
+        const unsigned img_off = (unsigned)n * (unsigned)a.C * (unsigned)HW;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int tp = a.tap[t];
+            const int ih = ihb + ((tp << 16) >> 16);
+            const int iw = iwb + (tp >> 16);
+            int ihr = ih < 0 ? -ih : ih;
+            int iwr = iw < 0 ? -iw : iw;
+            ihr = ihr >= a.LH ? 2 * (a.LH - 1) - ihr : ihr;
+            iwr = iwr >= a.LW ? 2 * (a.LW - 1) - iwr : iwr;
+            const bool inb = ((unsigned)ih < (unsigned)a.LH) && ((unsigned)iw < (unsigned)a.LW);
+            const bool ok = pix_ok[j] && (refl || inb);
+            const int ihs = (refl ? ihr : ih) >> us;
+            const int iws = (refl ? iwr : iw) >> us;
+            voff[j][t] = ok ? (img_off + (unsigned)(ihs * a.W + iws)) * 4u : OG_OOB;
+        }
     }
 
-    float acc[MT];
+    float acc[PX][MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+    for (int j = 0; j < PX; ++j)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[j][m] = 0.f;
     const float* __restrict__ wp = a.wt;
-    for (int c = 0; c < a.C; ++c) {
-        const int so = c * HW * 4;
-        float xv[T];
+    // the taps of the next channel are always in flight behind the FMAs of the current one (the
+    // bank carries one zero channel of padding, so an odd C needs no branch)
+    auto load_taps = [&](float (&xv)[PX][T], int c) {
+        const int so = min(c, a.C - 1) * HW * 4;
 #pragma unroll
-        for (int t = 0; t < T; ++t)
-            xv[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, voff[t], so, 0));
+        for (int j = 0; j < PX; ++j)
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                xv[j][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, voff[j][t], so, 0));
+    };
+    auto fma_taps = [&](const float (&xv)[PX][T], int c) {
         const float* __restrict__ wc = wp + (size_t)c * (T * MT);
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = fmaf(wc[t * MT + m], xv[t], acc[m]);
+            for (int m = 0; m < MT; ++m) {
+                const float wv = wc[t * MT + m];
+#pragma unroll
+                for (int j = 0; j < PX; ++j) acc[j][m] = fmaf(wv, xv[j][t], acc[j][m]);
+            }
+    };
+    float xa[PX][T], xb[PX][T];
+    load_taps(xa, 0);
+    for (int c = 0; c < a.C; c += 2) {
+        load_taps(xb, c + 1);
+        fma_taps(xa, c);
+        load_taps(xa, c + 2);
+        fma_taps(xb, c + 1);
     }
 
-    if (!pix_ok) return;
-    const int oh = pa * a.osh + a.ooh;
-    const int ow = pb * a.osw + a.oow;
     const size_t plane = (size_t)a.OHf * a.OWf;
-    float* yb = a.y + (size_t)n * a.M * plane + (size_t)oh * a.OWf + ow;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        if (m < a.M) {
-            float v = acc[m];
-            if (a.bias) v += a.bias[m];
-            if (MT <= 4) v = og_act(v, a.act);
-            else v = a.act == OG_ACT_LRELU ? (v > 0.f ? v : 0.2f * v) : (a.act == OG_ACT_RELU ? fmaxf(v, 0.f) : v);
-            yb[(size_t)m * plane] = v;
+    for (int j = 0; j < PX; ++j) {
+        if (!pix_ok[j]) continue;
+        const int oh = oa[j] * a.osh + a.ooh;
+        const int ow = ob[j] * a.osw + a.oow;
+        float* yb = a.y + (size_t)on[j] * a.M * plane + (size_t)oh * a.OWf + ow;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (m < a.M) {
+                float v = acc[j][m];
+                if (a.bias) v += a.bias[m];
+                if (MT <= 4) v = og_act(v, a.act);
+                else v = a.act == OG_ACT_LRELU ? (v > 0.f ? v : 0.2f * v) : (a.act == OG_ACT_RELU ? fmaxf(v, 0.f) : v);
+                yb[(size_t)m * plane] = v;
+            }
+        }
+    }
+}
+
+// 3x3 / stride 1 / pad 1 specialisation of the thin kernel (layout-map stems, to-RGB): one thread =
+// one output COLUMN of R consecutive rows.  The (R+2) x 3 input window of a channel is loaded once
+// (lanes = consecutive columns: fully coalesced dwords) and serves all R pixels -- (R+2)*3/R loads per
+// pixel and channel instead of 9; the generic kernel is bound by the vector-memory issue rate of
+// its nine tap loads, not by the FMAs.
+template <int MT, int R>
+__global__ __launch_bounds__(256) void conv_thin3x3_kernel(const IgemmArgs a) {
+    const int HW = a.H * a.W;
+    const int strips = (a.PH + R - 1) / R;
+    const int per_img = strips * a.PW;
+    const int total = a.N * per_img;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const bool t_ok = gid < total;
+    const int g = t_ok ? gid : 0;
+    const int n = g / per_img;
+    const int rem = g - n * per_img;
+    const int sr = rem / a.PW;
+    const int pb = rem - sr * a.PW;
+    const int pa0 = sr * R;
+    const int us = a.upsample ? 1 : 0;
+    const bool refl = a.pad_mode == 1;
+    __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.x, 0, (int)((unsigned)a.N * a.C * HW * 4u), OG_BUF_FLAGS);
+    const unsigned img_off = (unsigned)n * (unsigned)a.C * (unsigned)HW;
+
+    unsigned voff[R + 2][3];
+#pragma unroll
+    for (int r = 0; r < R + 2; ++r) {
+        const int ih = pa0 + r - 1;
+        int ihr = ih < 0 ? -ih : ih;
+        ihr = ihr >= a.LH ? 2 * (a.LH - 1) - ihr : ihr;
+        ihr = ihr < 0 ? 0 : ihr;                      // rows past the last strip row (unused)
+        const bool rok = t_ok && (refl ? (ih <= a.LH) : ((unsigned)ih < (unsigned)a.LH));
+        const int ihs = (refl ? ihr : ih) >> us;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int iw = pb + c - 1;
+            int iwr = iw < 0 ? -iw : iw;
+            iwr = iwr >= a.LW ? 2 * (a.LW - 1) - iwr : iwr;
+            const bool ok = rok && (refl || (unsigned)iw < (unsigned)a.LW);
+            const int iws = (refl ? iwr : iw) >> us;
+            voff[r][c] = ok ? (img_off + (unsigned)(ihs * a.W + iws)) * 4u : OG_OOB;
+        }
+    }
+
+    float acc[R][MT];
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[j][m] = 0.f;
+    const float* __restrict__ wp = a.wt;
+    auto load_win = [&](float (&xv)[R + 2][3], int c) {
+        const int so = min(c, a.C - 1) * HW * 4;
+#pragma unroll
+        for (int r = 0; r < R + 2; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                xv[r][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, voff[r][q], so, 0));
+    };
+    auto fma_win = [&](const float (&xv)[R + 2][3], int c) {
+        const float* __restrict__ wc = wp + (size_t)c * (9 * MT);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const float wv = wc[(kh * 3 + kw) * MT + m];
+#pragma unroll
+                    for (int j = 0; j < R; ++j) acc[j][m] = fmaf(wv, xv[j + kh][kw], acc[j][m]);
+                }
+    };
+    float xa[R + 2][3], xb[R + 2][3];
+    load_win(xa, 0);
+    for (int c = 0; c < a.C; c += 2) {
+        load_win(xb, c + 1);
+        fma_win(xa, c);
+        load_win(xa, c + 2);
+        fma_win(xb, c + 1);
+    }
+
+    if (!t_ok) return;
+    const size_t plane = (size_t)a.OHf * a.OWf;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        if (pa0 + j >= a.PH) break;
+        float* yb = a.y + (size_t)n * a.M * plane + (size_t)(pa0 + j) * a.OWf + pb;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (m < a.M) {
+                float v = acc[j][m];
+                if (a.bias) v += a.bias[m];
+                if (MT <= 4) v = og_act(v, a.act);
+                else v = a.act == OG_ACT_LRELU ? (v > 0.f ? v : 0.2f * v) : (a.act == OG_ACT_RELU ? fmaxf(v, 0.f) : v);
+                yb[(size_t)m * plane] = v;
+            }
         }
     }
 }
@@ -570,7 +704,7 @@ struct PackArgs {
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
     const int Kpad = a.Tg * a.Cp;
-    const long total = a.m_major == 2 ? (long)a.Ck * a.Tg * a.Mpad
+    const long total = a.m_major == 2 ? (long)(a.Ck + 1) * a.Tg * a.Mpad   // + one zero channel
                                       : (a.m_major ? (long)a.M * Kpad : (long)Kpad * a.Mpad);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long)gridDim.x * blockDim.x) {
@@ -1106,10 +1240,31 @@ static int og_nothin() {
 
 static int run_thin(IgemmArgs a, int MT, hipStream_t s) {
     const long Npix = (long)a.N * a.PH * a.PW;
-    dim3 grid(og_cdiv(Npix, 256));
+    bool canon = a.T == 9 && a.stride == 1 && a.osh == 1 && a.osw == 1 && a.ooh == 0 && a.oow == 0
+                 && a.PH == a.OHf && a.PW == a.OWf && a.PH == a.LH && a.PW == a.LW;
+    for (int t = 0; canon && t < 9; ++t)
+        canon = a.tap[t] == (int)((((unsigned)(t % 3 - 1)) << 16) | ((unsigned)(t / 3 - 1) & 0xffffu));
+    if (canon) {
+        const int R = MT <= 16 ? 4 : 2;
+        const long threads = (long)a.N * og_cdiv(a.PH, R) * a.PW;
+        dim3 g3(og_cdiv(threads, 256));
+        a.m_begin = 0; a.m_end = a.M; a.ksplit_steps = 0;
+        ProfRec* pr = prof_begin(prof_cat(0, a.T, 2), 2.0 * a.M * (double)a.K * (double)Npix, s);
+        switch (MT) {
+            case 4: hipLaunchKernelGGL((conv_thin3x3_kernel<4, 4>), g3, dim3(256), 0, s, a); break;
+            case 12: hipLaunchKernelGGL((conv_thin3x3_kernel<12, 4>), g3, dim3(256), 0, s, a); break;
+            case 16: hipLaunchKernelGGL((conv_thin3x3_kernel<16, 4>), g3, dim3(256), 0, s, a); break;
+            case 24: hipLaunchKernelGGL((conv_thin3x3_kernel<24, 2>), g3, dim3(256), 0, s, a); break;
+            default: hipLaunchKernelGGL((conv_thin3x3_kernel<32, 2>), g3, dim3(256), 0, s, a); break;
+        }
+        prof_end(pr, s);
+        return og_launch_status();
+    }
+    const int PX = MT <= 16 ? 2 : 1;
+    dim3 grid(og_cdiv(Npix, 256 * PX));
     a.m_begin = 0; a.m_end = a.M; a.ksplit_steps = 0;
     ProfRec* pr = prof_begin(prof_cat(0, a.T, 2), 2.0 * a.M * (double)a.K * (double)Npix, s);
-#define OG_THIN(MTv, Tv) hipLaunchKernelGGL((conv_thin_kernel<MTv, Tv>), grid, dim3(256), 0, s, a)
+#define OG_THIN(MTv, Tv) hipLaunchKernelGGL((conv_thin_kernel<MTv, Tv, (MTv <= 16 ? 2 : 1)>), grid, dim3(256), 0, s, a)
     if (a.T == 9) {
         switch (MT) { case 4: OG_THIN(4, 9); break; case 12: OG_THIN(12, 9); break; case 16: OG_THIN(16, 9); break;
                       case 24: OG_THIN(24, 9); break; default: OG_THIN(32, 9); break; }
@@ -1143,13 +1298,14 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed) {
     const int groups = og_cdiv(a.M, 32);
     const int Npix = a.N * a.PH * a.PW;
     const int tiles_n = og_cdiv(Npix, 128);
+    const int nph = a.nphase > 1 ? a.nphase : 1;
     int TM, full_rows, rest;                             // block rows of height TM + one of height rest
-    og_row_plan(groups, tiles_n, 0, &TM, &full_rows, &rest);
+    og_row_plan(groups, tiles_n * nph, 0, &TM, &full_rows, &rest);
     const int tiles = (full_rows + (rest ? 1 : 0)) * tiles_n;
     const int nk = a.Kpad / 16;
     const bool full_cover = (a.osh == 1 && a.osw == 1 && a.PH == a.OHf && a.PW == a.OWf);
     int splits = 1;
-    if (tiles < 128 && nk >= 16 && (full_cover || y_prezeroed)) {
+    if (tiles < 128 && nk >= 16 && (full_cover || y_prezeroed) && nph == 1) {
         splits = og_cdiv(512, tiles);
         if (splits > nk / 4) splits = nk / 4;
     }
@@ -1170,16 +1326,16 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed) {
     if (full_rows > 0) {
         a.m_begin = 0; a.m_end = min(a.M, full_rows * TM * 32);
         ProfRec* pr = prof_begin(prof_cat(0, a.T, TM <= 2 ? 2 : (TM <= 4 ? 1 : 0)),
-                                 2.0 * (a.m_end - a.m_begin) * (double)a.K * (double)Npix, s);
-        rc = launch_igemm2(a, TM, dim3(full_rows * tiles_n, splits), s);
+                                 2.0 * (a.m_end - a.m_begin) * (double)a.K * (double)Npix * nph, s);
+        rc = launch_igemm2(a, TM, dim3(full_rows * tiles_n, splits, nph), s);
         prof_end(pr, s);
         if (rc != OG_OK) return rc;
     }
     if (rest > 0) {
         a.m_begin = full_rows * TM * 32; a.m_end = a.M;
         ProfRec* pr = prof_begin(prof_cat(0, a.T, rest <= 2 ? 2 : (rest <= 4 ? 1 : 0)),
-                                 2.0 * (a.m_end - a.m_begin) * (double)a.K * (double)Npix, s);
-        rc = launch_igemm2(a, rest, dim3(tiles_n, splits), s);
+                                 2.0 * (a.m_end - a.m_begin) * (double)a.K * (double)Npix * nph, s);
+        rc = launch_igemm2(a, rest, dim3(tiles_n, splits, nph), s);
         prof_end(pr, s);
         if (rc != OG_OK) return rc;
     }
@@ -1249,6 +1405,7 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
     a.osh = osh; a.osw = osw; a.ooh = ooh; a.oow = oow;
     a.stride = stride; a.pad_mode = pad_mode; a.upsample = upsample; a.act = act;
     a.ksplit_steps = 0;
+    a.nphase = 0;
     for (int t = 0; t < OG_MAX_TAPS; ++t) {
         const int h = t < Tg ? dh[t] : 0, w_ = t < Tg ? dw[t] : 0;
         a.tap[t] = (int)(((unsigned)w_ << 16) | ((unsigned)h & 0xffffu));
@@ -1256,6 +1413,52 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
     if (!(osh == 1 && osw == 1 && PH == OHf && PW == OWf) && (bias || act)) return OG_BAD_ARGS;
     if (thin) return run_thin(a, MT, s);
     return v2 ? run_igemm2(a, s, y_prezeroed) : run_igemm(a, s, y_prezeroed);
+}
+
+// Data gradient of a stride-2 convolution whose four output parity phases have the same tap count
+// (k = 4, pad 1, even sizes: 2x2 taps each): ONE launch, blockIdx.z = phase.  x = dY [N, Cout, OH, OW],
+// y = dX [N, Cin, 2*PH, 2*PW] (every element is written by exactly one phase: no pre-zeroing).
+// dh/dw/src_tap: 4 phases x Tg entries, phase p = (row parity << 1) | column parity.
+// wt: 4 * Cin * Tg * ceil16(Cout) floats (<= 4 x objgan_conv_packed_floats(Cin, Cout, Tg)).
+int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float* wt,
+                                int N, int Cout, int OH, int OW, int Cin, int Torig,
+                                int Tg, const int* dh, const int* dw, const int* src_tap,
+                                int PH, int PW, int wt_packed, void* stream) {
+    if (Tg < 1 || Tg > 8) return OG_BAD_ARGS;
+    if (Torig < 1 || Torig > 127) return OG_BAD_ARGS;
+    if (N <= 0 || PH <= 0 || PW <= 0 || Cin <= 0) return OG_OK;
+    const int M = Cin, C = Cout;
+    const int Cp = (C + 15) / 16 * 16;
+    if ((double)N * C * OH * OW * 4.0 >= 4.0e9 || (double)M * Tg * Cp * 4.0 >= 4.0e9) return OG_BAD_ARGS;
+    hipStream_t s = (hipStream_t)stream;
+    const long bank = (long)M * Tg * Cp;             // phase banks are stored back to back
+    if (!wt_packed) {
+        for (int ph = 0; ph < 4; ++ph) {
+            PackArgs p;
+            p.w = w; p.wt = wt + ph * bank; p.Cout = Cout; p.Cin = Cin; p.Torig = Torig; p.Tg = Tg;
+            p.M = M; p.Mpad = (M + 127) / 128 * 128; p.Ck = C; p.Cp = Cp;
+            p.transpose = 1; p.m_major = 1;
+            for (int t = 0; t < OG_MAX_TAPS; ++t) p.src_tap[t] = (signed char)(t < Tg ? src_tap[ph * Tg + t] : -1);
+            hipLaunchKernelGGL(pack_weights_kernel, dim3(og_stream_grid(bank, 256)), dim3(256), 0, s, p);
+            int rc = og_launch_status();
+            if (rc != OG_OK) return rc;
+        }
+    }
+    IgemmArgs a;
+    a.x = x; a.wt = wt; a.bias = nullptr; a.y = y;
+    a.N = N; a.C = C; a.H = OH; a.W = OW; a.LH = OH; a.LW = OW;
+    a.M = M; a.Mpad = (M + 127) / 128 * 128; a.K = C * Tg; a.Kpad = Tg * Cp; a.T = Tg; a.Cp = Cp;
+    a.m_begin = 0; a.m_end = M;
+    a.PH = PH; a.PW = PW; a.OHf = 2 * PH; a.OWf = 2 * PW;
+    a.osh = 2; a.osw = 2; a.ooh = 0; a.oow = 0;
+    a.stride = 1; a.pad_mode = 0; a.upsample = 0; a.act = OG_ACT_NONE;
+    a.ksplit_steps = 0;
+    a.nphase = 4;
+    for (int t = 0; t < OG_MAX_TAPS; ++t) a.tap[t] = 0;
+    for (int ph = 0; ph < 4; ++ph)
+        for (int t = 0; t < Tg; ++t)
+            a.tap[ph * 8 + t] = (int)(((unsigned)dw[ph * Tg + t] << 16) | ((unsigned)dh[ph * Tg + t] & 0xffffu));
+    return run_igemm2(a, s, 0);
 }
 
 // dw must be zero-initialised by the caller (or hold a gradient to accumulate into).

@@ -28,6 +28,8 @@ SIGNATURES = {
                           _c_int, _c_int, _c_int,
                           _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                           _c_int, _c_int, _c_int, _ptr],
+    "objgan_conv_dgrad_s2_phases": [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                    _c_int, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _ptr],
     "objgan_conv_wgrad": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                           _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_norm_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,

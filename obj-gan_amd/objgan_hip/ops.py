@@ -96,6 +96,42 @@ def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, tran
               OHf, OWf, osh, osw, ooh, oow, act, int(y_prezeroed), packed, _stream())
 
 
+def _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad_h, pad_w, LH, LW):
+    """dX of a stride-2 conv in ONE launch when every output parity phase has the same tap count
+    (k even, even sizes); returns None when the shape does not qualify."""
+    KH, KW = (k, k) if isinstance(k, int) else k
+    if KH % 2 or KW % 2 or LH % 2 or LW % 2 or Cin <= 32:
+        return None
+    if float(N) * Cout * OH * OW * 4.0 >= 4.0e9:
+        return None
+    dh, dw, st = [], [], []
+    for a in range(2):
+        khs = [kh for kh in range(KH) if (a + pad_h - kh) % 2 == 0]
+        for b in range(2):
+            kws = [kw for kw in range(KW) if (b + pad_w - kw) % 2 == 0]
+            dh += [(a + pad_h - kh) // 2 for kh in khs for kw in kws]
+            dw += [(b + pad_w - kw) // 2 for kh in khs for kw in kws]
+            st += [kh * KW + kw for kh in khs for kw in kws]
+    Tg = len(st) // 4
+    if Tg > 8:
+        return None
+    dx = torch.empty((N, Cin, LH, LW), dtype=_F32, device=g.device)
+    n = 4 * Cin * Tg * ((Cout + 15) // 16 * 16)
+    key = _pack_key(w, 2, st, False)
+    ent = _PACK_CACHE.get(key) if key is not None else None
+    if ent is not None and ent[0] is w:
+        wt, packed = ent[1], 1
+    else:
+        wt, packed = torch.empty(n, dtype=_F32, device=g.device), 0
+        if key is not None:
+            if len(_PACK_CACHE) >= _PACK_CACHE_MAX:
+                _PACK_CACHE.clear()
+            _PACK_CACHE[key] = (w, wt)
+    _lib.call("objgan_conv_dgrad_s2_phases", _p(g), _p(w), _p(dx), _p(wt), N, Cout, OH, OW, Cin, KH * KW,
+              Tg, _iarr(dh), _iarr(dw), _iarr(st), LH // 2, LW // 2, packed, _stream())
+    return dx
+
+
 def _pad_taps(dh, dw, st):
     """(kept for callers) the GEMM accepts any tap count up to 32: nothing to pad."""
     if len(dh) > 32:
@@ -175,8 +211,11 @@ class _Conv2dFn(torch.autograd.Function):
             elif stride == 2:
                 if refl:
                     raise _lib.ObjganHipError("stride-2 reflect conv is not on the hot path")
-                dxl = torch.zeros((N, Cin, LH, LW), dtype=_F32, device=x.device)
-                for ph in range(2):
+                dxl = _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad, pad, LH, LW)
+                phases = range(2) if dxl is None else ()
+                if dxl is None:
+                    dxl = torch.zeros((N, Cin, LH, LW), dtype=_F32, device=x.device)
+                for ph in phases:
                     khs = [kh for kh in range(k) if (ph + pad - kh) % 2 == 0]
                     PHg = (LH - ph + 1) // 2
                     for pw in range(2):
@@ -261,8 +300,11 @@ class _ConvFrozenFn(torch.autograd.Function):
             _igemm(g, w, None, dx, N, Cout, OH, OW, 0, 0, Cout, Cin, T, 1, dh, dw, list(range(T)),
                    H, W, 1, H, W, 1, 1, 0, 0, 0)
         elif stride == 2:
-            dx = torch.zeros((N, Cin, H, W), dtype=_F32, device=dy.device)
-            for a in range(2):
+            dx = _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, (KH, KW), ph, pw, H, W)
+            phases = range(2) if dx is None else ()
+            if dx is None:
+                dx = torch.zeros((N, Cin, H, W), dtype=_F32, device=dy.device)
+            for a in phases:
                 khs = [kh for kh in range(KH) if (a + ph - kh) % 2 == 0]
                 PHg = (H - a + 1) // 2
                 for b in range(2):

@@ -90,6 +90,16 @@ int main(int argc, char** argv) {
                 int rc = objgan_conv_igemm(dg, dw, nullptr, dgx, wt, sh.N, sh.Cout, OH, OW, 0, 0, sh.Cout, sh.Cin, T, 1,
                                            T, h2.data(), w2.data(), stp.data(), TH, TW, 1, TH, TW, 1, 1, 0, 0, 0, 0, 0, st);
                 if (rc != 1) { fprintf(stderr, "dgrad rc=%d\n", rc); exit(1); }
+            } else if (sh.k % 2 == 0 && LH % 2 == 0 && sh.Cin > 32) {
+                std::vector<int> h2, w2, s2;
+                for (int ph = 0; ph < 2; ++ph) for (int pw = 0; pw < 2; ++pw)
+                    for (int kh = 0; kh < sh.k; ++kh) if (((ph + sh.p - kh) % 2 + 2) % 2 == 0)
+                        for (int kw = 0; kw < sh.k; ++kw) if (((pw + sh.p - kw) % 2 + 2) % 2 == 0) {
+                            h2.push_back((ph + sh.p - kh) / 2); w2.push_back((pw + sh.p - kw) / 2); s2.push_back(kh * sh.k + kw);
+                        }
+                int rc = objgan_conv_dgrad_s2_phases(dg, dw, dgx, wt, sh.N, sh.Cout, OH, OW, sh.Cin, T, (int)h2.size() / 4,
+                                                     h2.data(), w2.data(), s2.data(), LH / 2, LW / 2, 0, st);
+                if (rc != 1) { fprintf(stderr, "dgrad phases rc=%d\n", rc); exit(1); }
             } else {
                 CK(hipMemsetAsync(dgx, 0, ngx * 4, st));
                 for (int ph = 0; ph < 2; ++ph) for (int pw = 0; pw < 2; ++pw) {
@@ -160,9 +170,33 @@ int main(int argc, char** argv) {
             const double got = hgw[((size_t)co * sh.Cin + ci) * T + t];
             maxerr_w = fmax(maxerr_w, fabs(got - acc)); maxref_w = fmax(maxref_w, fabs(acc));
         }
-        printf("%-32s fwd %7.3f ms %6.1f TF | dgrad %7.3f ms %6.1f TF | wgrad %7.3f ms %6.1f TF | err f %.1e w %.1e\n",
+        double maxerr_d = 0, maxref_d = 0;
+        {
+            std::vector<float> hgx(ngx);
+            CK(hipMemcpy(hgx.data(), dgx, ngx * 4, hipMemcpyDeviceToHost));
+            for (int smp = 0; smp < 24; ++smp) {
+                g_seed = g_seed * 1664525u + 1013904223u; const int n = (g_seed >> 8) % sh.N;
+                g_seed = g_seed * 1664525u + 1013904223u; const int ci = (g_seed >> 8) % sh.Cin;
+                g_seed = g_seed * 1664525u + 1013904223u; int ih = (g_seed >> 8) % TH;
+                g_seed = g_seed * 1664525u + 1013904223u; int iw = (g_seed >> 8) % TW;
+                if (smp < 4) { ih = (smp & 1) ? TH - 1 : 0; iw = (smp & 2) ? TW - 1 : 0; }
+                // dgx is w.r.t. the (reflect-)padded / upsampled logical input [TH x TW]
+                const int pe = sh.refl ? 0 : sh.p;
+                double acc = 0;
+                for (int co = 0; co < sh.Cout; ++co) for (int kh = 0; kh < sh.k; ++kh) for (int kw = 0; kw < sh.k; ++kw) {
+                    const int nh = ih + pe - kh, nw_ = iw + pe - kw;
+                    if (nh < 0 || nw_ < 0 || nh % sh.s || nw_ % sh.s) continue;
+                    const int oh = nh / sh.s, ow = nw_ / sh.s;
+                    if (oh >= OH || ow >= OW) continue;
+                    acc += (double)hg[(((size_t)n * sh.Cout + co) * OH + oh) * OW + ow] * hw[((size_t)co * sh.Cin + ci) * T + kh * sh.k + kw];
+                }
+                const double got = hgx[(((size_t)n * sh.Cin + ci) * TH + ih) * TW + iw];
+                maxerr_d = fmax(maxerr_d, fabs(got - acc)); maxref_d = fmax(maxref_d, fabs(acc));
+            }
+        }
+        printf("%-32s fwd %7.3f ms %6.1f TF | dgrad %7.3f ms %6.1f TF | wgrad %7.3f ms %6.1f TF | err f %.1e d %.1e w %.1e\n",
                sh.name, tf, flops / tf / 1e9, td, flops / td / 1e9, tw, flops / tw / 1e9,
-               maxerr_f / (maxref_f + 1e-30), maxerr_w / (maxref_w + 1e-30));
+               maxerr_f / (maxref_f + 1e-30), maxerr_d / (maxref_d + 1e-30), maxerr_w / (maxref_w + 1e-30));
         fflush(stdout);
         hipFree(dx); hipFree(dw); hipFree(dy); hipFree(dg); hipFree(dgx); hipFree(dgw); hipFree(wt);
     }
