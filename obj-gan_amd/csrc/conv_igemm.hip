@@ -30,6 +30,7 @@
 // consecutive lanes on consecutive pixels (coalesced along W).  Workgroup ids are
 // remapped so that the M-tiles sharing one pixel tile run on the same XCD (shared L2).
 #include "common.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -60,6 +61,7 @@ struct IgemmArgs {
     int upsample;        // 1 = source index = logical index >> 1
     int act;
     int ksplit_steps;    // > 0: split-K -- blockIdx.y owns this many BK steps, epilogue = atomicAdd
+    int ablate;          // development only (OG_ABLATE): 1 no global loads, 2 no barrier, 4 no LDS writes, 8 no frag reads
     int nphase;          // > 1 (v2 kernel only): blockIdx.z = output phase p with its own tap table
                          // tap[p*8 ..], packed bank wt + p*M*Kpad and output offset (ooh, oow) = (p>>1, p&1)
     int tap[OG_MAX_TAPS];   // (dw << 16) | (dh & 0xffff): one scalar load per (uniform) tap
@@ -404,8 +406,10 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const IgemmArgs a) {
     t_ld = kt0 / spt;
     cb_ld = (kt0 - t_ld * spt) * BK;
     tap_geometry(t_ld);
+    // software pipeline, two K steps deep: step k+1 sits in LDS, step k+2 is in flight in registers
     load_step(kt0);
     store_step(0);
+    if (kt0 + 1 < nk) load_step(kt0 + 1);
     __syncthreads();
 
     const int lrow = lane >> 5;
@@ -420,9 +424,11 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const IgemmArgs a) {
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     int cur = 0;
     for (int kt = kt0; kt < nk; ++kt) {
-        const bool more = (kt + 1) < nk;
-        if (more) load_step(kt + 1);
-        const float* T = lds + cur * TILE;
+        // registers hold step kt+1 (loaded one iteration ago): park it in the other LDS buffer (free
+        // since the barrier that closed iteration kt-1), then refill the registers with step kt+2
+        if ((kt + 1) < nk && !(a.ablate & 4)) store_step(cur ^ 1);
+        if ((kt + 2) < nk && !(a.ablate & 1)) load_step(kt + 2);
+        const float* T = lds + ((a.ablate & 8) ? 0 : cur) * TILE;
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(T + b_rd);
         const f32x4 b1 = *reinterpret_cast<const f32x4*>(T + b_rd + 4);
         f32x4 a0[TM], a1[TM];
@@ -441,8 +447,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const IgemmArgs a) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][kk], b1[kk], acc[i], 0, 0, 0);
-        if (more) store_step(cur ^ 1);
-        __syncthreads();
+        if (!(a.ablate & 2)) __syncthreads();
         cur ^= 1;
     }
 
@@ -1035,6 +1040,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
     const int nk = (p_end - p_begin) / BK;
     load_step();
     store_step(0);
+    if (nk > 1) load_step();
     __syncthreads();
 
     const int lrow = lane >> 5;
@@ -1049,8 +1055,8 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        const bool more = (kt + 1) < nk;
-        if (more) load_step();
+        if ((kt + 1) < nk) store_step(cur ^ 1);      // two-deep pipeline, as in conv_igemm2_kernel
+        if ((kt + 2) < nk) load_step();
         const float* Tl = lds + cur * TILE;
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(Tl + b_rd);
         const f32x4 b1 = *reinterpret_cast<const f32x4*>(Tl + b_rd + 4);
@@ -1070,7 +1076,6 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
 #pragma unroll
             for (int i = 0; i < TM; ++i)
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][kk], b1[kk], acc[i], 0, 0, 0);
-        if (more) store_step(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
@@ -1208,25 +1213,31 @@ static int og_igemm_tmmax() {
 }
 
 // Block-row plan for M = `groups` 32-row groups over `tiles_n` column tiles: block rows of height TM
-// (<= 7: two workgroups per CU) plus one lower block row for the rest (its own launch).  The MFMA
-// time of a launch is ~ ceil(blocks / 256 CUs) * TM, so TM is chosen to minimise the quantised sum;
-// ties go to TM = 4 (three workgroups per CU), then to the taller tile (less re-reading of B).
+// (<= 7: two workgroups per CU) plus one lower block row for the remainder in its own launch
+// (388 rows = 13 groups -> 7 + 6, 194 -> 7, 768 -> 4 x 6).  The MFMA time of a launch is
+// ~ (workgroups per CU) x TM: whole rounds while the grid is small (quantisation is what decides
+// there), fractional once it spans many rounds; short tiles re-read the pixel operand more (pen).
+// The weight gradient always takes the tallest tiles: its gather is the expensive part.
+static double og_rounds(long blocks) {
+    if (blocks <= 256) return 1.25;                 // one workgroup per CU: nothing to overlap with
+    if (blocks < 1024) return (double)og_cdiv(blocks, 256);
+    return (double)blocks / 256.0;
+}
 static void og_row_plan(int groups, int tiles_n, int tall, int* TM_out, int* full_rows_out, int* rest_out) {
     int tmmax = og_igemm_tmmax();
     if (tmmax > 7) tmmax = 7;
     int bt = 1;
-    if (tall) {                                      // weight gradient: the gather is the expensive
-        const int brows = og_cdiv(groups, tmmax);    // part, amortise it over as many rows as fit
+    if (tall) {
+        const int brows = og_cdiv(groups, tmmax);
         bt = og_cdiv(groups, brows);
     } else {
-        // measured efficiency of the main loop by tile height (B traffic per MFMA falls with TM)
-        static const int pen[8] = {0, 112, 105, 102, 100, 100, 100, 100};
-        long best = -1;
+        static const double pen[8] = {0, 1.12, 1.05, 1.02, 1.0, 1.0, 1.0, 1.0};
+        double best = -1;
         for (int tm = 1; tm <= tmmax && tm <= groups; ++tm) {
             const int full = groups / tm, rest = groups - full * tm;
-            long cost = (long)og_cdiv((long)full * tiles_n, 256) * tm * pen[tm]
-                      + (rest ? (long)og_cdiv(tiles_n, 256) * rest * pen[rest] + 20 : 0);   // + a second launch
-            if (best < 0 || cost < best || (cost == best && tm > bt)) { best = cost; bt = tm; }
+            double cost = og_rounds((long)full * tiles_n) * tm * pen[tm]
+                        + (rest ? og_rounds(tiles_n) * rest * pen[rest] + 0.3 : 0.0);
+            if (best < 0 || cost < best - 1e-9 || (cost < best + 1e-9 && tm > bt)) { best = cost; bt = tm; }
         }
     }
     *TM_out = bt; *full_rows_out = groups / bt; *rest_out = groups - (groups / bt) * bt;
@@ -1277,7 +1288,16 @@ static int run_thin(IgemmArgs a, int MT, hipStream_t s) {
     return og_launch_status();
 }
 
+static int og_trace() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OG_TRACE"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v;
+}
+
 static int launch_igemm2(const IgemmArgs& a, int TM, dim3 grid, hipStream_t s) {
+    if (og_trace())
+        fprintf(stderr, "OGTRACE igemm2 TM=%d M=%d rows=%d C=%d T=%d Npix=%d grid=%u,%u,%u H=%d W=%d stride=%d\n", TM, a.M,
+                a.m_end - a.m_begin, a.C, a.T, a.N * a.PH * a.PW, grid.x, grid.y, grid.z, a.H, a.W, a.stride);
     switch (TM) {
         case 1: hipLaunchKernelGGL((conv_igemm2_kernel<1>), grid, dim3(256), 0, s, a); break;
         case 2: hipLaunchKernelGGL((conv_igemm2_kernel<2>), grid, dim3(256), 0, s, a); break;
@@ -1299,6 +1319,7 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed) {
     const int Npix = a.N * a.PH * a.PW;
     const int tiles_n = og_cdiv(Npix, 128);
     const int nph = a.nphase > 1 ? a.nphase : 1;
+    { static int abl = -1; if (abl < 0) { const char* e = getenv("OG_ABLATE"); abl = e ? atoi(e) : 0; } a.ablate = abl; }
     int TM, full_rows, rest;                             // block rows of height TM + one of height rest
     og_row_plan(groups, tiles_n * nph, 0, &TM, &full_rows, &rest);
     const int tiles = (full_rows + (rest ? 1 : 0)) * tiles_n;
