@@ -12,8 +12,10 @@ per-step Inception-score monitor on a side stream, as in the reference).  Per-GP
 batch and gradients are all-reduced: weak scaling, value = N * 16 * steps / time.
 
 One JSON line is printed by rank 0: the contract fields plus
-  roofline      the dominant kernel (MFMA implicit-GEMM conv, 128x128 tile, 3x3 taps): algorithmic
-                flops of its launches / their hipEvent-measured duration, against the fp32 MFMA peak
+  roofline      the dominant kernel instance (the MFMA implicit-GEMM conv with the largest share
+                of the step): algorithmic flops of its launches / their hipEvent-measured duration
+                (events recorded by the library on the launch stream), against the fp32 MFMA peak;
+                traffic = HBM bytes per launch from the rocprofv3 --pmc passes kept in profiles/
   cpu_baseline  the CPU oracle (oracle/torch_model.py, a port of the reference path) timed on this
                 host's cores on a bounded sample (one step at batch 2, <= 16 threads,
                 child process with a hard time limit)
@@ -34,8 +36,11 @@ import torch                                    # noqa: E402
 import torch.distributed as dist                # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3                   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
-CAT_NAMES = (["igemm_T%d_%s" % (t, c) for t in (1, 4, 9, 16) for c in ("128x128", "64x256", "32x256")] +
-             ["wgrad_k%d_%s" % (k, c) for k in (1, 3, 4) for c in ("128x128", "64x256", "32x256")])
+# timing categories of the library = kernel instances, named as rocprofv3 prints them
+CAT_NAMES = (["conv_igemm2_kernel<%d>" % tm for tm in range(1, 8)] +
+             ["conv_wgrad2_kernel<%d>" % tm for tm in range(1, 8)] +
+             ["conv_thin_kernel", "conv_thin3x3_kernel", "conv_igemm_kernel(v1)", "conv_wgrad_kernel(v1)"])
+PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
 def build_trainer(device, batch_size, seed, with_is_monitor=True):
@@ -197,9 +202,17 @@ def main():
             if cats:
                 name, tms, tfl, n = cats[0]
                 ach = tfl / (tms * 1e-3) / 1e12
+                traffic = None          # HBM bytes / launch from the committed rocprofv3 --pmc passes
+                if os.path.exists(PMC_TRAFFIC_JSON):
+                    try:
+                        ent = json.load(open(PMC_TRAFFIC_JSON)).get("kernels", {}).get(name)
+                        traffic = ent["hbm_bytes_per_launch"] if ent else None
+                    except (ValueError, KeyError, OSError):
+                        traffic = None
                 res["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2),
                                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                                   "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                                   "algorithmic_gflop_per_launch": round(tfl / n / 1e9, 2),
                                    "launches": int(n), "avg_launch_ms": round(tms / n, 4),
                                    "share_of_step": round(tms / (1000.0 * dt), 4)}
                 res["kernel_breakdown"] = [

@@ -1104,10 +1104,15 @@ static ProfRec* g_prof = nullptr;
 static int g_prof_n = 0;
 static int g_prof_made = 0;
 
-static inline int prof_cat(int wgrad, int t_or_k, int cfg) {
-    int ti = wgrad ? (t_or_k == 1 ? 0 : (t_or_k == 3 ? 1 : 2)) : (t_or_k <= 1 ? 0 : (t_or_k <= 4 ? 1 : (t_or_k <= 9 ? 2 : 3)));
-    return (wgrad ? 12 : 0) + ti * 3 + cfg;
-}
+// categories = kernel instances, so that they line up with the kernel names rocprofv3 reports:
+//   0..6  conv_igemm2_kernel<1..7>     7..13 conv_wgrad2_kernel<1..7>
+//   14 conv_thin_kernel<*>   15 conv_thin3x3_kernel<*>   16 conv_igemm_kernel<*> (v1)   17 conv_wgrad_kernel<*> (v1)
+#define OG_CAT_IGEMM2(tm) ((tm) - 1)
+#define OG_CAT_WGRAD2(tm) (7 + (tm) - 1)
+#define OG_CAT_THIN 14
+#define OG_CAT_THIN3 15
+#define OG_CAT_IGEMM1 16
+#define OG_CAT_WGRAD1 17
 static inline ProfRec* prof_begin(int cat, double flops, hipStream_t s) {
     if (!g_prof_on || g_prof_n >= OG_PROF_MAX) return nullptr;
     if (!g_prof) g_prof = (ProfRec*)calloc(OG_PROF_MAX, sizeof(ProfRec));
@@ -1186,7 +1191,7 @@ static int run_igemm(IgemmArgs a, hipStream_t s, int y_prezeroed) {
     for (int i = 0; i < np; ++i) {
         a.m_begin = parts[i].m_begin; a.m_end = parts[i].m_end;
         const double fl = 2.0 * (a.m_end - a.m_begin) * (double)a.K * ((double)a.N * a.PH * a.PW);
-        ProfRec* pr = prof_begin(prof_cat(0, a.T, parts[i].cfg), fl, s);
+        ProfRec* pr = prof_begin(OG_CAT_IGEMM1, fl, s);
         int rc = launch_igemm(a, parts[i].cfg, s);
         prof_end(pr, s);
         if (rc != OG_OK) return rc;
@@ -1260,7 +1265,7 @@ static int run_thin(IgemmArgs a, int MT, hipStream_t s) {
         const long threads = (long)a.N * og_cdiv(a.PH, R) * a.PW;
         dim3 g3(og_cdiv(threads, 256));
         a.m_begin = 0; a.m_end = a.M; a.ksplit_steps = 0;
-        ProfRec* pr = prof_begin(prof_cat(0, a.T, 2), 2.0 * a.M * (double)a.K * (double)Npix, s);
+        ProfRec* pr = prof_begin(OG_CAT_THIN3, 2.0 * a.M * (double)a.K * (double)Npix, s);
         switch (MT) {
             case 4: hipLaunchKernelGGL((conv_thin3x3_kernel<4, 4>), g3, dim3(256), 0, s, a); break;
             case 12: hipLaunchKernelGGL((conv_thin3x3_kernel<12, 4>), g3, dim3(256), 0, s, a); break;
@@ -1274,7 +1279,7 @@ static int run_thin(IgemmArgs a, int MT, hipStream_t s) {
     const int PX = MT <= 16 ? 2 : 1;
     dim3 grid(og_cdiv(Npix, 256 * PX));
     a.m_begin = 0; a.m_end = a.M; a.ksplit_steps = 0;
-    ProfRec* pr = prof_begin(prof_cat(0, a.T, 2), 2.0 * a.M * (double)a.K * (double)Npix, s);
+    ProfRec* pr = prof_begin(OG_CAT_THIN, 2.0 * a.M * (double)a.K * (double)Npix, s);
 #define OG_THIN(MTv, Tv) hipLaunchKernelGGL((conv_thin_kernel<MTv, Tv, (MTv <= 16 ? 2 : 1)>), grid, dim3(256), 0, s, a)
     if (a.T == 9) {
         switch (MT) { case 4: OG_THIN(4, 9); break; case 12: OG_THIN(12, 9); break; case 16: OG_THIN(16, 9); break;
@@ -1346,7 +1351,7 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed) {
     int rc = OG_OK;
     if (full_rows > 0) {
         a.m_begin = 0; a.m_end = min(a.M, full_rows * TM * 32);
-        ProfRec* pr = prof_begin(prof_cat(0, a.T, TM <= 2 ? 2 : (TM <= 4 ? 1 : 0)),
+        ProfRec* pr = prof_begin(OG_CAT_IGEMM2(TM),
                                  2.0 * (a.m_end - a.m_begin) * (double)a.K * (double)Npix * nph, s);
         rc = launch_igemm2(a, TM, dim3(full_rows * tiles_n, splits, nph), s);
         prof_end(pr, s);
@@ -1354,7 +1359,7 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed) {
     }
     if (rest > 0) {
         a.m_begin = full_rows * TM * 32; a.m_end = a.M;
-        ProfRec* pr = prof_begin(prof_cat(0, a.T, rest <= 2 ? 2 : (rest <= 4 ? 1 : 0)),
+        ProfRec* pr = prof_begin(OG_CAT_IGEMM2(rest),
                                  2.0 * (a.m_end - a.m_begin) * (double)a.K * (double)Npix * nph, s);
         rc = launch_igemm2(a, rest, dim3(tiles_n, splits, nph), s);
         prof_end(pr, s);
@@ -1525,7 +1530,7 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
             splits = og_cdiv(Npix, pps);
             a.pix_per_split = pps;
             dim3 grid(rows * tiles_n, splits);
-            ProfRec* pr = prof_begin(prof_cat(1, ksize, tm <= 2 ? 2 : (tm <= 4 ? 1 : 0)),
+            ProfRec* pr = prof_begin(OG_CAT_WGRAD2(tm),
                                      2.0 * (a.m_end - a.m_begin) * (double)a.ncol * (double)Npix, s);
             switch (tm) {
                 case 1: hipLaunchKernelGGL((conv_wgrad2_kernel<1>), grid, dim3(256), 0, s, a, ksize); break;
@@ -1565,7 +1570,7 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
         if (cfg == 0) hipLaunchKernelGGL((conv_wgrad_kernel<KS, 2, 2>), grid, dim3(256), 0, s, a);       \
         else if (cfg == 1) hipLaunchKernelGGL((conv_wgrad_kernel<KS, 1, 2>), grid, dim3(256), 0, s, a);  \
         else hipLaunchKernelGGL((conv_wgrad_kernel<KS, 1, 1>), grid, dim3(256), 0, s, a);
-        ProfRec* pr = prof_begin(prof_cat(1, ksize, cfg),
+        ProfRec* pr = prof_begin(OG_CAT_WGRAD1,
                                  2.0 * (a.m_end - a.m_begin) * (double)a.ncol * (double)Npix, s);
         if (ksize == 1) { OG_WG(1) } else if (ksize == 3) { OG_WG(3) } else { OG_WG(4) }
         prof_end(pr, s);
@@ -1584,8 +1589,7 @@ int objgan_prof_enable(int on) {
 }
 
 // Sums the recorded launches per category (the caller must have synchronised the device).
-// ms, flops, count: arrays of 32.  Categories: igemm (taps 1/4/9/16) x (tile 128x128, 64x256,
-// 32x256) = 0..11, wgrad (ksize 1/3/4) x tile = 12..20.
+// ms, flops, count: arrays of 32.  Categories = kernel instances (see OG_CAT_* above).
 int objgan_prof_collect(double* ms, double* flops, long* count) {
     for (int i = 0; i < OG_PROF_CATS; ++i) { ms[i] = 0; flops[i] = 0; count[i] = 0; }
     for (int i = 0; i < g_prof_n; ++i) {

@@ -196,6 +196,199 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(
     }
 }
 
+// ---- plane-structured variants (HW % 4 == 0, HW >= 256) ----------------------------------------
+// One workgroup = one (n, c) plane (or a chunk of it): the group / channel constants are scalars,
+// the element loop is pure 16-byte streaming -- no per-element index arithmetic.  GLU handles the
+// value and the gate plane of an output channel together, so x and dy are read exactly once.
+#define OG_NORM_CHUNK 8192          // elements of one plane per workgroup
+
+__device__ __forceinline__ float og_group_mean(const float* p, int g) { return p[g]; }
+
+// grid = (N*C, chunks): sums[g*2 + {0,1}] += shifted sums of this plane chunk (zero on entry)
+__global__ __launch_bounds__(256) void norm_stats_plane_kernel(const float* __restrict__ x,
+                                                               float* __restrict__ sums, NormGeom gm) {
+    __shared__ float red[16];
+    const int plane = blockIdx.x;                       // n*C + c
+    const int c = plane % gm.C;
+    const int g = gm.per_channel ? c : plane;
+    const float K = x[(size_t)g * gm.HW];               // first element of the group (n = 0 plane)
+    const float4* xp = reinterpret_cast<const float4*>(x + (size_t)plane * gm.HW);
+    const int i0 = blockIdx.y * (OG_NORM_CHUNK / 4);
+    const int i1 = min(gm.HW / 4, i0 + OG_NORM_CHUNK / 4);
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float4 v = xp[i];
+        const float a = v.x - K, b = v.y - K, cc = v.z - K, d = v.w - K;
+        s1 += (a + b) + (cc + d);
+        s2 += (a * a + b * b) + (cc * cc + d * d);
+    }
+    s1 = og_block_sum(s1, red);
+    s2 = og_block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[2 * g], s1);
+        atomicAdd(&sums[2 * g + 1], s2);
+    }
+}
+
+// grid = (N*Co, chunks)
+template <int MODE>
+__global__ __launch_bounds__(256) void norm_apply_plane_kernel(
+    const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ residual, float* __restrict__ y, NormGeom gm) {
+    const int Co = MODE == OG_NORM_GLU ? gm.C / 2 : gm.C;
+    const int plane = blockIdx.x;                       // n*Co + c
+    const int n = plane / Co;
+    const int c = plane - n * Co;
+    const int ga = gm.per_channel ? c : n * gm.C + c;
+    float sa = rstd[ga], ta = -mean[ga] * sa;           // z = x*sa + ta
+    if (gamma) { ta = ta * gamma[c] + beta[c]; sa *= gamma[c]; }
+    float sb = 0.f, tb = 0.f;
+    if (MODE == OG_NORM_GLU) {
+        const int cb = c + Co;
+        const int gb = gm.per_channel ? cb : n * gm.C + cb;
+        sb = rstd[gb]; tb = -mean[gb] * sb;
+        if (gamma) { tb = tb * gamma[cb] + beta[cb]; sb *= gamma[cb]; }
+    }
+    const float4* xa = reinterpret_cast<const float4*>(x + ((size_t)n * gm.C + c) * gm.HW);
+    const float4* xb = reinterpret_cast<const float4*>(x + ((size_t)n * gm.C + c + Co) * gm.HW);
+    const float4* rp = residual ? reinterpret_cast<const float4*>(residual + (size_t)plane * gm.HW) : nullptr;
+    float4* yp = reinterpret_cast<float4*>(y + (size_t)plane * gm.HW);
+    const int i0 = blockIdx.y * (OG_NORM_CHUNK / 4);
+    const int i1 = min(gm.HW / 4, i0 + OG_NORM_CHUNK / 4);
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float4 a = xa[i];
+        float z[4] = {a.x * sa + ta, a.y * sa + ta, a.z * sa + ta, a.w * sa + ta};
+        float v[4];
+        if (MODE == OG_NORM_GLU) {
+            const float4 b = xb[i];
+            const float zb[4] = {b.x * sb + tb, b.y * sb + tb, b.z * sb + tb, b.w * sb + tb};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = z[j] * og_sigmoid(zb[j]);
+        } else if (MODE == OG_NORM_LRELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = z[j] > 0.f ? z[j] : 0.2f * z[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = z[j];
+        }
+        if (rp) { const float4 r = rp[i]; v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+        yp[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// Backward, shared element math: from x (both halves for GLU) and dy produce dz and xhat of the
+// value channel (a) and, for GLU, of the gate channel (b).
+template <int MODE>
+__device__ __forceinline__ void norm_dz_pair(float xa, float xb, float d, float ma, float ra, float mb, float rb,
+                                             float gaa, float baa, float gab, float bab, bool affine,
+                                             float& dza, float& xha, float& dzb, float& xhb) {
+    xha = (xa - ma) * ra;
+    float za = affine ? xha * gaa + baa : xha;
+    if (MODE == OG_NORM_NONE) { dza = d; dzb = 0.f; xhb = 0.f; return; }
+    if (MODE == OG_NORM_LRELU) { dza = d * (za > 0.f ? 1.f : 0.2f); dzb = 0.f; xhb = 0.f; return; }
+    xhb = (xb - mb) * rb;
+    const float zb = affine ? xhb * gab + bab : xhb;
+    const float sg = og_sigmoid(zb);
+    dza = d * sg;
+    dzb = d * za * sg * (1.f - sg);
+}
+
+// grid = (N*Co, chunks); bsums zero on entry
+template <int MODE>
+__global__ __launch_bounds__(256) void norm_bwd_stats_plane_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ bsums, NormGeom gm) {
+    __shared__ float red[16];
+    const int Co = MODE == OG_NORM_GLU ? gm.C / 2 : gm.C;
+    const int plane = blockIdx.x;
+    const int n = plane / Co;
+    const int c = plane - n * Co;
+    const int cb = c + Co;
+    const int ga = gm.per_channel ? c : n * gm.C + c;
+    const int gb = gm.per_channel ? cb : n * gm.C + cb;
+    const bool affine = gamma != nullptr;
+    const float ma = mean[ga], ra = rstd[ga];
+    const float mb = MODE == OG_NORM_GLU ? mean[gb] : 0.f, rb = MODE == OG_NORM_GLU ? rstd[gb] : 0.f;
+    const float gaa = affine ? gamma[c] : 1.f, baa = affine ? beta[c] : 0.f;
+    const float gab = (affine && MODE == OG_NORM_GLU) ? gamma[cb] : 1.f, bab = (affine && MODE == OG_NORM_GLU) ? beta[cb] : 0.f;
+    const float4* xa = reinterpret_cast<const float4*>(x + ((size_t)n * gm.C + c) * gm.HW);
+    const float4* xb = reinterpret_cast<const float4*>(x + ((size_t)n * gm.C + cb) * gm.HW);
+    const float4* dp = reinterpret_cast<const float4*>(dy + (size_t)plane * gm.HW);
+    const int i0 = blockIdx.y * (OG_NORM_CHUNK / 4);
+    const int i1 = min(gm.HW / 4, i0 + OG_NORM_CHUNK / 4);
+    float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float4 va = xa[i];
+        const float4 vb = MODE == OG_NORM_GLU ? xb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 vd = dp[i];
+        const float xs[4] = {va.x, va.y, va.z, va.w}, ys[4] = {vb.x, vb.y, vb.z, vb.w}, ds[4] = {vd.x, vd.y, vd.z, vd.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float dza, xha, dzb, xhb;
+            norm_dz_pair<MODE>(xs[j], ys[j], ds[j], ma, ra, mb, rb, gaa, baa, gab, bab, affine, dza, xha, dzb, xhb);
+            a1 += dza; a2 += dza * xha;
+            if (MODE == OG_NORM_GLU) { b1 += dzb; b2 += dzb * xhb; }
+        }
+    }
+    a1 = og_block_sum(a1, red);
+    a2 = og_block_sum(a2, red);
+    if (MODE == OG_NORM_GLU) { b1 = og_block_sum(b1, red); b2 = og_block_sum(b2, red); }
+    if (threadIdx.x == 0) {
+        atomicAdd(&bsums[2 * ga], a1);
+        atomicAdd(&bsums[2 * ga + 1], a2);
+        if (MODE == OG_NORM_GLU) { atomicAdd(&bsums[2 * gb], b1); atomicAdd(&bsums[2 * gb + 1], b2); }
+    }
+}
+
+// grid = (N*Co, chunks): dx = gamma * rstd * (dz - mean(dz) - xhat * mean(dz * xhat))
+template <int MODE>
+__global__ __launch_bounds__(256) void norm_bwd_apply_plane_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ bsums, float* __restrict__ dx, NormGeom gm) {
+    const int Co = MODE == OG_NORM_GLU ? gm.C / 2 : gm.C;
+    const int plane = blockIdx.x;
+    const int n = plane / Co;
+    const int c = plane - n * Co;
+    const int cb = c + Co;
+    const int ga = gm.per_channel ? c : n * gm.C + c;
+    const int gb = gm.per_channel ? cb : n * gm.C + cb;
+    const bool affine = gamma != nullptr;
+    const float inv_cnt = 1.0f / (gm.per_channel ? (float)gm.N * gm.HW : (float)gm.HW);
+    const float ma = mean[ga], ra = rstd[ga];
+    const float mb = MODE == OG_NORM_GLU ? mean[gb] : 0.f, rb = MODE == OG_NORM_GLU ? rstd[gb] : 0.f;
+    const float gaa = affine ? gamma[c] : 1.f, baa = affine ? beta[c] : 0.f;
+    const float gab = (affine && MODE == OG_NORM_GLU) ? gamma[cb] : 1.f, bab = (affine && MODE == OG_NORM_GLU) ? beta[cb] : 0.f;
+    const float ka1 = bsums[2 * ga] * inv_cnt, ka2 = bsums[2 * ga + 1] * inv_cnt;
+    const float kb1 = MODE == OG_NORM_GLU ? bsums[2 * gb] * inv_cnt : 0.f, kb2 = MODE == OG_NORM_GLU ? bsums[2 * gb + 1] * inv_cnt : 0.f;
+    const float wa = gaa * ra, wb = gab * rb;
+    const float4* xa = reinterpret_cast<const float4*>(x + ((size_t)n * gm.C + c) * gm.HW);
+    const float4* xb = reinterpret_cast<const float4*>(x + ((size_t)n * gm.C + cb) * gm.HW);
+    const float4* dp = reinterpret_cast<const float4*>(dy + (size_t)plane * gm.HW);
+    float4* oa = reinterpret_cast<float4*>(dx + ((size_t)n * gm.C + c) * gm.HW);
+    float4* ob = reinterpret_cast<float4*>(dx + ((size_t)n * gm.C + cb) * gm.HW);
+    const int i0 = blockIdx.y * (OG_NORM_CHUNK / 4);
+    const int i1 = min(gm.HW / 4, i0 + OG_NORM_CHUNK / 4);
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float4 va = xa[i];
+        const float4 vb = MODE == OG_NORM_GLU ? xb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 vd = dp[i];
+        const float xs[4] = {va.x, va.y, va.z, va.w}, ys[4] = {vb.x, vb.y, vb.z, vb.w}, ds[4] = {vd.x, vd.y, vd.z, vd.w};
+        float ra4[4], rb4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float dza, xha, dzb, xhb;
+            norm_dz_pair<MODE>(xs[j], ys[j], ds[j], ma, ra, mb, rb, gaa, baa, gab, bab, affine, dza, xha, dzb, xhb);
+            ra4[j] = wa * (dza - ka1 - xha * ka2);
+            rb4[j] = wb * (dzb - kb1 - xhb * kb2);
+        }
+        oa[i] = make_float4(ra4[0], ra4[1], ra4[2], ra4[3]);
+        if (MODE == OG_NORM_GLU) ob[i] = make_float4(rb4[0], rb4[1], rb4[2], rb4[3]);
+    }
+}
+
 // dgamma[c] = bsums[2c+1], dbeta[c] = bsums[2c]   (BatchNorm only)
 __global__ void norm_affine_grad_kernel(const float* __restrict__ bsums, float* __restrict__ dgamma,
                                         float* __restrict__ dbeta, int C) {
@@ -267,11 +460,28 @@ int objgan_norm_forward(const float* x, float* y, const float* residual,
     const int G = per_channel ? C : N * C;
     const long per_group = per_channel ? (long)N * HW : HW;
     hipMemsetAsync(sums, 0, sizeof(float) * 2 * G, s);
-    dim3 grid(G, norm_splits(G, per_group));
-    hipLaunchKernelGGL(norm_stats_kernel, grid, dim3(256), 0, s, x, sums, gm);
+    const bool planes = (HW % 4 == 0) && HW >= 256 && (long)N * C < 2000000;
+    const int chunks = og_cdiv(HW, OG_NORM_CHUNK);
+    const int Co = mode == OG_NORM_GLU ? C / 2 : C;
+    if (planes) {
+        hipLaunchKernelGGL(norm_stats_plane_kernel, dim3(N * C, chunks), dim3(256), 0, s, x, sums, gm);
+    } else {
+        dim3 grid(G, norm_splits(G, per_group));
+        hipLaunchKernelGGL(norm_stats_kernel, grid, dim3(256), 0, s, x, sums, gm);
+    }
     hipLaunchKernelGGL(norm_finalize_kernel, dim3(og_cdiv(G, 256)), dim3(256), 0, s, x, sums, mean,
                        rstd, running_mean, running_var, gm, G, eps, momentum);
-    const long total = (long)N * (mode == OG_NORM_GLU ? C / 2 : C) * HW;
+    if (planes) {
+        dim3 grid(N * Co, chunks);
+        if (mode == OG_NORM_GLU)
+            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_GLU>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm);
+        else if (mode == OG_NORM_LRELU)
+            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_LRELU>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm);
+        else
+            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_NONE>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm);
+        return og_launch_status();
+    }
+    const long total = (long)N * Co * HW;
     hipLaunchKernelGGL(norm_apply_kernel, dim3(og_stream_grid(total, 256)), dim3(256), 0, s, x, mean,
                        rstd, gamma, beta, residual, y, gm, mode);
     return og_launch_status();
@@ -290,12 +500,25 @@ int objgan_norm_backward(const float* x, const float* dy, const float* mean, con
     const int G = per_channel ? C : N * C;
     const long per_group = per_channel ? (long)N * HW : HW;
     hipMemsetAsync(bsums, 0, sizeof(float) * 2 * G, s);
-    dim3 grid(G, norm_splits(G, per_group));
-    hipLaunchKernelGGL(norm_bwd_stats_kernel, grid, dim3(256), 0, s, x, dy, mean, rstd, gamma, beta,
-                       bsums, gm, mode);
-    const long total = (long)N * C * HW;
-    hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(og_stream_grid(total, 256)), dim3(256), 0, s, x,
-                       dy, mean, rstd, gamma, beta, bsums, dx, gm, mode);
+    const bool planes = (HW % 4 == 0) && HW >= 256 && (long)N * C < 2000000;
+    if (planes) {
+        const int Co = mode == OG_NORM_GLU ? C / 2 : C;
+        dim3 grid(N * Co, og_cdiv(HW, OG_NORM_CHUNK));
+#define OG_NB(MODE)                                                                                         \
+        hipLaunchKernelGGL((norm_bwd_stats_plane_kernel<MODE>), grid, dim3(256), 0, s, x, dy, mean, rstd,   \
+                           gamma, beta, bsums, gm);                                                         \
+        hipLaunchKernelGGL((norm_bwd_apply_plane_kernel<MODE>), grid, dim3(256), 0, s, x, dy, mean, rstd,   \
+                           gamma, beta, bsums, dx, gm);
+        if (mode == OG_NORM_GLU) { OG_NB(OG_NORM_GLU) } else if (mode == OG_NORM_LRELU) { OG_NB(OG_NORM_LRELU) } else { OG_NB(OG_NORM_NONE) }
+#undef OG_NB
+    } else {
+        dim3 grid(G, norm_splits(G, per_group));
+        hipLaunchKernelGGL(norm_bwd_stats_kernel, grid, dim3(256), 0, s, x, dy, mean, rstd, gamma, beta,
+                           bsums, gm, mode);
+        const long total = (long)N * C * HW;
+        hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(og_stream_grid(total, 256)), dim3(256), 0, s, x,
+                           dy, mean, rstd, gamma, beta, bsums, dx, gm, mode);
+    }
     if (dgamma && per_channel)
         hipLaunchKernelGGL(norm_affine_grad_kernel, dim3(og_cdiv(C, 256)), dim3(256), 0, s, bsums,
                            dgamma, dbeta, C);

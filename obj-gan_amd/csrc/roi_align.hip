@@ -143,6 +143,58 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(
     }
 }
 
+// Backward, privatised: one workgroup owns one (image, channel) plane, accumulates every ROI of
+// that image into an LDS copy of the plane (LDS atomics: the boxes of an image overlap heavily --
+// with the reference's spatial_scale quirk they all land in the top-left corner -- which makes
+// global atomics serialise), then adds the plane into bottom_grad with plain coalesced
+// read-modify-writes.  Same per-term arithmetic as roi_align_bwd_kernel; the summation order of
+// the four-tap scatter is unspecified in the reference kernel as well (atomicAdd).
+__global__ __launch_bounds__(256) void roi_align_bwd_plane_kernel(
+    const float* __restrict__ top_grad, const float* __restrict__ rois,
+    float* __restrict__ bottom_grad, int num_rois,
+    int C, int H, int W, int AH, int AW, float spatial_scale) {
+    extern __shared__ __attribute__((aligned(16))) float plane[];      // H*W floats, then the samples
+    const int HW = H * W;
+    const int S = AH * AW;
+    RoiSample* smp = reinterpret_cast<RoiSample*>(plane + HW);
+    const int c = blockIdx.x;
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) plane[i] = 0.f;
+    bool any = false;
+    for (int r = 0; r < num_rois; ++r) {
+        const float* roi = rois + (size_t)r * 5;
+        // reference: img_start = (int)(roi_batch_ind * C * H * W) -- the plane of image roi[0]
+        const int img_start = (int)(((roi[0] * (float)C) * (float)H) * (float)W);
+        if (img_start != b * C * HW) continue;                       // wave-uniform
+        any = true;
+        __syncthreads();
+        for (int s = threadIdx.x; s < S; s += blockDim.x)
+            roi_geometry(roi, spatial_scale, H, W, AH, AW, s, smp[s]);
+        __syncthreads();
+        const float* tg = top_grad + ((size_t)r * C + c) * S;
+        for (int s = threadIdx.x; s < S; s += blockDim.x) {
+            const RoiSample g = smp[s];
+            if (!g.valid) continue;
+            const float d = tg[s];
+            float* p = plane + g.off;
+            const double omh = 1.0 - (double)g.h_ratio;
+            const float omw = 1.0f - g.w_ratio;
+            const float dh_ = d * g.h_ratio;
+            atomicAdd(p,         (float)(((double)d * omh) * (double)omw));
+            atomicAdd(p + 1,     (float)(((double)d * omh) * (double)g.w_ratio));
+            atomicAdd(p + W,     dh_ * omw);
+            atomicAdd(p + W + 1, dh_ * g.w_ratio);
+        }
+    }
+    if (!any) return;
+    __syncthreads();
+    float* dst = bottom_grad + ((size_t)b * C + c) * HW;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+        const float v = plane[i];
+        if (v != 0.f) dst[i] += v;
+    }
+}
+
 // ---- 2x2 stride-1 average pool over the last two dims (RoIAlignAvg tail) ------------
 // in: [P, IH, IW] -> out: [P, IH-1, IW-1]
 __global__ __launch_bounds__(256) void avgpool2s1_fwd_kernel(
@@ -207,12 +259,19 @@ int objgan_roi_align_backward(const float* top_grad, const float* rois, float* b
                               int batch_size, int num_rois, int roi_cols, int channels,
                               int height, int width, int aligned_height, int aligned_width,
                               float spatial_scale, void* stream) {
-    (void)batch_size;
     if (roi_cols != 5) return OG_BAD_ARGS;
     if (aligned_height * aligned_width > ROI_MAX_SAMPLES || aligned_height < 2 || aligned_width < 2)
         return OG_BAD_ARGS;
     if (num_rois <= 0 || channels <= 0) return OG_OK;
     const int S = aligned_height * aligned_width;
+    const size_t lds = (size_t)height * width * sizeof(float) + (size_t)S * sizeof(RoiSample);
+    if (batch_size > 0 && lds <= 64 * 1024 && (double)batch_size * channels * height * width < 2.0e9) {
+        dim3 grid(channels, batch_size);
+        hipLaunchKernelGGL(roi_align_bwd_plane_kernel, grid, dim3(256), lds, (hipStream_t)stream,
+                           top_grad, rois, bottom_grad, num_rois, channels, height, width,
+                           aligned_height, aligned_width, spatial_scale);
+        return og_launch_status();
+    }
     const int cpb = roi_c_per_block(channels, S);
     dim3 grid(num_rois, og_cdiv(channels, cpb));
     hipLaunchKernelGGL(roi_align_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream,
