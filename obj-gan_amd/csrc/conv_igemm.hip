@@ -919,7 +919,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 // SCALAR (n, oh, ow0 .. ow0+7), the per-lane part is the column's (ci, kh, kw) -- dy rows are read
 // as aligned 16-byte pieces with a constant per-lane offset, x elements as dwords whose validity
 // (zero padding) rides on the buffer range check.
-template <int TM>
+template <int TM, bool PM>
 __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, const int KS) {
     constexpr int BM = 32 * TM;
     constexpr int BN = 128;
@@ -976,6 +976,38 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
     const int us = a.upsample ? 1 : 0;
     const bool refl = a.pad_mode == 1;
 
+    // ---- pixel-major gather (PM): thread = (pixel kp of the K step, column slot); it loads the
+    // eight columns slot + 16 j at ITS pixel, so that the 16 lanes of a slot read 16 consecutive
+    // pixels (one 64-byte segment) -- 4-5 cache lines per load instruction instead of ~20 when
+    // every lane owns a different (channel, tap) column.  Column constants are per-thread registers.
+    const int kp = tid & 15;
+    const int slot = tid >> 4;
+    int cdh[8], cdw[8];
+    unsigned coff[8];        // ci*HW (+ dh*W + dw when the tap offset can be pre-added), or OOB marker
+    if (PM) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int cj = c0 + slot + 16 * j;
+            const bool ok = cj < a.ncol;
+            const int cc = ok ? cj : 0;
+            const int ci = cc / T;
+            const int t = cc - ci * T;
+            const int kh = t / KS;
+            cdh[j] = kh - a.pad;
+            cdw[j] = (t - kh * KS) - a.pad;
+            coff[j] = ok ? (unsigned)ci * (unsigned)HW : OG_OOB;
+        }
+    }
+    // per-lane pixel state of the next K step (PM)
+    int pn = 0, poh = 0, pow_ = 0;
+    if (PM) {
+        const int p = p_begin + kp;
+        pn = p / OHW;
+        const int r = p - pn * OHW;
+        poh = r / a.OW;
+        pow_ = r - poh * a.OW;
+    }
+
     // ---- A (dy) geometry: float4 idx -> (row, quarter); constant per-lane offset
     unsigned avoff[NA_PER];
     int alds[NA_PER];
@@ -1010,6 +1042,27 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
             oh_ld = (bg * 8) / a.OW;
             ow_ld = (bg * 8) - oh_ld * a.OW;
         }
+        if (PM) {
+            const int ihb = poh * a.stride, iwb = pow_ * a.stride;
+            const unsigned nb = (unsigned)pn * (unsigned)a.Cin * (unsigned)HW;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ih = ihb + cdh[j], iw = iwb + cdw[j];
+                int ihr = ih < 0 ? -ih : ih;
+                int iwr = iw < 0 ? -iw : iw;
+                ihr = ihr >= a.LH ? 2 * (a.LH - 1) - ihr : ihr;
+                iwr = iwr >= a.LW ? 2 * (a.LW - 1) - iwr : iwr;
+                const bool inb = ((unsigned)ih < (unsigned)a.LH) && ((unsigned)iw < (unsigned)a.LW);
+                const bool ok = (coff[j] != OG_OOB) && (refl || inb);
+                const int ihs = (refl ? ihr : ih) >> us, iws = (refl ? iwr : iw) >> us;
+                const unsigned vo = ok ? (nb + coff[j] + (unsigned)(ihs * a.W + iws)) * 4u : OG_OOB;
+                rb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, vo, 0, 0));
+            }
+            pow_ += BK;                               // advance this lane's pixel by one K step
+            while (pow_ >= a.OW) { pow_ -= a.OW; poh += 1; }
+            while (poh >= a.OH) { poh -= a.OH; pn += 1; }
+            return;
+        }
         const int ih = oh * a.stride + dh;
         int ihr = ih < 0 ? -ih : ih;
         ihr = ihr >= a.LH ? 2 * (a.LH - 1) - ihr : ihr;
@@ -1032,6 +1085,11 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
 #pragma unroll
         for (int i = 0; i < NA_PER; ++i)
             if (NA4 % 256 == 0 || alds[i] >= 0) *reinterpret_cast<f32x4*>(As + alds[i]) = ra[i];
+        if (PM) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Bs[(slot + 16 * j) * LD + kp] = rb[j];
+            return;
+        }
         f32x4 v0 = {rb[0], rb[1], rb[2], rb[3]}, v1 = {rb[4], rb[5], rb[6], rb[7]};
         *reinterpret_cast<f32x4*>(Bs + bc * LD + bg * 8) = v0;
         *reinterpret_cast<f32x4*>(Bs + bc * LD + bg * 8 + 4) = v1;
@@ -1088,6 +1146,458 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
             if (m < a.m_end) atomicAdd(a.dw + (size_t)m * a.ncol + ocol, acc[i][r]);
+        }
+    }
+}
+
+// =============================================================================================
+// v3: the pixel / column operand never touches LDS.  In the (32*TM) x 128 tiling a wave owns its 32
+// pixel (or weight-gradient column) positions exclusively, and the eight consecutive k values a
+// thread gathers for one position are exactly the lane's MFMA operand for a K step (lane = (position
+// l & 31, k half l >> 5)): the gather registers ARE the fragment.  Only the row operand (filter bank /
+// dy), which all four waves share, is staged through LDS -- and for TM = 1 (thin outputs) it is read
+// straight from L1/L2 as two 16-byte loads per lane, so those launches run without LDS and without
+// barriers at all: waves are independent and latency is hidden by occupancy.
+template <int TM>
+__global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
+    constexpr int BM = 32 * TM;
+    constexpr int BN = 128;
+    constexpr int BK = 16;
+    constexpr int LD = BK + 4;
+    constexpr int NA4 = BM * 4;
+    constexpr int NA_PER = (NA4 + 255) / 256;
+    constexpr int TILE = BM * LD;
+    constexpr bool ALDS = TM > 1;                     // row operand through LDS (shared by 4 waves)
+
+    __shared__ __attribute__((aligned(16))) float lds[ALDS ? 2 * TILE : 4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane >> 5;
+    const int lcol = lane & 31;
+
+    const int Npix = a.N * a.PH * a.PW;
+    const int tiles_m = (a.m_end - a.m_begin + BM - 1) / BM;
+    const int tiles_n = (Npix + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    const int wg = og_xcd_remap(blockIdx.x, nwg);
+    const int tile_m = wg % tiles_m;
+    const int tile_n = wg / tiles_m;
+    const int m0 = a.m_begin + tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    const int phase = a.nphase > 1 ? (int)blockIdx.z : 0;
+    const int tapbase = phase * 8;
+    const int HW = a.H * a.W;
+    __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.x, 0, (int)((unsigned)a.N * a.C * HW * 4u), OG_BUF_FLAGS);
+    __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.wt + (size_t)phase * a.M * a.Kpad), 0, (int)((unsigned)a.M * a.Kpad * 4u), OG_BUF_FLAGS);
+
+    // ---- pixel operand: this lane's pixel and k half
+    const int pix = n0 + wid * 32 + lcol;
+    const bool pix_ok = pix < Npix;
+    int ihb, iwb;
+    unsigned img_off;
+    {
+        const int ppi = a.PH * a.PW;
+        const int pp = pix_ok ? pix : 0;
+        const int n = pp / ppi;
+        const int rem = pp - n * ppi;
+        const int pa = rem / a.PW;
+        const int pb = rem - pa * a.PW;
+        ihb = pa * a.stride;
+        iwb = pb * a.stride;
+        img_off = (unsigned)n * (unsigned)a.C * (unsigned)HW + (unsigned)(lrow * 8) * (unsigned)HW;
+    }
+    const int us = a.upsample ? 1 : 0;
+    const bool refl = a.pad_mode == 1;
+    unsigned bvoff = OG_OOB;
+    auto tap_geometry = [&](int t) {
+        const int tp = a.tap[tapbase + t];
+        const int ih = ihb + ((tp << 16) >> 16);
+        const int iw = iwb + (tp >> 16);
+        int ihr = ih < 0 ? -ih : ih;
+        int iwr = iw < 0 ? -iw : iw;
+        ihr = ihr >= a.LH ? 2 * (a.LH - 1) - ihr : ihr;
+        iwr = iwr >= a.LW ? 2 * (a.LW - 1) - iwr : iwr;
+        const bool inb = ((unsigned)ih < (unsigned)a.LH) && ((unsigned)iw < (unsigned)a.LW);
+        const bool ok = pix_ok && (refl || inb);
+        const int ihs = (refl ? ihr : ih) >> us;
+        const int iws = (refl ? iwr : iw) >> us;
+        bvoff = ok ? (img_off + (unsigned)(ihs * a.W + iws)) * 4u : OG_OOB;
+    };
+    int t_ld, cb_ld;
+    const int spt = a.Cp / BK;
+    // channels past C (padding of the last 16-channel chunk) read finite neighbouring data or the
+    // range-check zero; their filter entries are zero
+    auto load_b = [&](float (&rb)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, bvoff, (cb_ld + i) * HW * 4, 0));
+        cb_ld += BK;
+        if (cb_ld >= a.Cp) {
+            cb_ld = 0;
+            t_ld += 1;
+            if (t_ld < a.T) tap_geometry(t_ld);
+        }
+    };
+
+    // ---- row operand (filter bank [M][Kpad])
+    unsigned avoff[NA_PER];
+    int alds[NA_PER];
+    if (ALDS) {
+#pragma unroll
+        for (int i = 0; i < NA_PER; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 2, q = idx & 3;
+            const bool on = (NA4 % 256 == 0 || idx < NA4) && (m0 + row) < a.m_end;
+            avoff[i] = on ? ((unsigned)(m0 + row) * (unsigned)a.Kpad + q * 4u) * 4u : OG_OOB;
+            alds[i] = (NA4 % 256 == 0 || idx < NA4) ? row * LD + q * 4 : -1;
+        }
+    }
+    const unsigned adir = (m0 + lcol) < a.m_end ? ((unsigned)(m0 + lcol) * (unsigned)a.Kpad + lrow * 8u) * 4u : OG_OOB;
+    f32x4 ra[NA_PER];
+    auto load_a = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < NA_PER; ++i)
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, avoff[i], kt * (BK * 4), 0));
+    };
+    auto store_a = [&](int buf) {
+        float* As = lds + buf * TILE;
+#pragma unroll
+        for (int i = 0; i < NA_PER; ++i)
+            if (NA4 % 256 == 0 || alds[i] >= 0) *reinterpret_cast<f32x4*>(As + alds[i]) = ra[i];
+    };
+
+    const int nk_all = a.Kpad / BK;
+    const int kt0 = a.ksplit_steps > 0 ? blockIdx.y * a.ksplit_steps : 0;
+    const int nk = a.ksplit_steps > 0 ? min(nk_all, kt0 + a.ksplit_steps) : nk_all;
+    t_ld = kt0 / spt;
+    cb_ld = (kt0 - t_ld * spt) * BK;
+    tap_geometry(t_ld);
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const int a_rd = lcol * LD + lrow * 8;
+    float rb0[8], rb1[8];
+    f32x4 ad0[2], ad1[2];                              // TM == 1: direct row fragments (ping-pong)
+    auto load_adir = [&](f32x4 (&ad)[2], int kt) {
+        ad[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, adir, kt * (BK * 4), 0));
+        ad[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, adir + 16u, kt * (BK * 4), 0));
+    };
+    auto mma = [&](const float (&rb)[8], const f32x4 (&ad)[2], int cur) {
+        if (ALDS) {
+            const float* T = lds + cur * TILE;
+            f32x4 a0[TM], a1[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                a0[i] = *reinterpret_cast<const f32x4*>(T + a_rd + i * 32 * LD);
+                a1[i] = *reinterpret_cast<const f32x4*>(T + a_rd + i * 32 * LD + 4);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][kk], rb[kk], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][kk], rb[4 + kk], acc[i], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[0][kk], rb[kk], acc[0], 0, 0, 0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[1][kk], rb[4 + kk], acc[0], 0, 0, 0);
+        }
+    };
+
+    // prologue: row tile of step kt0 in LDS buffer 0, of kt0+1 in flight; pixel fragment of kt0 in rb0
+    if (ALDS) {
+        load_a(kt0);
+        store_a(0);
+        if (kt0 + 1 < nk) load_a(kt0 + 1);
+    } else {
+        load_adir(ad0, kt0);
+    }
+    load_b(rb0);
+    if (ALDS) __syncthreads();
+    int cur = 0;
+    for (int kt = kt0; kt < nk; ++kt) {
+        // fetch the fragments of step kt+1 (rb1 / ad1) behind the MFMAs of step kt (rb0 / ad0)
+        if (kt + 1 < nk) {
+            if (ALDS) store_a(cur ^ 1); else load_adir(ad1, kt + 1);
+            load_b(rb1);
+        }
+        if (ALDS && kt + 2 < nk) load_a(kt + 2);
+        mma(rb0, ad0, cur);
+        if (ALDS) __syncthreads();
+        cur ^= 1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rb0[i] = rb1[i];
+        if (!ALDS) { ad0[0] = ad1[0]; ad0[1] = ad1[1]; }
+    }
+
+    // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+    if (!pix_ok) return;
+    const int ppi = a.PH * a.PW;
+    const int n = pix / ppi;
+    const int rem = pix - n * ppi;
+    const int pa = rem / a.PW;
+    const int pb = rem - pa * a.PW;
+    const int oh = pa * a.osh + (a.nphase > 1 ? (phase >> 1) : a.ooh);
+    const int ow = pb * a.osw + (a.nphase > 1 ? (phase & 1) : a.oow);
+    const size_t plane = (size_t)a.OHf * a.OWf;
+    float* yb = a.y + (size_t)n * a.M * plane + (size_t)oh * a.OWf + ow;
+    const bool split = a.ksplit_steps > 0;
+    const bool lrelu = a.act == OG_ACT_LRELU, relu = a.act == OG_ACT_RELU;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+            if (m < a.m_end) {
+                float v = acc[i][r];
+                if (split) {
+                    atomicAdd(&yb[(size_t)m * plane], v);
+                } else {
+                    if (a.bias) v += a.bias[m];
+                    v = lrelu ? (v > 0.f ? v : 0.2f * v) : (relu ? fmaxf(v, 0.f) : v);
+                    yb[(size_t)m * plane] = v;
+                }
+            }
+        }
+    }
+}
+
+// Weight gradient on the v3 scheme: the gathered-x fragment goes straight to registers (lane =
+// (column l & 31 of the wave, pixel half l >> 5)), dy rows through LDS (TM > 1) or direct (TM = 1).
+// Requires OW % 8 == 0 and (OH*OW) % 16 == 0 like v2.
+template <int TM>
+__global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, const int KS) {
+    constexpr int BM = 32 * TM;
+    constexpr int BN = 128;
+    constexpr int BK = 16;
+    constexpr int LD = BK + 4;
+    constexpr int NA4 = BM * 4;
+    constexpr int NA_PER = (NA4 + 255) / 256;
+    constexpr int TILE = BM * LD;
+    constexpr bool ALDS = TM > 1;
+
+    __shared__ __attribute__((aligned(16))) float lds[ALDS ? 2 * TILE : 4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane >> 5;
+    const int lcol = lane & 31;
+
+    const int T = KS * KS;
+    const int tiles_m = (a.m_end - a.m_begin + BM - 1) / BM;
+    const int tiles_n = (a.ncol + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    const int wg = og_xcd_remap(blockIdx.x, nwg);
+    const int tile_m = wg % tiles_m;
+    const int tile_n = wg / tiles_m;
+    const int m0 = a.m_begin + tile_m * BM;
+    const int c0 = tile_n * BN;
+
+    const int OHW = a.OH * a.OW;
+    const int HW = a.H * a.W;
+    const int Npix = a.N * OHW;
+    const int p_begin = blockIdx.y * a.pix_per_split;
+    const int p_end = min(Npix, p_begin + a.pix_per_split);
+    if (p_begin >= p_end) return;
+
+    __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.x, 0, (int)((unsigned)a.N * a.Cin * HW * 4u), OG_BUF_FLAGS);
+    __amdgpu_buffer_rsrc_t dyres = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.dy, 0, (int)((unsigned)a.N * a.Cout * OHW * 4u), OG_BUF_FLAGS);
+
+    // ---- column of this lane
+    const int col = c0 + wid * 32 + lcol;
+    const bool col_ok = col < a.ncol;
+    int dh, dw;
+    unsigned ci_off;
+    {
+        const int cc = col_ok ? col : 0;
+        const int ci = cc / T;
+        const int t = cc - ci * T;
+        const int kh = t / KS;
+        dh = kh - a.pad;
+        dw = (t - kh * KS) - a.pad;
+        ci_off = (unsigned)ci * (unsigned)HW;
+    }
+    const int us = a.upsample ? 1 : 0;
+    const bool refl = a.pad_mode == 1;
+
+    // per-lane pixel state: the eight pixels (one output row) of this lane's k half in the next step
+    int pn, poh, pow_;
+    {
+        const int p = p_begin + lrow * 8;
+        pn = p / OHW;
+        const int r = p - pn * OHW;
+        poh = r / a.OW;
+        pow_ = r - poh * a.OW;
+    }
+    auto load_b = [&](float (&rb)[8]) {
+        const int ih = poh * a.stride + dh;
+        int ihr = ih < 0 ? -ih : ih;
+        ihr = ihr >= a.LH ? 2 * (a.LH - 1) - ihr : ihr;
+        const bool row_ok = col_ok && (refl || (unsigned)ih < (unsigned)a.LH);
+        const unsigned rbase = (unsigned)pn * (unsigned)a.Cin * (unsigned)HW + ci_off
+                             + (unsigned)(((refl ? ihr : ih) >> us) * a.W);
+        // Fast path (no upsampling; stride 1 or 2): when the eight taps of every lane of the wave are
+        // interior -- or the whole row is padding -- they sit at a constant byte stride from the
+        // first one, which folds into the instruction's immediate offset: no per-element address
+        // arithmetic.  Spans touching the left / right border (2 of OW/8 per row) take the general path.
+        const int iw0 = pow_ * a.stride + dw;
+        const bool interior = iw0 >= 0 && iw0 + 7 * a.stride < a.LW;
+        if (!us && (a.stride == 1 || a.stride == 2) && __all(interior || !row_ok)) {
+            const unsigned vo = row_ok ? (rbase + (unsigned)iw0) * 4u : OG_OOB;
+            if (a.stride == 1) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, vo + 4u * i, 0, 0));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, vo + 8u * i, 0, 0));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int iw = (pow_ + i) * a.stride + dw;
+                int iwr = iw < 0 ? -iw : iw;
+                iwr = iwr >= a.LW ? 2 * (a.LW - 1) - iwr : iwr;
+                const bool ok = row_ok && (refl || (unsigned)iw < (unsigned)a.LW);
+                const unsigned vo = ok ? (rbase + (unsigned)((refl ? iwr : iw) >> us)) * 4u : OG_OOB;
+                rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, vo, 0, 0));
+            }
+        }
+        pow_ += BK;
+        while (pow_ >= a.OW) { pow_ -= a.OW; poh += 1; }
+        while (poh >= a.OH) { poh -= a.OH; pn += 1; }
+    };
+
+    // ---- dy rows
+    unsigned avoff[NA_PER];
+    int alds[NA_PER];
+    if (ALDS) {
+#pragma unroll
+        for (int i = 0; i < NA_PER; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 2, q = idx & 3;
+            const bool on = (NA4 % 256 == 0 || idx < NA4) && (m0 + row) < a.m_end;
+            avoff[i] = on ? ((unsigned)(m0 + row) * (unsigned)OHW + q * 4u) * 4u : OG_OOB;
+            alds[i] = (NA4 % 256 == 0 || idx < NA4) ? row * LD + q * 4 : -1;
+        }
+    }
+    const unsigned adir = (m0 + lcol) < a.m_end ? ((unsigned)(m0 + lcol) * (unsigned)OHW + lrow * 8u) * 4u : OG_OOB;
+    int n_ld = p_begin / OHW;                        // scalar (image, offset) of the next dy step
+    int rem_ld = p_begin - n_ld * OHW;
+    auto a_soff = [&]() {
+        const int so = (n_ld * a.Cout * OHW + rem_ld) * 4;
+        rem_ld += BK;
+        if (rem_ld >= OHW) { rem_ld = 0; n_ld += 1; }
+        return so;
+    };
+    f32x4 ra[NA_PER];
+    auto load_a = [&]() {
+        const int so = a_soff();
+#pragma unroll
+        for (int i = 0; i < NA_PER; ++i)
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyres, avoff[i], so, 0));
+    };
+    auto store_a = [&](int buf) {
+        float* As = lds + buf * TILE;
+#pragma unroll
+        for (int i = 0; i < NA_PER; ++i)
+            if (NA4 % 256 == 0 || alds[i] >= 0) *reinterpret_cast<f32x4*>(As + alds[i]) = ra[i];
+    };
+    auto load_adir = [&](f32x4 (&ad)[2]) {
+        const int so = a_soff();
+        ad[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyres, adir, so, 0));
+        ad[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyres, adir + 16u, so, 0));
+    };
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int a_rd = lcol * LD + lrow * 8;
+    float rb0[8], rb1[8];
+    f32x4 ad0[2], ad1[2];
+    auto mma = [&](const float (&rb)[8], const f32x4 (&ad)[2], int cur) {
+        if (ALDS) {
+            const float* Tl = lds + cur * TILE;
+            f32x4 a0[TM], a1[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                a0[i] = *reinterpret_cast<const f32x4*>(Tl + a_rd + i * 32 * LD);
+                a1[i] = *reinterpret_cast<const f32x4*>(Tl + a_rd + i * 32 * LD + 4);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][kk], rb[kk], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][kk], rb[4 + kk], acc[i], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[0][kk], rb[kk], acc[0], 0, 0, 0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[1][kk], rb[4 + kk], acc[0], 0, 0, 0);
+        }
+    };
+
+    const int nk = (p_end - p_begin) / BK;
+    if (ALDS) {
+        load_a();
+        store_a(0);
+        if (nk > 1) load_a();
+    } else {
+        load_adir(ad0);
+    }
+    load_b(rb0);
+    if (ALDS) __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) {
+            if (ALDS) store_a(cur ^ 1); else load_adir(ad1);
+            load_b(rb1);
+        }
+        if (ALDS && kt + 2 < nk) load_a();
+        mma(rb0, ad0, cur);
+        if (ALDS) __syncthreads();
+        cur ^= 1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rb0[i] = rb1[i];
+        if (!ALDS) { ad0[0] = ad1[0]; ad0[1] = ad1[1]; }
+    }
+
+    if (!col_ok) return;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+            if (m < a.m_end) atomicAdd(a.dw + (size_t)m * a.ncol + col, acc[i][r]);
         }
     }
 }
@@ -1293,6 +1803,12 @@ static int run_thin(IgemmArgs a, int MT, hipStream_t s) {
     return og_launch_status();
 }
 
+static int og_v3() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OG_V3"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
 static int og_trace() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("OG_TRACE"); v = (e && e[0] == '1') ? 1 : 0; }
@@ -1303,6 +1819,20 @@ static int launch_igemm2(const IgemmArgs& a, int TM, dim3 grid, hipStream_t s) {
     if (og_trace())
         fprintf(stderr, "OGTRACE igemm2 TM=%d M=%d rows=%d C=%d T=%d Npix=%d grid=%u,%u,%u H=%d W=%d stride=%d\n", TM, a.M,
                 a.m_end - a.m_begin, a.C, a.T, a.N * a.PH * a.PW, grid.x, grid.y, grid.z, a.H, a.W, a.stride);
+    // v3 (pixel fragments straight to registers); its TM = 1 form reads the filter rows directly
+    // as well, which only pays while the bank is tiny (thin outputs)
+    if (og_v3() && (TM > 1 || a.M <= 32)) {
+        switch (TM) {
+            case 1: hipLaunchKernelGGL((conv_igemm3_kernel<1>), grid, dim3(256), 0, s, a); break;
+            case 2: hipLaunchKernelGGL((conv_igemm3_kernel<2>), grid, dim3(256), 0, s, a); break;
+            case 3: hipLaunchKernelGGL((conv_igemm3_kernel<3>), grid, dim3(256), 0, s, a); break;
+            case 4: hipLaunchKernelGGL((conv_igemm3_kernel<4>), grid, dim3(256), 0, s, a); break;
+            case 5: hipLaunchKernelGGL((conv_igemm3_kernel<5>), grid, dim3(256), 0, s, a); break;
+            case 6: hipLaunchKernelGGL((conv_igemm3_kernel<6>), grid, dim3(256), 0, s, a); break;
+            default: hipLaunchKernelGGL((conv_igemm3_kernel<7>), grid, dim3(256), 0, s, a); break;
+        }
+        return og_launch_status();
+    }
     switch (TM) {
         case 1: hipLaunchKernelGGL((conv_igemm2_kernel<1>), grid, dim3(256), 0, s, a); break;
         case 2: hipLaunchKernelGGL((conv_igemm2_kernel<2>), grid, dim3(256), 0, s, a); break;
@@ -1520,7 +2050,7 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
             a.m_end = part == 0 ? (Cout < full_rows * TM * 32 ? Cout : full_rows * TM * 32) : Cout;
             // split K (pixels) so that this launch fills the resident workgroup slots once
             // (2 per CU for tall tiles, 3 up to TM = 4) without spilling into a second round
-            const int slots = 256 * (tm <= 4 ? 3 : 2);
+            const int slots = 256 * (tm == 1 && og_v3() ? 6 : (tm <= 4 ? 3 : 2));   // LDS-free TM = 1: more waves
             int splits = slots / (rows * tiles_n);
             const int max_splits = og_cdiv(Npix, 512);       // >= 32 K steps per split
             if (splits > max_splits) splits = max_splits;
@@ -1532,15 +2062,22 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
             dim3 grid(rows * tiles_n, splits);
             ProfRec* pr = prof_begin(OG_CAT_WGRAD2(tm),
                                      2.0 * (a.m_end - a.m_begin) * (double)a.ncol * (double)Npix, s);
+            static int pmode = -1;
+            if (pmode < 0) { const char* e = getenv("OG_WGRAD_PM"); pmode = e ? atoi(e) : 1; }
+            const bool pm = pmode == 2;
+#define OG_WG2(TMv) if (og_v3() && TMv <= 2) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv>), grid, dim3(256), 0, s, a, ksize); \
+                    else if (pm) hipLaunchKernelGGL((conv_wgrad2_kernel<TMv, true>), grid, dim3(256), 0, s, a, ksize); \
+                    else hipLaunchKernelGGL((conv_wgrad2_kernel<TMv, false>), grid, dim3(256), 0, s, a, ksize);
             switch (tm) {
-                case 1: hipLaunchKernelGGL((conv_wgrad2_kernel<1>), grid, dim3(256), 0, s, a, ksize); break;
-                case 2: hipLaunchKernelGGL((conv_wgrad2_kernel<2>), grid, dim3(256), 0, s, a, ksize); break;
-                case 3: hipLaunchKernelGGL((conv_wgrad2_kernel<3>), grid, dim3(256), 0, s, a, ksize); break;
-                case 4: hipLaunchKernelGGL((conv_wgrad2_kernel<4>), grid, dim3(256), 0, s, a, ksize); break;
-                case 5: hipLaunchKernelGGL((conv_wgrad2_kernel<5>), grid, dim3(256), 0, s, a, ksize); break;
-                case 6: hipLaunchKernelGGL((conv_wgrad2_kernel<6>), grid, dim3(256), 0, s, a, ksize); break;
-                default: hipLaunchKernelGGL((conv_wgrad2_kernel<7>), grid, dim3(256), 0, s, a, ksize); break;
+                case 1: OG_WG2(1) break;
+                case 2: OG_WG2(2) break;
+                case 3: OG_WG2(3) break;
+                case 4: OG_WG2(4) break;
+                case 5: OG_WG2(5) break;
+                case 6: OG_WG2(6) break;
+                default: OG_WG2(7) break;
             }
+#undef OG_WG2
             prof_end(pr, s);
             int rc = og_launch_status();
             if (rc != OG_OK) return rc;

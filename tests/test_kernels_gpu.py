@@ -41,6 +41,14 @@ CONV_CASES = [
     (2, 256, 12, 1, 48, 1, 1, 0, "zeros", False, False, None),          # conv_context 1x1
     (4, 200, 1, 1, 300, 1, 1, 0, "zeros", False, True, None),           # linear
     (1, 7, 13, 10, 130, 3, 2, 1, "zeros", False, True, None),           # odd sizes, stride 2, k3
+    # >= 65536 output pixels and <= 32 output channels: the direct (VALU) thin kernels
+    (2, 10, 192, 192, 12, 3, 1, 1, "reflect", False, True, None),       # 3x3 column-strip kernel, shp_code
+    (2, 9, 192, 192, 24, 3, 1, 1, "reflect", False, True, None),        # ... G_HMAP stem (odd C)
+    (2, 6, 190, 194, 3, 3, 1, 1, "zeros", False, False, "tanh"),        # ... to-RGB, ragged strips
+    (1, 5, 136, 128, 20, 3, 1, 1, "zeros", True, False, "lrelu"),       # generic thin kernel (upsample)
+    (2, 15, 384, 384, 40, 4, 2, 1, "zeros", False, False, "lrelu"),     # dgrad phases with M = 15: thin T=4
+    # one-launch four-phase data gradient (Cin > 32, even sizes)
+    (2, 48, 24, 40, 64, 4, 2, 1, "zeros", False, False, None),
 ]
 
 
@@ -79,6 +87,12 @@ NORM_CASES = [
     (4, 10, 8, 8, True, "glu", True, False),     # BN + GLU (upBlock)
     (4, 12, 6, 6, True, "lrelu", True, False),   # BN + LeakyReLU (D encoder)
     (16, 64, 1, 1, True, "glu", True, False),    # BatchNorm1d + GLU (INIT_STAGE_G.fc)
+    # H*W >= 256 and a multiple of 4: the plane-structured float4 kernels
+    (3, 8, 32, 32, False, None, False, True),
+    (2, 12, 16, 24, False, "glu", False, False),
+    (3, 10, 16, 16, True, "glu", True, False),
+    (2, 6, 96, 96, True, "lrelu", True, False),  # more than one chunk per plane
+    (2, 4, 16, 18, False, "lrelu", False, False),
 ]
 
 
@@ -400,3 +414,34 @@ def test_inception_encoder_gpu_matches_cpu(dev):
         pr = mon(x)
         pd = copy.deepcopy(mon).to(dev)(x.to(dev))
     assert rel_l2(pd, pr) < TOL
+
+
+def test_packed_filter_cache_follows_weight_updates(dev):
+    """The host-side packed-bank cache must notice (a) torch in-place edits (version counter) and
+    (b) the fused Adam kernel writing through a raw pointer (arena epoch)."""
+    import trainer as T
+    ops, tr = _ops(), _tref()
+    g = torch.Generator().manual_seed(3)
+    conv = torch.nn.Conv2d(40, 64, 3, padding=1, bias=False).to(dev)
+    x = torch.randn(2, 40, 16, 16, generator=g).to(dev)
+    arena = T.ParamArena(conv)
+    opt = T.ArenaAdam(arena, 1e-2)
+
+    def check():
+        y = ops.conv2d(x, conv.weight, None, 1, 1)
+        want = tr.conv2d(x.cpu(), conv.weight.detach().cpu(), None, 1, 1)
+        assert rel_l2(y, want) < TOL
+    check()
+    check()                                     # second call: served from the cache
+    opt.zero_grad()
+    ops.conv2d(x, conv.weight, None, 1, 1).square().mean().backward()
+    opt.step()                                  # raw-pointer update
+    check()
+    with torch.no_grad():
+        conv.weight.mul_(0.5)                   # torch-side update
+    check()
+    frozen = torch.randn(8, 40, 3, 3, generator=g).to(dev)
+    y1 = ops.conv2d(x, frozen, None, 1, 1)
+    frozen.add_(1.0)
+    y2 = ops.conv2d(x, frozen, None, 1, 1)
+    assert rel_l2(y2, tr.conv2d(x.cpu(), frozen.cpu(), None, 1, 1)) < TOL and rel_l2(y1, y2) > 1e-2
