@@ -17,7 +17,7 @@ One JSON line is printed by rank 0: the contract fields plus
                 (events recorded by the library on the launch stream), against the fp32 MFMA peak;
                 traffic = HBM bytes per launch from the rocprofv3 --pmc passes kept in profiles/
   cpu_baseline  the CPU oracle (oracle/torch_model.py, a port of the reference path) timed on this
-                host's cores on a bounded sample (one step at batch 2, <= 16 threads,
+                host's cores on a bounded sample (one step at batch 8, <= 16 threads,
                 child process with a hard time limit)
 """
 import argparse
@@ -37,9 +37,10 @@ import torch.distributed as dist                # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3                   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 # timing categories of the library = kernel instances, named as rocprofv3 prints them
-CAT_NAMES = (["conv_igemm2_kernel<%d>" % tm for tm in range(1, 8)] +
-             ["conv_wgrad2_kernel<%d>" % tm for tm in range(1, 8)] +
-             ["conv_thin_kernel", "conv_thin3x3_kernel", "conv_igemm_kernel(v1)", "conv_wgrad_kernel(v1)"])
+CAT_NAMES = (["conv_igemm3_kernel<%d, false>" % tm for tm in range(1, 8)] +
+             ["conv_wgrad2_kernel<%d, false>" % tm for tm in range(1, 8)] +
+             ["conv_thin_kernel", "conv_thin3x3_kernel", "conv_igemm_kernel", "conv_wgrad_kernel",
+              "conv_igemm3_kernel<1, true>", "conv_wgrad3_kernel<1>", "conv_wgrad3_kernel<2>"])
 PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
@@ -105,7 +106,7 @@ def _cpu_baseline_worker(sample_batch, threads, seed=1234):
                    % (sample_batch, dt, threads, os.cpu_count() or 1)}), flush=True)
 
 
-def cpu_baseline(sample_batch=2, max_threads=16, timeout_s=240):
+def cpu_baseline(sample_batch=8, max_threads=16, timeout_s=240):
     """The oracle timed on the host cores, on a bounded sample (one step at a small batch), in a
     child process with a hard time limit so that the default bench run always finishes."""
     import subprocess

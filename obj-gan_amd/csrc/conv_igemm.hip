@@ -1158,7 +1158,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
 // dy), which all four waves share, is staged through LDS -- and for TM = 1 (thin outputs) it is read
 // straight from L1/L2 as two 16-byte loads per lane, so those launches run without LDS and without
 // barriers at all: waves are independent and latency is hidden by occupancy.
-template <int TM>
+template <int TM, bool ADIRECT = false>
 __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
     constexpr int BM = 32 * TM;
     constexpr int BN = 128;
@@ -1167,7 +1167,7 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
     constexpr int NA4 = BM * 4;
     constexpr int NA_PER = (NA4 + 255) / 256;
     constexpr int TILE = BM * LD;
-    constexpr bool ALDS = TM > 1;                     // row operand through LDS (shared by 4 waves)
+    constexpr bool ALDS = !(ADIRECT && TM == 1);      // row operand through LDS (shared by 4 waves)
 
     __shared__ __attribute__((aligned(16))) float lds[ALDS ? 2 * TILE : 4];
 
@@ -1606,6 +1606,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, con
 // When enabled, every conv launch is bracketed by hipEvents on its own stream and tagged with a
 // category (kind, taps / ksize, tile config) and its ALGORITHMIC flops 2*M*K*Npix.  Off by default;
 // the only mutable global state of the library, touched by the host thread only.
+static int og_v3();
 #define OG_PROF_CATS 32
 #define OG_PROF_MAX 16384
 struct ProfRec { hipEvent_t a, b; int cat; double flops; };
@@ -1615,10 +1616,12 @@ static int g_prof_n = 0;
 static int g_prof_made = 0;
 
 // categories = kernel instances, so that they line up with the kernel names rocprofv3 reports:
-//   0..6  conv_igemm2_kernel<1..7>     7..13 conv_wgrad2_kernel<1..7>
+//   0..6  conv_igemm3_kernel<1..7>     7..13 conv_wgrad2_kernel<1..7, false>
 //   14 conv_thin_kernel<*>   15 conv_thin3x3_kernel<*>   16 conv_igemm_kernel<*> (v1)   17 conv_wgrad_kernel<*> (v1)
-#define OG_CAT_IGEMM2(tm) ((tm) - 1)
-#define OG_CAT_WGRAD2(tm) (7 + (tm) - 1)
+//   18 conv_igemm3_kernel<1, true> (LDS-free form for thin outputs)   19..20 conv_wgrad3_kernel<1..2>
+// (with OG_V3=0 the 0..6 / 7..13 slots hold the v2 instances instead)
+#define OG_CAT_IGEMM2(tm) ((og_v3() && (tm) == 1 && a.M <= 32) ? 18 : ((tm) - 1))
+#define OG_CAT_WGRAD2(tm) ((og_v3() && (tm) <= 2) ? 18 + (tm) : (7 + (tm) - 1))
 #define OG_CAT_THIN 14
 #define OG_CAT_THIN3 15
 #define OG_CAT_IGEMM1 16
@@ -1821,9 +1824,11 @@ static int launch_igemm2(const IgemmArgs& a, int TM, dim3 grid, hipStream_t s) {
                 a.m_end - a.m_begin, a.C, a.T, a.N * a.PH * a.PW, grid.x, grid.y, grid.z, a.H, a.W, a.stride);
     // v3 (pixel fragments straight to registers); its TM = 1 form reads the filter rows directly
     // as well, which only pays while the bank is tiny (thin outputs)
-    if (og_v3() && (TM > 1 || a.M <= 32)) {
+    if (og_v3()) {
         switch (TM) {
-            case 1: hipLaunchKernelGGL((conv_igemm3_kernel<1>), grid, dim3(256), 0, s, a); break;
+            case 1: if (a.M <= 32) hipLaunchKernelGGL((conv_igemm3_kernel<1, true>), grid, dim3(256), 0, s, a);
+                    else hipLaunchKernelGGL((conv_igemm3_kernel<1, false>), grid, dim3(256), 0, s, a);
+                    break;
             case 2: hipLaunchKernelGGL((conv_igemm3_kernel<2>), grid, dim3(256), 0, s, a); break;
             case 3: hipLaunchKernelGGL((conv_igemm3_kernel<3>), grid, dim3(256), 0, s, a); break;
             case 4: hipLaunchKernelGGL((conv_igemm3_kernel<4>), grid, dim3(256), 0, s, a); break;
