@@ -38,7 +38,7 @@ import torch.distributed as dist                # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3                   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 # timing categories of the library = kernel instances, named as rocprofv3 prints them
 CAT_NAMES = (["conv_igemm3_kernel<%d, false>" % tm for tm in range(1, 8)] +
-             ["conv_wgrad2_kernel<%d, false>" % tm for tm in range(1, 8)] +
+             ["conv_wgrad2_kernel<%d>" % tm for tm in range(1, 8)] +
              ["conv_thin_kernel", "conv_thin3x3_kernel", "conv_igemm_kernel", "conv_wgrad_kernel",
               "conv_igemm3_kernel<1, true>", "conv_wgrad3_kernel<1>", "conv_wgrad3_kernel<2>"])
 PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")

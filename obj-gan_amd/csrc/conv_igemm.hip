@@ -19,16 +19,17 @@
 //
 // GEMM view: M = output channels, N = pixels (n, a, b), K = T*Cp (TAP-MAJOR: k = t*Cp + c with
 // Cp = C rounded up to the K step of 16, so that one K step of the main loop touches ONE tap:
-// the tap geometry -- bounds / reflect / upsample / offset -- is evaluated once per step and
-// lane, the 8-16 gathered elements of the step differ only by a wave-uniform channel offset).  A workgroup of 4 waves
-// owns a BM x BN tile (BM in {128, 64, 32}); each wave owns TM x 2 MFMA tiles of 32x32,
-// accumulators stay in AGPRs for the whole K loop.  Operands go HBM -> VGPR -> LDS ->
-// VGPR -> MFMA, double-buffered in LDS with one barrier per K step (BK = 16); the global
-// loads of step k+1 are issued before the MFMAs of step k.  The weight matrix is
-// pre-packed K-major ([K][Mpad], zero padded) so its loads are 16-byte and coalesced and
-// its LDS image needs no transpose; the activation gather is one dword per lane with
-// consecutive lanes on consecutive pixels (coalesced along W).  Workgroup ids are
-// remapped so that the M-tiles sharing one pixel tile run on the same XCD (shared L2).
+// the tap geometry -- bounds / reflect / upsample / offset -- is evaluated once per tap and lane).
+//
+// Kernels in this file, in the order they are chosen:
+//   conv_thin3x3_kernel / conv_thin_kernel   M <= 32 outputs: direct fp32 VALU convolution
+//   conv_igemm3_kernel<TM>                   everything else: (32*TM) x 128 tile, pixel fragments
+//                                            straight from the gather registers, filter rows via LDS
+//   conv_wgrad3_kernel<TM<=2> / conv_wgrad2_kernel<TM>   weight gradient on the same tiling
+//   conv_igemm_kernel / conv_wgrad_kernel    the first-generation 128x128 / 64x256 / 32x256 kernels:
+//                                            kept for tensors beyond the 2 GiB reach of a buffer
+//                                            descriptor and for weight gradients of maps narrower
+//                                            than 8 pixels
 #include "common.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -61,7 +62,6 @@ struct IgemmArgs {
     int upsample;        // 1 = source index = logical index >> 1
     int act;
     int ksplit_steps;    // > 0: split-K -- blockIdx.y owns this many BK steps, epilogue = atomicAdd
-    int ablate;          // development only (OG_ABLATE): 1 no global loads, 2 no barrier, 4 no LDS writes, 8 no frag reads
     int nphase;          // > 1 (v2 kernel only): blockIdx.z = output phase p with its own tap table
                          // tap[p*8 ..], packed bank wt + p*M*Kpad and output offset (ooh, oow) = (p>>1, p&1)
     int tap[OG_MAX_TAPS];   // (dw << 16) | (dh & 0xffff): one scalar load per (uniform) tap
@@ -267,222 +267,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
     }
 }
 
-// =============================================================================================
-// v2 main loop.  Same GEMM view as above, re-tiled for the CDNA4 issue model:
-//   * workgroup = 4 waves, tile = (32*TM) x 128: every wave owns ONE 32-pixel column group and ALL
-//     TM 32-row groups (TM 32x32 accumulators in AGPRs), so ragged channel counts cost at most one
-//     partly filled 32-row group per block row (194 -> 7 groups, 388 -> 7 + 6) and row groups
-//     beyond M are skipped by a wave-uniform branch;
-//   * LDS tiles are k-contiguous, [row][16 + 4 pad]: a lane's eight k values of a K step are two
-//     ds_read_b128 (conflict-free with the 80-byte row pitch).  The MFMA k pairing is permuted
-//     accordingly -- MFMA kk multiplies k positions {kk, 8 + kk} -- identically for both operands;
-//   * global loads are buffer loads through SGPR resource descriptors: the per-lane offset carries
-//     the pixel, the scalar offset the channel / k position -- no 64-bit address arithmetic in the
-//     loop -- and zero padding / out-of-tile rows come from the hardware range check
-//     (out-of-range offset -> 0), not from selects;
-//   * the tap geometry (bounds, reflection, upsample) is recomputed only when the tap changes.
-// The filter bank is packed [M][Kpad] (k contiguous) for this kernel.
 template <int V> struct OgInt { static constexpr int value = V; };
 #define OG_BUF_FLAGS 0x00020000
 #define OG_OOB 0x7ffffff0u
-
-template <int TM>
-__global__ __launch_bounds__(256) void conv_igemm2_kernel(const IgemmArgs a) {
-    constexpr int BM = 32 * TM;
-    constexpr int BN = 128;
-    constexpr int BK = 16;
-    constexpr int LD = BK + 4;
-    constexpr int NA4 = BM * 4;                      // float4s of one A tile
-    constexpr int NA_PER = (NA4 + 255) / 256;
-    constexpr int TILE = (BM + BN) * LD;
-
-    __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    const int Npix = a.N * a.PH * a.PW;
-    const int tiles_m = (a.m_end - a.m_begin + BM - 1) / BM;
-    const int tiles_n = (Npix + BN - 1) / BN;
-    const int nwg = tiles_m * tiles_n;
-    const int wg = og_xcd_remap(blockIdx.x, nwg);
-    const int tile_m = wg % tiles_m;
-    const int tile_n = wg / tiles_m;
-    const int m0 = a.m_begin + tile_m * BM;
-    const int n0 = tile_n * BN;
-
-    const int phase = a.nphase > 1 ? (int)blockIdx.z : 0;      // wave-uniform
-    const int tapbase = phase * 8;
-    const int HW = a.H * a.W;
-    __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.x, 0, (int)((unsigned)a.N * a.C * HW * 4u), OG_BUF_FLAGS);
-    __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.wt + (size_t)phase * a.M * a.Kpad), 0, (int)((unsigned)a.M * a.Kpad * 4u), OG_BUF_FLAGS);
-
-    // ---- B gather geometry: thread = (pixel p of the tile, k half g)
-    const int bp = tid & (BN - 1);
-    const int bg = __builtin_amdgcn_readfirstlane(tid >> 7);      // 0: k 0..7, 1: k 8..15
-    const int pix = n0 + bp;
-    const bool pix_ok = pix < Npix;
-    int ihb, iwb;
-    unsigned img_off;
-    {
-        const int ppi = a.PH * a.PW;
-        const int pp = pix_ok ? pix : 0;
-        const int n = pp / ppi;
-        const int rem = pp - n * ppi;
-        const int pa = rem / a.PW;
-        const int pb = rem - pa * a.PW;
-        ihb = pa * a.stride;
-        iwb = pb * a.stride;
-        img_off = (unsigned)n * (unsigned)a.C * (unsigned)HW;
-    }
-    const int us = a.upsample ? 1 : 0;
-    const bool refl = a.pad_mode == 1;
-    unsigned bvoff = OG_OOB;                         // byte offset of (n, c = 0, ih, iw) or out of range
-    auto tap_geometry = [&](int t) {
-        const int tp = a.tap[tapbase + t];
-        const int ih = ihb + ((tp << 16) >> 16);
-        const int iw = iwb + (tp >> 16);
-        int ihr = ih < 0 ? -ih : ih;
-        int iwr = iw < 0 ? -iw : iw;
-        ihr = ihr >= a.LH ? 2 * (a.LH - 1) - ihr : ihr;
-        iwr = iwr >= a.LW ? 2 * (a.LW - 1) - iwr : iwr;
-        const bool inb = ((unsigned)ih < (unsigned)a.LH) && ((unsigned)iw < (unsigned)a.LW);
-        const bool ok = pix_ok && (refl || inb);
-        const int ihs = (refl ? ihr : ih) >> us;
-        const int iws = (refl ? iwr : iw) >> us;
-        bvoff = ok ? (img_off + (unsigned)(ihs * a.W + iws)) * 4u : OG_OOB;
-    };
-
-    // ---- A (filter bank) geometry: float4 idx -> (row, quarter)
-    unsigned avoff[NA_PER];
-    int alds[NA_PER];
-#pragma unroll
-    for (int i = 0; i < NA_PER; ++i) {
-        const int idx = tid + 256 * i;
-        const int row = idx >> 2, q = idx & 3;
-        const bool on = idx < NA4 && (m0 + row) < a.m_end;
-        avoff[i] = on ? ((unsigned)(m0 + row) * (unsigned)a.Kpad + q * 4u) * 4u : OG_OOB;
-        alds[i] = (NA4 % 256 == 0 || idx < NA4) ? row * LD + q * 4 : -1;
-    }
-
-    f32x4 ra[NA_PER];
-    float rb[8];
-    int t_ld, cb_ld;                                 // (tap, channel base) of the next K step to load
-    const int spt = a.Cp / BK;
-    auto load_step = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < NA_PER; ++i)
-            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, avoff[i], kt * (BK * 4), 0));
-        const int cbase = cb_ld + bg * 8;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = min(cbase + i, a.C - 1);   // padded channels: finite data x zero weight
-            rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, bvoff, c * HW * 4, 0));
-        }
-        cb_ld += BK;
-        if (cb_ld >= a.Cp) {                         // wave-uniform: next step starts a new tap
-            cb_ld = 0;
-            t_ld += 1;
-            if (t_ld < a.T) tap_geometry(t_ld);
-        }
-    };
-    auto store_step = [&](int buf) {
-        float* As = lds + buf * TILE;
-        float* Bs = As + BM * LD;
-#pragma unroll
-        for (int i = 0; i < NA_PER; ++i)
-            if (NA4 % 256 == 0 || alds[i] >= 0) *reinterpret_cast<f32x4*>(As + alds[i]) = ra[i];
-        f32x4 v0 = {rb[0], rb[1], rb[2], rb[3]}, v1 = {rb[4], rb[5], rb[6], rb[7]};
-        *reinterpret_cast<f32x4*>(Bs + bp * LD + bg * 8) = v0;
-        *reinterpret_cast<f32x4*>(Bs + bp * LD + bg * 8 + 4) = v1;
-    };
-
-    const int nk_all = a.Kpad / BK;
-    const int kt0 = a.ksplit_steps > 0 ? blockIdx.y * a.ksplit_steps : 0;
-    const int nk = a.ksplit_steps > 0 ? min(nk_all, kt0 + a.ksplit_steps) : nk_all;
-    t_ld = kt0 / spt;
-    cb_ld = (kt0 - t_ld * spt) * BK;
-    tap_geometry(t_ld);
-    // software pipeline, two K steps deep: step k+1 sits in LDS, step k+2 is in flight in registers
-    load_step(kt0);
-    store_step(0);
-    if (kt0 + 1 < nk) load_step(kt0 + 1);
-    __syncthreads();
-
-    const int lrow = lane >> 5;
-    const int lcol = lane & 31;
-    const int a_rd = lcol * LD + lrow * 8;                       // + i*32*LD
-    const int b_rd = BM * LD + (wid * 32 + lcol) * LD + lrow * 8;
-
-    f32x16 acc[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    int cur = 0;
-    for (int kt = kt0; kt < nk; ++kt) {
-        // registers hold step kt+1 (loaded one iteration ago): park it in the other LDS buffer (free
-        // since the barrier that closed iteration kt-1), then refill the registers with step kt+2
-        if ((kt + 1) < nk && !(a.ablate & 4)) store_step(cur ^ 1);
-        if ((kt + 2) < nk && !(a.ablate & 1)) load_step(kt + 2);
-        const float* T = lds + ((a.ablate & 8) ? 0 : cur) * TILE;
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(T + b_rd);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(T + b_rd + 4);
-        f32x4 a0[TM], a1[TM];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            a0[i] = *reinterpret_cast<const f32x4*>(T + a_rd + i * 32 * LD);
-            a1[i] = *reinterpret_cast<const f32x4*>(T + a_rd + i * 32 * LD + 4);
-        }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][kk], b0[kk], acc[i], 0, 0, 0);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][kk], b1[kk], acc[i], 0, 0, 0);
-        if (!(a.ablate & 2)) __syncthreads();
-        cur ^= 1;
-    }
-
-    // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
-    const int p = n0 + wid * 32 + lcol;
-    if (p >= Npix) return;
-    const int ppi = a.PH * a.PW;
-    const int n = p / ppi;
-    const int rem = p - n * ppi;
-    const int pa = rem / a.PW;
-    const int pb = rem - pa * a.PW;
-    const int oh = pa * a.osh + (a.nphase > 1 ? (phase >> 1) : a.ooh);
-    const int ow = pb * a.osw + (a.nphase > 1 ? (phase & 1) : a.oow);
-    const size_t plane = (size_t)a.OHf * a.OWf;
-    float* yb = a.y + (size_t)n * a.M * plane + (size_t)oh * a.OWf + ow;
-    const bool split = a.ksplit_steps > 0;
-    const bool lrelu = a.act == OG_ACT_LRELU, relu = a.act == OG_ACT_RELU;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-            if (m < a.m_end) {
-                float v = acc[i][r];
-                if (split) {
-                    atomicAdd(&yb[(size_t)m * plane], v);       // bias/act: follow-up pass
-                } else {
-                    if (a.bias) v += a.bias[m];
-                    v = lrelu ? (v > 0.f ? v : 0.2f * v) : (relu ? fmaxf(v, 0.f) : v);   // tanh/sigmoid: follow-up pass
-                    yb[(size_t)m * plane] = v;
-                }
-            }
-        }
-    }
-}
 
 // =============================================================================================
 // Thin outputs (M <= 32 channels: the 80->12 / 80->24 layout-map stems, to-RGB, data gradients
@@ -912,14 +699,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 }
 
 // ---- weight gradient, v2 -----------------------------------------------------------------------
-// Same tiling / LDS layout / buffer-load scheme as conv_igemm2_kernel: tile (32*TM) x 128 columns
+// Same tiling / LDS layout / buffer-load scheme as conv_igemm3_kernel (with both operands in LDS): tile (32*TM) x 128 columns
 // (column = ci*T + t), K = 16 output pixels per step.  Requires OW % 8 == 0 and (OH*OW) % 16 == 0
 // (every layer of the hot path above 4x4 maps), so that the eight pixels a thread gathers per step
 // lie in one output row and a K step lies in one image: the pixel part of every address is then a
 // SCALAR (n, oh, ow0 .. ow0+7), the per-lane part is the column's (ci, kh, kw) -- dy rows are read
 // as aligned 16-byte pieces with a constant per-lane offset, x elements as dwords whose validity
 // (zero padding) rides on the buffer range check.
-template <int TM, bool PM>
+template <int TM>
 __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, const int KS) {
     constexpr int BM = 32 * TM;
     constexpr int BN = 128;
@@ -976,38 +763,6 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
     const int us = a.upsample ? 1 : 0;
     const bool refl = a.pad_mode == 1;
 
-    // ---- pixel-major gather (PM): thread = (pixel kp of the K step, column slot); it loads the
-    // eight columns slot + 16 j at ITS pixel, so that the 16 lanes of a slot read 16 consecutive
-    // pixels (one 64-byte segment) -- 4-5 cache lines per load instruction instead of ~20 when
-    // every lane owns a different (channel, tap) column.  Column constants are per-thread registers.
-    const int kp = tid & 15;
-    const int slot = tid >> 4;
-    int cdh[8], cdw[8];
-    unsigned coff[8];        // ci*HW (+ dh*W + dw when the tap offset can be pre-added), or OOB marker
-    if (PM) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int cj = c0 + slot + 16 * j;
-            const bool ok = cj < a.ncol;
-            const int cc = ok ? cj : 0;
-            const int ci = cc / T;
-            const int t = cc - ci * T;
-            const int kh = t / KS;
-            cdh[j] = kh - a.pad;
-            cdw[j] = (t - kh * KS) - a.pad;
-            coff[j] = ok ? (unsigned)ci * (unsigned)HW : OG_OOB;
-        }
-    }
-    // per-lane pixel state of the next K step (PM)
-    int pn = 0, poh = 0, pow_ = 0;
-    if (PM) {
-        const int p = p_begin + kp;
-        pn = p / OHW;
-        const int r = p - pn * OHW;
-        poh = r / a.OW;
-        pow_ = r - poh * a.OW;
-    }
-
     // ---- A (dy) geometry: float4 idx -> (row, quarter); constant per-lane offset
     unsigned avoff[NA_PER];
     int alds[NA_PER];
@@ -1042,27 +797,6 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
             oh_ld = (bg * 8) / a.OW;
             ow_ld = (bg * 8) - oh_ld * a.OW;
         }
-        if (PM) {
-            const int ihb = poh * a.stride, iwb = pow_ * a.stride;
-            const unsigned nb = (unsigned)pn * (unsigned)a.Cin * (unsigned)HW;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int ih = ihb + cdh[j], iw = iwb + cdw[j];
-                int ihr = ih < 0 ? -ih : ih;
-                int iwr = iw < 0 ? -iw : iw;
-                ihr = ihr >= a.LH ? 2 * (a.LH - 1) - ihr : ihr;
-                iwr = iwr >= a.LW ? 2 * (a.LW - 1) - iwr : iwr;
-                const bool inb = ((unsigned)ih < (unsigned)a.LH) && ((unsigned)iw < (unsigned)a.LW);
-                const bool ok = (coff[j] != OG_OOB) && (refl || inb);
-                const int ihs = (refl ? ihr : ih) >> us, iws = (refl ? iwr : iw) >> us;
-                const unsigned vo = ok ? (nb + coff[j] + (unsigned)(ihs * a.W + iws)) * 4u : OG_OOB;
-                rb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, vo, 0, 0));
-            }
-            pow_ += BK;                               // advance this lane's pixel by one K step
-            while (pow_ >= a.OW) { pow_ -= a.OW; poh += 1; }
-            while (poh >= a.OH) { poh -= a.OH; pn += 1; }
-            return;
-        }
         const int ih = oh * a.stride + dh;
         int ihr = ih < 0 ? -ih : ih;
         ihr = ihr >= a.LH ? 2 * (a.LH - 1) - ihr : ihr;
@@ -1085,11 +819,6 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
 #pragma unroll
         for (int i = 0; i < NA_PER; ++i)
             if (NA4 % 256 == 0 || alds[i] >= 0) *reinterpret_cast<f32x4*>(As + alds[i]) = ra[i];
-        if (PM) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) Bs[(slot + 16 * j) * LD + kp] = rb[j];
-            return;
-        }
         f32x4 v0 = {rb[0], rb[1], rb[2], rb[3]}, v1 = {rb[4], rb[5], rb[6], rb[7]};
         *reinterpret_cast<f32x4*>(Bs + bc * LD + bg * 8) = v0;
         *reinterpret_cast<f32x4*>(Bs + bc * LD + bg * 8 + 4) = v1;
@@ -1113,7 +842,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if ((kt + 1) < nk) store_step(cur ^ 1);      // two-deep pipeline, as in conv_igemm2_kernel
+        if ((kt + 1) < nk) store_step(cur ^ 1);      // two-deep register -> LDS pipeline
         if ((kt + 2) < nk) load_step();
         const float* Tl = lds + cur * TILE;
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(Tl + b_rd);
@@ -1606,7 +1335,6 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, con
 // When enabled, every conv launch is bracketed by hipEvents on its own stream and tagged with a
 // category (kind, taps / ksize, tile config) and its ALGORITHMIC flops 2*M*K*Npix.  Off by default;
 // the only mutable global state of the library, touched by the host thread only.
-static int og_v3();
 #define OG_PROF_CATS 32
 #define OG_PROF_MAX 16384
 struct ProfRec { hipEvent_t a, b; int cat; double flops; };
@@ -1619,9 +1347,8 @@ static int g_prof_made = 0;
 //   0..6  conv_igemm3_kernel<1..7>     7..13 conv_wgrad2_kernel<1..7, false>
 //   14 conv_thin_kernel<*>   15 conv_thin3x3_kernel<*>   16 conv_igemm_kernel<*> (v1)   17 conv_wgrad_kernel<*> (v1)
 //   18 conv_igemm3_kernel<1, true> (LDS-free form for thin outputs)   19..20 conv_wgrad3_kernel<1..2>
-// (with OG_V3=0 the 0..6 / 7..13 slots hold the v2 instances instead)
-#define OG_CAT_IGEMM2(tm) ((og_v3() && (tm) == 1 && a.M <= 32) ? 18 : ((tm) - 1))
-#define OG_CAT_WGRAD2(tm) ((og_v3() && (tm) <= 2) ? 18 + (tm) : (7 + (tm) - 1))
+#define OG_CAT_IGEMM2(tm) (((tm) == 1 && a.M <= 32) ? 18 : ((tm) - 1))
+#define OG_CAT_WGRAD2(tm) (((tm) <= 2) ? 18 + (tm) : (7 + (tm) - 1))
 #define OG_CAT_THIN 14
 #define OG_CAT_THIN3 15
 #define OG_CAT_IGEMM1 16
@@ -1806,12 +1533,6 @@ static int run_thin(IgemmArgs a, int MT, hipStream_t s) {
     return og_launch_status();
 }
 
-static int og_v3() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("OG_V3"); v = e ? atoi(e) : 1; }
-    return v;
-}
-
 static int og_trace() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("OG_TRACE"); v = (e && e[0] == '1') ? 1 : 0; }
@@ -1820,33 +1541,19 @@ static int og_trace() {
 
 static int launch_igemm2(const IgemmArgs& a, int TM, dim3 grid, hipStream_t s) {
     if (og_trace())
-        fprintf(stderr, "OGTRACE igemm2 TM=%d M=%d rows=%d C=%d T=%d Npix=%d grid=%u,%u,%u H=%d W=%d stride=%d\n", TM, a.M,
+        fprintf(stderr, "OGTRACE igemm TM=%d M=%d rows=%d C=%d T=%d Npix=%d grid=%u,%u,%u H=%d W=%d stride=%d\n", TM, a.M,
                 a.m_end - a.m_begin, a.C, a.T, a.N * a.PH * a.PW, grid.x, grid.y, grid.z, a.H, a.W, a.stride);
-    // v3 (pixel fragments straight to registers); its TM = 1 form reads the filter rows directly
-    // as well, which only pays while the bank is tiny (thin outputs)
-    if (og_v3()) {
-        switch (TM) {
-            case 1: if (a.M <= 32) hipLaunchKernelGGL((conv_igemm3_kernel<1, true>), grid, dim3(256), 0, s, a);
-                    else hipLaunchKernelGGL((conv_igemm3_kernel<1, false>), grid, dim3(256), 0, s, a);
-                    break;
-            case 2: hipLaunchKernelGGL((conv_igemm3_kernel<2>), grid, dim3(256), 0, s, a); break;
-            case 3: hipLaunchKernelGGL((conv_igemm3_kernel<3>), grid, dim3(256), 0, s, a); break;
-            case 4: hipLaunchKernelGGL((conv_igemm3_kernel<4>), grid, dim3(256), 0, s, a); break;
-            case 5: hipLaunchKernelGGL((conv_igemm3_kernel<5>), grid, dim3(256), 0, s, a); break;
-            case 6: hipLaunchKernelGGL((conv_igemm3_kernel<6>), grid, dim3(256), 0, s, a); break;
-            default: hipLaunchKernelGGL((conv_igemm3_kernel<7>), grid, dim3(256), 0, s, a); break;
-        }
-        return og_launch_status();
-    }
     switch (TM) {
-        case 1: hipLaunchKernelGGL((conv_igemm2_kernel<1>), grid, dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL((conv_igemm2_kernel<2>), grid, dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL((conv_igemm2_kernel<3>), grid, dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL((conv_igemm2_kernel<4>), grid, dim3(256), 0, s, a); break;
-        case 5: hipLaunchKernelGGL((conv_igemm2_kernel<5>), grid, dim3(256), 0, s, a); break;
-        case 6: hipLaunchKernelGGL((conv_igemm2_kernel<6>), grid, dim3(256), 0, s, a); break;
-        case 7: hipLaunchKernelGGL((conv_igemm2_kernel<7>), grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((conv_igemm2_kernel<8>), grid, dim3(256), 0, s, a); break;
+        // TM = 1: the LDS-free form reads the filter rows directly, which only pays while the bank is tiny
+        case 1: if (a.M <= 32) hipLaunchKernelGGL((conv_igemm3_kernel<1, true>), grid, dim3(256), 0, s, a);
+                else hipLaunchKernelGGL((conv_igemm3_kernel<1, false>), grid, dim3(256), 0, s, a);
+                break;
+        case 2: hipLaunchKernelGGL((conv_igemm3_kernel<2>), grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((conv_igemm3_kernel<3>), grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((conv_igemm3_kernel<4>), grid, dim3(256), 0, s, a); break;
+        case 5: hipLaunchKernelGGL((conv_igemm3_kernel<5>), grid, dim3(256), 0, s, a); break;
+        case 6: hipLaunchKernelGGL((conv_igemm3_kernel<6>), grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((conv_igemm3_kernel<7>), grid, dim3(256), 0, s, a); break;
     }
     return og_launch_status();
 }
@@ -1859,7 +1566,6 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed) {
     const int Npix = a.N * a.PH * a.PW;
     const int tiles_n = og_cdiv(Npix, 128);
     const int nph = a.nphase > 1 ? a.nphase : 1;
-    { static int abl = -1; if (abl < 0) { const char* e = getenv("OG_ABLATE"); abl = e ? atoi(e) : 0; } a.ablate = abl; }
     int TM, full_rows, rest;                             // block rows of height TM + one of height rest
     og_row_plan(groups, tiles_n * nph, 0, &TM, &full_rows, &rest);
     const int tiles = (full_rows + (rest ? 1 : 0)) * tiles_n;
@@ -2055,7 +1761,7 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
             a.m_end = part == 0 ? (Cout < full_rows * TM * 32 ? Cout : full_rows * TM * 32) : Cout;
             // split K (pixels) so that this launch fills the resident workgroup slots once
             // (2 per CU for tall tiles, 3 up to TM = 4) without spilling into a second round
-            const int slots = 256 * (tm == 1 && og_v3() ? 6 : (tm <= 4 ? 3 : 2));   // LDS-free TM = 1: more waves
+            const int slots = 256 * (tm == 1 ? 6 : (tm <= 4 ? 3 : 2));   // LDS-free TM = 1: more waves
             int splits = slots / (rows * tiles_n);
             const int max_splits = og_cdiv(Npix, 512);       // >= 32 K steps per split
             if (splits > max_splits) splits = max_splits;
@@ -2067,12 +1773,9 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
             dim3 grid(rows * tiles_n, splits);
             ProfRec* pr = prof_begin(OG_CAT_WGRAD2(tm),
                                      2.0 * (a.m_end - a.m_begin) * (double)a.ncol * (double)Npix, s);
-            static int pmode = -1;
-            if (pmode < 0) { const char* e = getenv("OG_WGRAD_PM"); pmode = e ? atoi(e) : 1; }
-            const bool pm = pmode == 2;
-#define OG_WG2(TMv) if (og_v3() && TMv <= 2) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv>), grid, dim3(256), 0, s, a, ksize); \
-                    else if (pm) hipLaunchKernelGGL((conv_wgrad2_kernel<TMv, true>), grid, dim3(256), 0, s, a, ksize); \
-                    else hipLaunchKernelGGL((conv_wgrad2_kernel<TMv, false>), grid, dim3(256), 0, s, a, ksize);
+            // LDS-free register-fragment form for short tiles, LDS-staged form for tall ones
+#define OG_WG2(TMv) if (TMv <= 2) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv>), grid, dim3(256), 0, s, a, ksize); \
+                    else hipLaunchKernelGGL((conv_wgrad2_kernel<TMv>), grid, dim3(256), 0, s, a, ksize);
             switch (tm) {
                 case 1: OG_WG2(1) break;
                 case 2: OG_WG2(2) break;
