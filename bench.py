@@ -5,9 +5,10 @@
 
 A "step" is one full iteration of the reference's training loop (reference
 image_generation/trainer.py:357-472) on one synthetic COCO-shaped minibatch: three-stage G_NET
-forward at 256x256, the three patch and three shape discriminators, the two ROIAlign object
-discriminators, generator loss with DAMSM + KL, nine Adam updates and the generator EMA (and the
-per-step Inception-score monitor on a side stream, as in the reference).  Per-GPU batch 16; under
+forward at 256x256 (fed by the frozen caption encoder and GloVe lookup), the three patch and three
+shape discriminators, the two ROIAlign object discriminators, generator loss with DAMSM + KL, nine
+Adam updates and the generator EMA (and the per-step Inception-score monitor on a side stream, as in
+the reference).  Per-GPU batch 16; under
 `--gpus N` (launched by torch.distributed.run, one rank per GPU, RCCL) every rank steps its own
 batch and gradients are all-reduced: weak scaling, value = N * 16 * steps / time.
 
@@ -56,6 +57,12 @@ def build_trainer(device, batch_size, seed, with_is_monitor=True):
     class SynthDataset(object):
         num_classes = 80
     ds = SynthDataset()
+    import model as M
+    # frozen text front-end of the step (reference trainer.py:91-100, 63-73): caption encoder + GloVe table
+    ds.text_encoder = encoders.seeded_init_(M.RNN_ENCODER(1000, nhidden=cfg.TEXT.EMBEDDING_DIM), 2).to(device).eval()
+    ds.glove_embed = torch.nn.Embedding(401, cfg.TEXT.GLOVE_EMBEDDING_DIM).to(device).eval()
+    for p in list(ds.text_encoder.parameters()) + list(ds.glove_embed.parameters()):
+        p.requires_grad_(False)
     trunk = encoders.seeded_init_(encoders.inception_v3(), 1)
     ds.image_encoder = encoders.CNN_ENCODER(256, trunk).to(device).eval()
     for p in ds.image_encoder.parameters():
@@ -187,7 +194,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp32", "data": "synthetic",
-            "config": {"workload": "stage3_256x256_full_GD_step: G_NET(3 stages)+PatD x3+ShpD x3+"
+            "config": {"workload": "stage3_256x256_full_GD_step: RNN_ENCODER+G_NET(3 stages)+PatD x3+ShpD x3+"
                                    "ObjSSD+ObjLSD(ROIAlign)+DAMSM+KL+Adam x9+EMA"
                                    + ("" if args.no_is_monitor else "+IS-monitor"),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,

@@ -83,6 +83,15 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
                       int N, int Cin, int H, int W, int upsample, int pad_mode,
                       int Cout, int OH, int OW, int ksize, int stride, int pad, void* stream);
 
+/* ---- frozen text encoder (reference model.py:85-179 RNN_ENCODER: Embedding + bidirectional LSTM on
+ * a packed sequence).  table [ntoken][I]; captions [B][L] int64; lens [B] int32; wt_ih [2][I][4H] and
+ * wt_hh [2][H][4H] are the transposed weight_ih_l0(_reverse) / weight_hh_l0(_reverse); b_* [2][4H]
+ * (gate order i, f, g, o).  out [B][2H][Lout] = words_emb (zero past each length), hn [B][2H] = sent_emb. */
+int objgan_lstm_bidir_forward(const float* table, const long* captions, const int* lens,
+                              const float* wt_ih, const float* wt_hh, const float* b_ih, const float* b_hh,
+                              float* out, float* hn, int B, int L, int Lout, int I, int H, int ntoken,
+                              void* stream);
+
 /* ---- normalisation + GLU / LeakyReLU / residual (BatchNorm train mode, InstanceNorm) -------- */
 int objgan_norm_forward(const float* x, float* y, const float* residual,
                         const float* gamma, const float* beta,

@@ -18,8 +18,8 @@ gfx950 kernels of objgan_hip.ops instead:
   attention      GlobalAttention.py (fused kernels), masked max without 5-D temporaries
   object Ds      fused bilinear lift to 512^2, ROIAlign kernel, 4x4 conv with LeakyReLU epilogue
 
-The frozen encoders (RNN_ENCODER, CNN_ENCODER, INCEPTION_V3) are outside this hot-path scope
-(SURVEY.md section 8f); `encoders.py` holds plain-PyTorch stand-ins for them.
+RNN_ENCODER (frozen caption encoder) runs on its own fused LSTM kernel; the frozen image encoders
+(CNN_ENCODER, INCEPTION_V3) live in `encoders.py` with their convolutions on the same MFMA kernels.
 """
 import numpy as np
 import torch
@@ -158,6 +158,67 @@ class HmapResBlock(nn.Module):
 
     def forward(self, x):
         return self.block(x)
+
+
+# ---------------------------------------------------------------------------------------------
+# frozen text encoder
+# ---------------------------------------------------------------------------------------------
+class RNN_ENCODER(nn.Module):
+    """Bidirectional-LSTM caption encoder (reference model.py:85-179): same constructor arguments,
+    state-dict keys (`encoder.weight`, `rnn.weight_ih_l0`, `rnn.weight_hh_l0_reverse`, ...) and
+    `forward(captions, cap_lens, max_len) -> (words_emb [B, nhidden, max_len], sent_emb [B, nhidden])`.
+    nn.Embedding / nn.LSTM are parameter holders; the forward pass is one fused kernel per step
+    (objgan_lstm_bidir_forward).  The encoder is frozen on this path (trainer.py:97-100 of the
+    reference): forward only, eval-mode dropout (identity)."""
+
+    def __init__(self, ntoken, ninput=300, drop_prob=0.5, nhidden=128, nlayers=1, bidirectional=True):
+        super(RNN_ENCODER, self).__init__()
+        self.n_steps = cfg.TEXT.WORDS_NUM
+        self.ntoken = ntoken
+        self.ninput = ninput
+        self.drop_prob = drop_prob
+        self.nlayers = nlayers
+        self.bidirectional = bidirectional
+        self.rnn_type = cfg.RNN_TYPE
+        self.num_directions = 2 if bidirectional else 1
+        self.nhidden = nhidden // self.num_directions
+        if self.rnn_type != 'LSTM' or nlayers != 1 or not bidirectional:
+            raise NotImplementedError("the hot path uses the reference default: 1-layer bidirectional LSTM")
+        self.encoder = nn.Embedding(self.ntoken, self.ninput)
+        self.drop = nn.Dropout(self.drop_prob)
+        self.rnn = nn.LSTM(self.ninput, self.nhidden, self.nlayers, batch_first=True,
+                           dropout=self.drop_prob, bidirectional=self.bidirectional)
+        self.encoder.weight.data.uniform_(-0.1, 0.1)
+        self._packed = None
+
+    def init_hidden(self, bsz):
+        w = next(self.parameters()).data
+        z = w.new_zeros(self.nlayers * self.num_directions, bsz, self.nhidden)
+        return (z, z.clone())
+
+    def _weights(self):
+        """[2][I][4H] / [2][H][4H] transposed copies (consecutive gate outputs contiguous), rebuilt
+        when a weight tensor was replaced or edited."""
+        r = self.rnn
+        srcs = (r.weight_ih_l0, r.weight_ih_l0_reverse, r.weight_hh_l0, r.weight_hh_l0_reverse,
+                r.bias_ih_l0, r.bias_ih_l0_reverse, r.bias_hh_l0, r.bias_hh_l0_reverse)
+        key = tuple((t.data_ptr(), t._version) for t in srcs)
+        if self._packed is None or self._packed[0] != key:
+            with torch.no_grad():
+                wt_ih = torch.stack((srcs[0].t(), srcs[1].t())).contiguous()
+                wt_hh = torch.stack((srcs[2].t(), srcs[3].t())).contiguous()
+                b_ih = torch.stack((srcs[4], srcs[5])).contiguous()
+                b_hh = torch.stack((srcs[6], srcs[7])).contiguous()
+            self._packed = (key, wt_ih, wt_hh, b_ih, b_hh)
+        return self._packed[1:]
+
+    def forward(self, captions, cap_lens, max_len, mask=None):
+        if self.training and self.drop_prob > 0:
+            raise NotImplementedError("RNN_ENCODER is frozen on the training path: call .eval()")
+        wt_ih, wt_hh, b_ih, b_hh = self._weights()
+        words_emb, sent_emb = ops.lstm_bidir_forward(self.encoder.weight.detach(), captions, cap_lens,
+                                                     wt_ih, wt_hh, b_ih, b_hh, max_len)
+        return words_emb, sent_emb
 
 
 # ---------------------------------------------------------------------------------------------

@@ -637,6 +637,27 @@ def bilinear_resize(x, oh, ow):
 
 
 # ----------------------------------------------------------------------------------------------
+# frozen text encoder
+# ----------------------------------------------------------------------------------------------
+def lstm_bidir_forward(table, captions, lens, wt_ih, wt_hh, b_ih, b_hh, max_len):
+    """Embedding + bidirectional LSTM over packed captions -> (words_emb [B, 2H, max_len],
+    sent_emb [B, 2H]); forward only (the encoder is frozen on the training path)."""
+    _chk(table, wt_ih, wt_hh, b_ih, b_hh)
+    if not captions.is_cuda or captions.dtype != torch.int64:
+        raise _lib.ObjganHipError("lstm: captions must be an int64 tensor on the GPU")
+    captions = _c(captions)
+    lens = _c(lens.to(device=captions.device, dtype=torch.int32))
+    B, L = captions.shape
+    I, G = wt_ih.shape[1], wt_ih.shape[2]
+    H = G // 4
+    out = torch.empty((B, 2 * H, int(max_len)), dtype=_F32, device=captions.device)
+    hn = torch.empty((B, 2 * H), dtype=_F32, device=captions.device)
+    _lib.call("objgan_lstm_bidir_forward", _p(table), _p(captions), _p(lens), _p(wt_ih), _p(wt_hh),
+              _p(b_ih), _p(b_hh), _p(out), _p(hn), B, L, int(max_len), I, H, table.shape[0], _stream())
+    return out, hn
+
+
+# ----------------------------------------------------------------------------------------------
 # optimiser on flat arenas
 # ----------------------------------------------------------------------------------------------
 def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, n=None):

@@ -88,6 +88,8 @@ def make_batch(batch_size=16, seed=1234, num_classes=80, words_num=12, boxes_num
         "num_rois": torch.from_numpy(num_rois.astype(np.int64)),
         "bt_masks": bt_masks, "fm_bt_masks": fm_bt_masks,
         "captions": torch.from_numpy(captions), "cap_lens": cap_lens_t,
+        # GloVe vocabulary ids of the same words (reference trainDataset.py: glove_captions)
+        "glove_captions": torch.from_numpy(np.where(captions > 0, (captions * 7) % 400 + 1, 0)),
         "words_embs": words_embs, "sent_emb": sent_emb, "glove_words_embs": glove_words_embs,
         "mask": mask, "clabels_emb": clabels_emb,
         "class_ids": np.arange(B),

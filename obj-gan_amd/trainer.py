@@ -142,6 +142,7 @@ class condGANTrainer(object):
         self.text_encoder = getattr(dataset, "text_encoder", None)
         self.image_encoder = getattr(dataset, "image_encoder", None)
         self.inception_model = getattr(dataset, "inception_model", None)
+        self.glove_emb = getattr(dataset, "glove_embed", None)       # nn.Embedding(n, 50), frozen
         self.rank = dist.get_rank() if _dist_on() else 0
         self.world = dist.get_world_size() if _dist_on() else 1
         self.is_stream = torch.cuda.Stream(device=self.device) if self.inception_model is not None else None
@@ -231,12 +232,27 @@ class condGANTrainer(object):
         b = batch
         imgs, hmaps, rois = b["imgs"], b["hmaps"], b["rois"]
         fm_rois, num_rois = b["fm_rois"], b["num_rois"]
-        words_embs, sent_emb = b["words_embs"], b["sent_emb"]
         clabels_emb = b["clabels_emb"]
+        # (1) text-side inputs (reference trainer.py:367-380): frozen caption encoder and GloVe table
+        # when the dataset provides them; a batch may also carry precomputed embeddings (unit tests)
+        mask, glove_words_embs = b.get("mask"), b.get("glove_words_embs")
+        if self.text_encoder is not None and "captions" in b:
+            captions, cap_lens = b["captions"], b["cap_lens"]
+            max_len = int(b.get("max_len", captions.shape[1]))
+            with torch.no_grad():
+                words_embs, sent_emb = self.text_encoder(captions, cap_lens, max_len)
+            num_words = words_embs.size(2)
+            mask = (captions == 0)[:, :num_words]
+            if self.glove_emb is not None and "glove_captions" in b:
+                gc = b["glove_captions"]
+                with torch.no_grad():
+                    gw = torch.nn.functional.embedding(gc.reshape(-1), self.glove_emb.weight)
+                glove_words_embs = gw.view(gc.size(0), gc.size(1), -1)[:, :num_words].transpose(1, 2)
+        else:
+            words_embs, sent_emb = b["words_embs"], b["sent_emb"]
         inv_world = 1.0 / self.world
         out = {}
 
-        # (1) text-side inputs
         clabels_feat = form_clabels_feat(clabels_emb, rois[0], num_rois)
         # (2) generate fake images
         if noise is None:
@@ -244,7 +260,7 @@ class condGANTrainer(object):
             noise = self.noise
         glb_max_num_roi = int(torch.max(num_rois))
         fake_imgs, bt_c_codes, _, _, mu, logvar = self.netG(
-            noise, sent_emb, words_embs, b["glove_words_embs"], clabels_feat, b["mask"], hmaps, rois,
+            noise, sent_emb, words_embs, glove_words_embs, clabels_feat, mask, hmaps, rois,
             fm_rois, num_rois, b["bt_masks"], b["fm_bt_masks"], glb_max_num_roi)
         bt_c_codes = [c.detach() for c in bt_c_codes]
 

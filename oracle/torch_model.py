@@ -408,3 +408,35 @@ def train_step(sds, opts, ema, batch, image_encoder=None, use_obj=True, lr=2e-4)
     out.update(errG=total.detach(), kl=kl.detach(), fake_imgs=[f.detach() for f in fake])
     out.update({k: v.detach() for k, v in parts.items()})
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# frozen text encoder (reference model.py:85-179)
+# ---------------------------------------------------------------------------------------------
+def rnn_encoder_forward(sd, captions, cap_lens, max_len):
+    """RNN_ENCODER.forward restated with explicit LSTM cell loops: Embedding -> bidirectional LSTM over
+    the first cap_lens[b] words of each caption (packed-sequence semantics, reference model.py:152-161)
+    -> words_emb [B, 2H, max_len] zero past each length (:164-167, 139-146), sent_emb = final hidden
+    states of both directions concatenated (:169-175).  Gate order i, f, g, o (PyTorch nn.LSTM)."""
+    emb = sd["encoder.weight"][captions]                       # B x L x I   (eval: dropout = identity)
+    B, L, _ = emb.shape
+    H = sd["rnn.weight_hh_l0"].shape[1]
+    words = torch.zeros(B, 2 * H, max_len, dtype=emb.dtype)
+    sent = torch.zeros(B, 2 * H, dtype=emb.dtype)
+    for d, suffix in enumerate(("", "_reverse")):
+        w_ih, w_hh = sd["rnn.weight_ih_l0" + suffix], sd["rnn.weight_hh_l0" + suffix]
+        bias = sd["rnn.bias_ih_l0" + suffix] + sd["rnn.bias_hh_l0" + suffix]
+        for b in range(B):
+            n = int(cap_lens[b])
+            h = torch.zeros(H, dtype=emb.dtype)
+            c = torch.zeros(H, dtype=emb.dtype)
+            steps = range(n) if d == 0 else range(n - 1, -1, -1)
+            for t in steps:
+                g = w_ih @ emb[b, t] + w_hh @ h + bias
+                i, f, gg, o = g[:H].sigmoid(), g[H:2 * H].sigmoid(), g[2 * H:3 * H].tanh(), g[3 * H:].sigmoid()
+                c = f * c + i * gg
+                h = o * c.tanh()
+                if t < max_len:
+                    words[b, d * H:(d + 1) * H, t] = h
+            sent[b, d * H:(d + 1) * H] = h
+    return words, sent

@@ -29,6 +29,18 @@ def grad_summary(module):
     return {k: (p.grad.norm().item() if p.grad is not None else 0.0) for k, p in module.named_parameters()}
 
 
+def make_rnn_golden():
+    """Reference RNN_ENCODER (model.py:85-179) on the synthetic captions -> tests/golden/rnn_encoder_ref.pt"""
+    ref = rh.load_reference(branch_num=3, batch_size=4)
+    b = synth_batch.make_batch(4, seed=SEEDS["batch"])
+    enc = rh.seeded_state_(ref.model.RNN_ENCODER(1000, nhidden=256), 61, scale=None).eval()
+    with torch.no_grad():
+        words, sent = enc(b["captions"], b["cap_lens"], 12)
+    torch.save({"seed": 61, "B": 4, "ntoken": 1000, "words_emb": words.clone(), "sent_emb": sent.clone()},
+               os.path.join(HERE, "rnn_encoder_ref.pt"))
+    print("rnn golden", tuple(words.shape), tuple(sent.shape), float(words.abs().mean()))
+
+
 def main():
     torch.set_num_threads(8)
     ref = rh.load_reference(branch_num=3, batch_size=B)
@@ -136,4 +148,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--rnn" in sys.argv:
+        make_rnn_golden()
+    else:
+        main()
+        make_rnn_golden()

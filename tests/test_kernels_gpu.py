@@ -445,3 +445,31 @@ def test_packed_filter_cache_follows_weight_updates(dev):
     frozen.add_(1.0)
     y2 = ops.conv2d(x, frozen, None, 1, 1)
     assert rel_l2(y2, tr.conv2d(x.cpu(), frozen.cpu(), None, 1, 1)) < TOL and rel_l2(y1, y2) > 1e-2
+
+
+def test_rnn_encoder_matches_oracle_and_reference_golden(dev):
+    import os
+    import model as M
+    import synth_batch
+    from conftest import ROOT
+    from oracle import ref_harness as rh, torch_model as tm
+    gold = torch.load(os.path.join(ROOT, "tests", "golden", "rnn_encoder_ref.pt"))
+    b = synth_batch.make_batch(gold["B"], seed=1234)
+    enc = rh.seeded_state_(M.RNN_ENCODER(gold["ntoken"], nhidden=256), gold["seed"]).eval()
+    sd = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    enc.to(dev)
+    words, sent = enc(b["captions"].to(dev), b["cap_lens"].to(dev), 12)
+    torch.cuda.synchronize()
+    assert words.shape == (gold["B"], 256, 12) and sent.shape == (gold["B"], 256)
+    assert rel_l2(words, gold["words_emb"]) < 1e-5 and rel_l2(sent, gold["sent_emb"]) < 1e-5
+    # larger weights (saturating gates), ragged lengths, max_len shorter than the caption tensor
+    g = torch.Generator().manual_seed(5)
+    for k in sd:
+        sd[k] = sd[k] * (6.0 if "weight" in k and "encoder" not in k else 1.0)
+    enc.load_state_dict(sd)
+    caps = torch.randint(1, 1000, (5, 12), generator=g)
+    lens = torch.tensor([12, 9, 9, 4, 1])
+    w_want, s_want = tm.rnn_encoder_forward(sd, caps, lens, 10)
+    w_got, s_got = enc(caps.to(dev), lens.to(dev), 10)
+    assert rel_l2(w_got, w_want) < 1e-5 and rel_l2(s_got, s_want) < 1e-5
+    assert float(w_got[4, :, 1:].abs().sum()) == 0.0

@@ -269,3 +269,25 @@ def test_feat_select_and_permute_seg_host_logic():
     random.seed(5)
     s2, v2 = tm.permute_seg(b["hmaps"][0], b["rois"][0], b["num_rois"])
     assert v1 == v2 and torch.equal(s1, s2)
+
+
+def test_oracle_rnn_encoder_matches_reference_golden():
+    """oracle restatement of RNN_ENCODER.forward vs the output of the reference class itself
+    (tests/golden/rnn_encoder_ref.pt, written by make_golden.py --rnn)."""
+    from oracle import torch_model as tm
+    from oracle import ref_harness as rh
+    import model as M
+    import synth_batch
+    gold = torch.load(os.path.join(ROOT, "tests", "golden", "rnn_encoder_ref.pt"))
+    b = synth_batch.make_batch(gold["B"], seed=1234)
+    enc = rh.seeded_state_(M.RNN_ENCODER(gold["ntoken"], nhidden=256), gold["seed"])
+    sd = {k: v.detach() for k, v in enc.state_dict().items()}
+    assert set(sd) == {"encoder.weight", "rnn.weight_ih_l0", "rnn.weight_hh_l0", "rnn.bias_ih_l0",
+                       "rnn.bias_hh_l0", "rnn.weight_ih_l0_reverse", "rnn.weight_hh_l0_reverse",
+                       "rnn.bias_ih_l0_reverse", "rnn.bias_hh_l0_reverse"}
+    words, sent = tm.rnn_encoder_forward(sd, b["captions"], b["cap_lens"], 12)
+    assert rel_l2(words, gold["words_emb"]) < 1e-5
+    assert rel_l2(sent, gold["sent_emb"]) < 1e-5
+    lens = b["cap_lens"].tolist()
+    for i, n in enumerate(lens):
+        assert float(words[i, :, n:].abs().sum()) == 0.0
