@@ -132,13 +132,6 @@ def _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad_h, pad_w, LH, LW):
     return dx
 
 
-def _pad_taps(dh, dw, st):
-    """(kept for callers) the GEMM accepts any tap count up to 32: nothing to pad."""
-    if len(dh) > 32:
-        raise _lib.ObjganHipError("more than 32 taps")
-    return dh, dw, st
-
-
 def conv_out_size(L, k, s, p):
     return (L + 2 * p - k) // s + 1
 
@@ -228,7 +221,6 @@ class _Conv2dFn(torch.autograd.Function):
                         st = [kh * k + kw for kh in khs for kw in kws]
                         if not st:      # no tap reaches this phase: gradient is zero there
                             dh, dw, st = [0], [0], [-1]
-                        dh, dw, st = _pad_taps(dh, dw, st)
                         _igemm(g, w, None, dxl, N, Cout, OH, OW, 0, 0, Cout, Cin, k * k, 1,
                                dh, dw, st, PHg, PWg, 1, LH, LW, 2, 2, ph, pw, 0, y_prezeroed=1)
             else:

@@ -264,32 +264,33 @@ class condGANTrainer(object):
             fm_rois, num_rois, b["bt_masks"], b["fm_bt_masks"], glb_max_num_roi)
         bt_c_codes = [c.detach() for c in bt_c_codes]
 
-        pending = []
-        # (3-1) patch discriminators
+        # (3) the eight discriminator updates (reference trainer.py:398-443).  They are independent of
+        # each other (own weights, the real batch, the detached fake images); issuing them on separate
+        # HIP streams was measured and bought nothing (the step is MFMA-bound, 317.5 vs 319.6 ms), so
+        # they run in the reference's order on the current stream.
+        jobs = []
         for i, opt in enumerate(self.optimizersPatD):
-            opt.zero_grad()
-            err = patD_loss(self.netsPatD[i], imgs[i], fake_imgs[i], sent_emb)
-            err.backward()
-            pending.append((opt, self._reduce_async(opt), True))
-            out["errPatD%d" % i] = err.detach()
-        # (3-2) shape discriminators
+            jobs.append(("errPatD%d" % i, opt,
+                         lambda i=i: patD_loss(self.netsPatD[i], imgs[i], fake_imgs[i], sent_emb)))
         for i, opt in enumerate(self.optimizersShpD):
-            opt.zero_grad()
-            err = shpD_loss(self.netsShpD[i], imgs[i], fake_imgs[i], hmaps[i], rois[i], num_rois)
-            err.backward()
-            pending.append((opt, self._reduce_async(opt), True))
-            out["errShpD%d" % i] = err.detach()
-        # (3-3/3-4) object discriminators; the reference updates only `if float(err) > 0`, i.e.
-        # when at least one box of the wanted scale exists (BCE of a sigmoid is > 0 otherwise)
+            jobs.append(("errShpD%d" % i, opt,
+                         lambda i=i: shpD_loss(self.netsShpD[i], imgs[i], fake_imgs[i], hmaps[i], rois[i], num_rois)))
+        # the reference updates an object discriminator only `if float(err) > 0`, i.e. when at least one
+        # box of the wanted scale exists (BCE of a sigmoid is > 0 otherwise)
         for name, net, opt, r, large in (("errObjSSD", self.netObjSSD, self.optimizerObjSSD, rois[0], False),
                                           ("errObjLSD", self.netObjLSD, self.optimizerObjLSD, fm_rois, True)):
+            jobs.append((name, opt,
+                         lambda net=net, r=r, large=large: objD_loss(net, imgs[-1], fake_imgs[-1], hmaps[-1],
+                                                                     clabels_emb, bt_c_codes[-1], r, num_rois,
+                                                                     is_large_scale=large)))
+        pending = []
+        for name, opt, loss_fn in jobs:
             opt.zero_grad()
-            err = objD_loss(net, imgs[-1], fake_imgs[-1], hmaps[-1], clabels_emb, bt_c_codes[-1], r,
-                            num_rois, is_large_scale=large)
+            err = loss_fn()
             active = torch.is_tensor(err)
             if active:
                 err.backward()
-                opt.arena.grad[-1] = 1.0            # "this rank has a gradient" flag
+                opt.arena.grad[-1] = 1.0             # "this rank has a gradient" flag
                 out[name] = err.detach()
             pending.append((opt, self._reduce_async(opt), active))
 
