@@ -99,6 +99,10 @@ int objgan_norm_forward(const float* x, float* y, const float* residual,
                         float* sums, float* mean, float* rstd,
                         int N, int C, int HW, int per_channel, int mode,
                         float eps, float momentum, void* stream);
+/* apply with given statistics (eval-mode BatchNorm: mean = running_mean, rstd = 1/sqrt(running_var+eps)) */
+int objgan_norm_apply(const float* x, float* y, const float* residual, const float* gamma, const float* beta,
+                      const float* mean, const float* rstd, int N, int C, int HW, int per_channel, int mode,
+                      void* stream);
 int objgan_norm_backward(const float* x, const float* dy, const float* mean, const float* rstd,
                          const float* gamma, const float* beta, float* bsums,
                          float* dx, float* dgamma, float* dbeta,

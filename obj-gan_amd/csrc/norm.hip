@@ -487,6 +487,32 @@ int objgan_norm_forward(const float* x, float* y, const float* residual,
     return og_launch_status();
 }
 
+// Apply only, with given statistics (eval-mode BatchNorm: running_mean / 1/sqrt(running_var + eps) --
+// generator sampling with the EMA weights, reference evaluator.py; trainer.save_img_results).
+int objgan_norm_apply(const float* x, float* y, const float* residual, const float* gamma, const float* beta,
+                      const float* mean, const float* rstd, int N, int C, int HW, int per_channel, int mode,
+                      void* stream) {
+    if (mode == OG_NORM_GLU && (C & 1)) return OG_BAD_ARGS;
+    if (N <= 0 || C <= 0 || HW <= 0) return OG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    NormGeom gm{N, C, HW, per_channel};
+    const int Co = mode == OG_NORM_GLU ? C / 2 : C;
+    if ((HW % 4 == 0) && HW >= 256 && (long)N * C < 2000000) {
+        dim3 grid(N * Co, og_cdiv(HW, OG_NORM_CHUNK));
+        if (mode == OG_NORM_GLU)
+            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_GLU>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm);
+        else if (mode == OG_NORM_LRELU)
+            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_LRELU>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm);
+        else
+            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_NONE>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm);
+        return og_launch_status();
+    }
+    const long total = (long)N * Co * HW;
+    hipLaunchKernelGGL(norm_apply_kernel, dim3(og_stream_grid(total, 256)), dim3(256), 0, s, x, mean,
+                       rstd, gamma, beta, residual, y, gm, mode);
+    return og_launch_status();
+}
+
 // Backward.  dy has the shape of y (C/2 channels for GLU).  bsums [2G] workspace (zeroed
 // here).  dgamma/dbeta may be null.  (The residual gradient is dy itself.)
 int objgan_norm_backward(const float* x, const float* dy, const float* mean, const float* rstd,

@@ -37,9 +37,10 @@ from objgan_hip import ops
 # small helpers shared by the blocks
 # ---------------------------------------------------------------------------------------------
 def _bn_act(x, bn, mode):
-    """BatchNorm (train: batch statistics + running-stat update) fused with GLU / LeakyReLU."""
+    """BatchNorm fused with GLU / LeakyReLU: batch statistics + running-stat update in train mode,
+    running statistics (forward only) in eval mode -- sampling with the EMA generator."""
     if not bn.training:
-        raise NotImplementedError("eval-mode BatchNorm is not part of the training hot path")
+        return ops.norm_act_eval(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, mode=mode, eps=bn.eps)
     if bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     return ops.norm_act(x, bn.weight, bn.bias, None, bn.running_mean, bn.running_var,

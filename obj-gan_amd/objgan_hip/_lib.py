@@ -36,6 +36,7 @@ SIGNATURES = {
                                   _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_norm_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                             _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _ptr],
+    "objgan_norm_apply": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_norm_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                              _c_int, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_act_backward": [_ptr, _ptr, _ptr, _c_long, _c_int, _ptr],

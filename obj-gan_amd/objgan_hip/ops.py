@@ -380,6 +380,23 @@ def norm_act(x, gamma=None, beta=None, residual=None, running_mean=None, running
                             eps, momentum)
 
 
+def norm_act_eval(x, gamma, beta, running_mean, running_var, mode=None, eps=1e-5):
+    """Eval-mode BatchNorm (running statistics) fused with GLU / LeakyReLU: forward only (generator
+    sampling with the EMA weights)."""
+    _chk(x, gamma, beta, running_mean, running_var)
+    if x.requires_grad and torch.is_grad_enabled():
+        raise _lib.ObjganHipError("eval-mode BatchNorm is forward-only: wrap the call in torch.no_grad()")
+    x = _c(x)
+    N, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * C) if x.numel() else 0
+    Co = C // 2 if mode == "glu" else C
+    y = torch.empty((N, Co) + tuple(x.shape[2:]), dtype=_F32, device=x.device)
+    rstd = torch.rsqrt(running_var + eps)
+    _lib.call("objgan_norm_apply", _p(x), _p(y), None, _p(gamma), _p(beta), _p(running_mean), _p(rstd),
+              N, C, HW, 1, _NORM_MODE[mode], _stream())
+    return y
+
+
 # ----------------------------------------------------------------------------------------------
 # attention
 # ----------------------------------------------------------------------------------------------

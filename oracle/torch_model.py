@@ -29,8 +29,30 @@ def _sub(sd, prefix):
     return {k[n:]: v for k, v in sd.items() if k.startswith(prefix)}
 
 
+_BN_EVAL = [False]
+
+
+class bn_eval(object):
+    """with bn_eval(): BatchNorm layers use their running statistics (module.eval() semantics)."""
+
+    def __enter__(self):
+        _BN_EVAL[0] = True
+
+    def __exit__(self, *exc):
+        _BN_EVAL[0] = False
+
+
 def _bn(x, sd, p, mode):
-    """BatchNorm in train mode (batch statistics, running stats updated in place) + activation."""
+    """BatchNorm in train mode (batch statistics, running stats updated in place) + activation;
+    under bn_eval(): running statistics."""
+    if _BN_EVAL[0]:
+        shape = x.shape
+        y = torch.nn.functional.batch_norm(x.reshape(shape[0], shape[1], -1), sd[p + "running_mean"],
+                                           sd[p + "running_var"], sd[p + "weight"], sd[p + "bias"], False,
+                                           0.0, 1e-5).reshape(shape)
+        if mode == "glu":
+            return T.glu(y)
+        return torch.nn.functional.leaky_relu(y, 0.2) if mode == "lrelu" else y
     if sd.get(p + "num_batches_tracked") is not None:
         sd[p + "num_batches_tracked"] += 1
     return T.norm_act(x, sd[p + "weight"], sd[p + "bias"], None, sd[p + "running_mean"],
