@@ -37,6 +37,7 @@ import torch                                    # noqa: E402
 import torch.distributed as dist                # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3                   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0                  # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
 # timing categories of the library = kernel instances, named as rocprofv3 prints them
 CAT_NAMES = (["conv_igemm3_kernel<%d, false>" % tm for tm in range(1, 8)] +
              ["conv_wgrad2_kernel<%d>" % tm for tm in range(1, 8)] +
@@ -144,6 +145,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-is-monitor", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--math", choices=("fp32", "bf16"), default="fp32",
+                    help="fp32: exact fp32 MFMA (headline, parity path); bf16: mixed precision of BASELINE "
+                         "config 5 (bf16 matrix-core inputs, fp32 accumulation / storage / norms / optimizer)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -158,7 +162,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=device)
 
     import synth_batch
-    from objgan_hip import _lib
+    from objgan_hip import _lib, ops
+    ops.set_conv_math(args.math)
     tr = build_trainer(device, args.batch, seed=1234, with_is_monitor=not args.no_is_monitor)
     batch = synth_batch.make_batch(args.batch, seed=1234 + rank, device=device)   # per-rank data shard
 
@@ -193,7 +198,8 @@ def main():
             "value": round(n_img / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp32", "data": "synthetic",
+            "dtype": "fp32" if args.math == "fp32" else "bf16-in/fp32-acc (mixed precision, config 5)",
+            "data": "synthetic",
             "config": {"workload": "stage3_256x256_full_GD_step: RNN_ENCODER+G_NET(3 stages)+PatD x3+ShpD x3+"
                                    "ObjSSD+ObjLSD(ROIAlign)+DAMSM+KL+Adam x9+EMA"
                                    + ("" if args.no_is_monitor else "+IS-monitor"),
@@ -217,9 +223,10 @@ def main():
                         traffic = ent["hbm_bytes_per_launch"] if ent else None
                     except (ValueError, KeyError, OSError):
                         traffic = None
+                peak = FP32_MFMA_PEAK_TFLOPS if args.math == "fp32" else BF16_MFMA_PEAK_TFLOPS
                 res["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2),
-                                   "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                                   "peak": peak, "unit": "TFLOP/s",
+                                   "frac": round(ach / peak, 4), "traffic": traffic if args.math == "fp32" else None,
                                    "algorithmic_gflop_per_launch": round(tfl / n / 1e9, 2),
                                    "launches": int(n), "avg_launch_ms": round(tms / n, 4),
                                    "share_of_step": round(tms / (1000.0 * dt), 4)}

@@ -54,6 +54,9 @@ int objgan_avgpool2s1_backward(const float* grad_out, float* grad_in, long plane
 
 /* ---- implicit-GEMM convolution on MFMA (reference model.py conv stacks, via cuDNN) ---------- */
 long objgan_conv_packed_floats(int M, int C, int T);
+/* layout class (0..3) of the packed bank objgan_conv_igemm uses for these arguments: part of the key of
+ * any caller-side bank cache (the same filter is served by different kernels at different sizes) */
+int objgan_conv_bank_layout(int N, int C, int H, int W, int M, int Tg, int PH, int PW, int act, int math);
 /* y[n,m,a*osh+ooh,b*osw+oow] = act(bias[m] + sum_{c,t} Wp[m][c*Tg+t] * x[n,c,a*s+dh[t],b*s+dw[t]])
  * for (a,b) in PH x PW.  w: [Cout][Cin][Torig]; transpose=0 -> m=cout,c=cin; 1 -> m=cin,c=cout.
  * src_tap[t]: which of the Torig taps GEMM tap t uses (-1 = zero).  1 <= Tg <= 32.
@@ -62,14 +65,17 @@ long objgan_conv_packed_floats(int M, int C, int T);
  * objgan_conv_packed_floats(M, C, Tg) floats.  y_prezeroed=1 tells the library that y already
  * holds zeros (lets partial-coverage launches, i.e. stride-2 dgrad phases, use split-K).
  * wt_packed=1: wt still holds the packed bank written by an earlier call with the same w, taps,
- * transpose flag and input size class (the caller caches it while w is unchanged); 0: pack now. */
+ * transpose flag, math and input size class (the caller caches it while w is unchanged); 0: pack now.
+ * math: 0 = fp32 MFMA (exact fp32 fmaf chains); 1 = mixed precision (BASELINE config 5): operands rounded
+ * to bf16 (RNE) at the matrix-core inputs, fp32 accumulation, fp32 tensors in HBM.  Outputs with <= 32
+ * channels always run on the fp32 VALU kernels. */
 int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* y, float* wt,
                       int N, int C, int H, int W, int upsample, int pad_mode,
                       int Cout, int Cin, int Torig, int transpose,
                       int Tg, const int* dh, const int* dw, const int* src_tap,
                       int PH, int PW, int stride,
                       int OHf, int OWf, int osh, int osw, int ooh, int oow,
-                      int act, int y_prezeroed, int wt_packed, void* stream);
+                      int act, int y_prezeroed, int wt_packed, int math, void* stream);
 /* Data gradient of a stride-2 convolution whose four output parity phases have the same number
  * of taps (k=4, pad 1, even sizes): one launch for all phases.  x = dY [N,Cout,OH,OW],
  * y = dX [N,Cin,2*PH,2*PW], fully written (no pre-zeroing).  dh/dw/src_tap: 4 x Tg entries, phase
@@ -77,11 +83,11 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
 int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float* wt,
                                 int N, int Cout, int OH, int OW, int Cin, int Torig,
                                 int Tg, const int* dh, const int* dw, const int* src_tap,
-                                int PH, int PW, int wt_packed, void* stream);
+                                int PH, int PW, int wt_packed, int math, void* stream);
 /* dw[co][ci][kh][kw] += sum dy * x (dw zero-filled / accumulated by the caller); ksize in {1,3,4} */
 int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
                       int N, int Cin, int H, int W, int upsample, int pad_mode,
-                      int Cout, int OH, int OW, int ksize, int stride, int pad, void* stream);
+                      int Cout, int OH, int OW, int ksize, int stride, int pad, int math, void* stream);
 
 /* ---- frozen text encoder (reference model.py:85-179 RNN_ENCODER: Embedding + bidirectional LSTM on
  * a packed sequence).  table [ntoken][I]; captions [B][L] int64; lens [B] int32; wt_ih [2][I][4H] and

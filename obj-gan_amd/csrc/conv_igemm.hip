@@ -36,6 +36,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define OG_MAX_TAPS 32
 #define OG_ACT_NONE 0
@@ -52,6 +53,8 @@ struct IgemmArgs {
     int N, C, H, W;      // physical source dims
     int LH, LW;          // logical source dims seen by the taps (2H x 2W when upsampling)
     int M, Mpad, K, Kpad;   // K = T*C (algorithmic), Kpad = T*Cp (padded, what the loop walks)
+    int math;               // 0: fp32 MFMA, 1: bf16 inputs (RNE) on the bf16 MFMA, fp32 accumulation
+    int Krow;               // row pitch of the [M][Krow] bank in elements (= Kpad; bf16 bank: Kpad rounded up to 32)
     int T, Cp;              // taps, channels rounded up to 16
     int m_begin, m_end;  // output-channel rows covered by this launch
     int PH, PW;          // GEMM pixel grid per image
@@ -491,29 +494,33 @@ struct PackArgs {
     int transpose;
     int m_major;         // 0: wt[K][Mpad] (v1 kernels), 1: wt[M][Kpad] (k contiguous, v2 kernel),
                          // 2: wt[Ck][Tg][Mpad] with Mpad = MT (thin direct kernel)
+                         // 3: bf16 wt[M][Krow], Krow = Kpad rounded up to 32 (bf16 MFMA kernels)
     signed char src_tap[OG_MAX_TAPS];
 };
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
     const int Kpad = a.Tg * a.Cp;
+    const int Krow = a.m_major == 3 ? (Kpad + 31) / 32 * 32 : Kpad;
     const long total = a.m_major == 2 ? (long)(a.Ck + 1) * a.Tg * a.Mpad   // + one zero channel
-                                      : (a.m_major ? (long)a.M * Kpad : (long)Kpad * a.Mpad);
+                                      : (a.m_major ? (long)a.M * Krow : (long)Kpad * a.Mpad);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long)gridDim.x * blockDim.x) {
         int m, t, ck;
+        bool pad = false;
         if (a.m_major == 2) {
             m = (int)(i % a.Mpad);
             const int r = (int)(i / a.Mpad);
             t = r % a.Tg;
             ck = r / a.Tg;
         } else {
-            m = a.m_major ? (int)(i / Kpad) : (int)(i % a.Mpad);
-            const int k = a.m_major ? (int)(i % Kpad) : (int)(i / a.Mpad);
-            t = k / a.Cp;
+            m = a.m_major ? (int)(i / Krow) : (int)(i % a.Mpad);
+            const int k = a.m_major ? (int)(i % Krow) : (int)(i / a.Mpad);
+            pad = k >= Kpad;
+            t = pad ? 0 : k / a.Cp;
             ck = k - t * a.Cp;
         }
         float v = 0.f;
-        if (m < a.M && ck < a.Ck) {
+        if (!pad && m < a.M && ck < a.Ck) {
             const int st = a.src_tap[t];
             if (st >= 0) {
                 const int co = a.transpose ? ck : m;
@@ -521,7 +528,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
                 v = a.w[((size_t)co * a.Cin + ci) * a.Torig + st];
             }
         }
-        a.wt[i] = v;
+        if (a.m_major == 3) reinterpret_cast<__bf16*>(a.wt)[i] = (__bf16)v;
+        else a.wt[i] = v;
     }
 }
 
@@ -551,6 +559,7 @@ struct WgradArgs {
     int m_begin, m_end;
     int ncol;
     int pix_per_split;
+    int math;          // 0 fp32, 1 bf16 inputs
 };
 
 template <int KS, int WM, int TM>
@@ -706,7 +715,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 // SCALAR (n, oh, ow0 .. ow0+7), the per-lane part is the column's (ci, kh, kw) -- dy rows are read
 // as aligned 16-byte pieces with a constant per-lane offset, x elements as dwords whose validity
 // (zero padding) rides on the buffer range check.
-template <int TM>
+template <int TM, bool BF = false>
 __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, const int KS) {
     constexpr int BM = 32 * TM;
     constexpr int BN = 128;
@@ -853,16 +862,29 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
             a0[i] = *reinterpret_cast<const f32x4*>(Tl + a_rd + i * 32 * LD);
             a1[i] = *reinterpret_cast<const f32x4*>(Tl + a_rd + i * 32 * LD + 4);
         }
+        if (BF) {           // bf16 inputs (RNE of the fp32 tiles), one 32x32x16 MFMA per row group and K step
+            bf16x8 bq;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+            for (int j = 0; j < 4; ++j) { bq[j] = (__bf16)b0[j]; bq[4 + j] = (__bf16)b1[j]; }
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][kk], b0[kk], acc[i], 0, 0, 0);
+            for (int i = 0; i < TM; ++i) {
+                bf16x8 aq;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+                for (int j = 0; j < 4; ++j) { aq[j] = (__bf16)a0[i][j]; aq[4 + j] = (__bf16)a1[i][j]; }
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, bq, acc[i], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][kk], b1[kk], acc[i], 0, 0, 0);
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][kk], b0[kk], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][kk], b1[kk], acc[i], 0, 0, 0);
+        }
         __syncthreads();
         cur ^= 1;
     }
@@ -887,7 +909,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
 // dy), which all four waves share, is staged through LDS -- and for TM = 1 (thin outputs) it is read
 // straight from L1/L2 as two 16-byte loads per lane, so those launches run without LDS and without
 // barriers at all: waves are independent and latency is hidden by occupancy.
-template <int TM, bool ADIRECT = false>
+template <int TM, bool ADIRECT = false, bool BF = false>
 __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
     constexpr int BM = 32 * TM;
     constexpr int BN = 128;
@@ -897,6 +919,12 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
     constexpr int NA_PER = (NA4 + 255) / 256;
     constexpr int TILE = BM * LD;
     constexpr bool ALDS = !(ADIRECT && TM == 1);      // row operand through LDS (shared by 4 waves)
+    // BF: bf16 inputs (round-to-nearest-even of the fp32 operands) on v_mfma_f32_32x32x16_bf16, fp32
+    // accumulation.  One loop iteration then covers 32 k (two 16-channel gathers, two MFMAs per row
+    // group); the bank is bf16 [M][Krow], so a row piece is again 64 bytes per iteration and the
+    // LDS image / fragment reads keep their 80-byte pitch.
+    constexpr int ESZ = BF ? 2 : 4;
+    constexpr int NB = BF ? 16 : 8;                   // gathered pixel-operand values per lane and iteration
 
     __shared__ __attribute__((aligned(16))) float lds[ALDS ? 2 * TILE : 4];
 
@@ -922,7 +950,8 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
     __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
         (void*)a.x, 0, (int)((unsigned)a.N * a.C * HW * 4u), OG_BUF_FLAGS);
     __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.wt + (size_t)phase * a.M * a.Kpad), 0, (int)((unsigned)a.M * a.Kpad * 4u), OG_BUF_FLAGS);
+        (void*)((const char*)a.wt + (size_t)phase * a.M * a.Krow * ESZ), 0,
+        (int)((unsigned)a.M * a.Krow * (unsigned)ESZ), OG_BUF_FLAGS);
 
     // ---- pixel operand: this lane's pixel and k half
     const int pix = n0 + wid * 32 + lcol;
@@ -961,7 +990,7 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
     const int spt = a.Cp / BK;
     // channels past C (padding of the last 16-channel chunk) read finite neighbouring data or the
     // range-check zero; their filter entries are zero
-    auto load_b = [&](float (&rb)[8]) {
+    auto load_b8 = [&](float* rb) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, bvoff, (cb_ld + i) * HW * 4, 0));
@@ -971,6 +1000,10 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
             t_ld += 1;
             if (t_ld < a.T) tap_geometry(t_ld);
         }
+    };
+    auto load_b = [&](float (&rb)[NB]) {
+        load_b8(&rb[0]);
+        if (BF) load_b8(&rb[NB - 8]);      // second 16-channel chunk (past the last one: zero filter entries)
     };
 
     // ---- row operand (filter bank [M][Kpad])
@@ -982,11 +1015,12 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
             const int idx = tid + 256 * i;
             const int row = idx >> 2, q = idx & 3;
             const bool on = (NA4 % 256 == 0 || idx < NA4) && (m0 + row) < a.m_end;
-            avoff[i] = on ? ((unsigned)(m0 + row) * (unsigned)a.Kpad + q * 4u) * 4u : OG_OOB;
+            avoff[i] = on ? (unsigned)(m0 + row) * (unsigned)a.Krow * (unsigned)ESZ + q * 16u : OG_OOB;
             alds[i] = (NA4 % 256 == 0 || idx < NA4) ? row * LD + q * 4 : -1;
         }
     }
-    const unsigned adir = (m0 + lcol) < a.m_end ? ((unsigned)(m0 + lcol) * (unsigned)a.Kpad + lrow * 8u) * 4u : OG_OOB;
+    const unsigned adir = (m0 + lcol) < a.m_end
+        ? (unsigned)(m0 + lcol) * (unsigned)a.Krow * (unsigned)ESZ + lrow * (BF ? 16u : 32u) : OG_OOB;
     f32x4 ra[NA_PER];
     auto load_a = [&](int kt) {
 #pragma unroll
@@ -1000,12 +1034,15 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
             if (NA4 % 256 == 0 || alds[i] >= 0) *reinterpret_cast<f32x4*>(As + alds[i]) = ra[i];
     };
 
-    const int nk_all = a.Kpad / BK;
+    const int nk_all = BF ? a.Krow / 32 : a.Kpad / BK;
     const int kt0 = a.ksplit_steps > 0 ? blockIdx.y * a.ksplit_steps : 0;
     const int nk = a.ksplit_steps > 0 ? min(nk_all, kt0 + a.ksplit_steps) : nk_all;
-    t_ld = kt0 / spt;
-    cb_ld = (kt0 - t_ld * spt) * BK;
-    tap_geometry(t_ld);
+    {
+        const int sub0 = BF ? 2 * kt0 : kt0;            // first 16-channel chunk of this block
+        t_ld = sub0 / spt;
+        cb_ld = (sub0 - t_ld * spt) * BK;
+    }
+    tap_geometry(min(t_ld, a.T - 1));
 
     f32x16 acc[TM];
 #pragma unroll
@@ -1014,13 +1051,38 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     const int a_rd = lcol * LD + lrow * 8;
-    float rb0[8], rb1[8];
+    float rb0[NB], rb1[NB];
     f32x4 ad0[2], ad1[2];                              // TM == 1: direct row fragments (ping-pong)
     auto load_adir = [&](f32x4 (&ad)[2], int kt) {
         ad[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, adir, kt * (BK * 4), 0));
-        ad[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, adir + 16u, kt * (BK * 4), 0));
+        ad[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, adir + (BF ? 32u : 16u), kt * (BK * 4), 0));
     };
-    auto mma = [&](const float (&rb)[8], const f32x4 (&ad)[2], int cur) {
+    auto mma = [&](const float (&rb)[NB], const f32x4 (&ad)[2], int cur) {
+        if (BF) {
+            bf16x8 bq[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bq[h][j] = (__bf16)rb[(NB - 8) * h + j];
+            if (ALDS) {
+                const float* T = lds + cur * TILE;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    bf16x8 aq[TM];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        aq[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(T + lcol * LD + h * 8 + lrow * 4 + i * 32 * LD));
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[i], bq[h], acc[i], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ad[h]), bq[h], acc[0], 0, 0, 0);
+            }
+            return;
+        }
         if (ALDS) {
             const float* T = lds + cur * TILE;
             f32x4 a0[TM], a1[TM];
@@ -1071,7 +1133,7 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
         if (ALDS) __syncthreads();
         cur ^= 1;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) rb0[i] = rb1[i];
+        for (int i = 0; i < NB; ++i) rb0[i] = rb1[i];
         if (!ALDS) { ad0[0] = ad1[0]; ad0[1] = ad1[1]; }
     }
 
@@ -1110,7 +1172,7 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
 // Weight gradient on the v3 scheme: the gathered-x fragment goes straight to registers (lane =
 // (column l & 31 of the wave, pixel half l >> 5)), dy rows through LDS (TM > 1) or direct (TM = 1).
 // Requires OW % 8 == 0 and (OH*OW) % 16 == 0 like v2.
-template <int TM>
+template <int TM, bool BF = false>
 __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, const int KS) {
     constexpr int BM = 32 * TM;
     constexpr int BN = 128;
@@ -1267,6 +1329,27 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, con
     float rb0[8], rb1[8];
     f32x4 ad0[2], ad1[2];
     auto mma = [&](const float (&rb)[8], const f32x4 (&ad)[2], int cur) {
+        if (BF) {
+            bf16x8 bq;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bq[j] = (__bf16)rb[j];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                f32x4 x0, x1;
+                if (ALDS) {
+                    const float* Tl = lds + cur * TILE;
+                    x0 = *reinterpret_cast<const f32x4*>(Tl + a_rd + i * 32 * LD);
+                    x1 = *reinterpret_cast<const f32x4*>(Tl + a_rd + i * 32 * LD + 4);
+                } else {
+                    x0 = ad[0]; x1 = ad[1];
+                }
+                bf16x8 aq;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { aq[j] = (__bf16)x0[j]; aq[4 + j] = (__bf16)x1[j]; }
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, bq, acc[i], 0, 0, 0);
+            }
+            return;
+        }
         if (ALDS) {
             const float* Tl = lds + cur * TILE;
             f32x4 a0[TM], a1[TM];
@@ -1488,6 +1571,7 @@ static void og_row_plan(int groups, int tiles_n, int tall, int* TM_out, int* ful
     *TM_out = bt; *full_rows_out = groups / bt; *rest_out = groups - (groups / bt) * bt;
 }
 
+static int og_trace();
 static int og_nothin() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("OG_NO_THIN"); v = (e && e[0] == '1') ? 1 : 0; }
@@ -1496,6 +1580,7 @@ static int og_nothin() {
 
 static int run_thin(IgemmArgs a, int MT, hipStream_t s) {
     const long Npix = (long)a.N * a.PH * a.PW;
+    if (og_trace()) fprintf(stderr, "OGTRACE thin MT=%d M=%d C=%d T=%d Npix=%ld\n", MT, a.M, a.C, a.T, Npix);
     bool canon = a.T == 9 && a.stride == 1 && a.osh == 1 && a.osw == 1 && a.ooh == 0 && a.oow == 0
                  && a.PH == a.OHf && a.PW == a.OWf && a.PH == a.LH && a.PW == a.LW;
     for (int t = 0; canon && t < 9; ++t)
@@ -1543,6 +1628,20 @@ static int launch_igemm2(const IgemmArgs& a, int TM, dim3 grid, hipStream_t s) {
     if (og_trace())
         fprintf(stderr, "OGTRACE igemm TM=%d M=%d rows=%d C=%d T=%d Npix=%d grid=%u,%u,%u H=%d W=%d stride=%d\n", TM, a.M,
                 a.m_end - a.m_begin, a.C, a.T, a.N * a.PH * a.PW, grid.x, grid.y, grid.z, a.H, a.W, a.stride);
+    if (a.math == 1) {
+        switch (TM) {
+            case 1: if (a.M <= 32) hipLaunchKernelGGL((conv_igemm3_kernel<1, true, true>), grid, dim3(256), 0, s, a);
+                    else hipLaunchKernelGGL((conv_igemm3_kernel<1, false, true>), grid, dim3(256), 0, s, a);
+                    break;
+            case 2: hipLaunchKernelGGL((conv_igemm3_kernel<2, false, true>), grid, dim3(256), 0, s, a); break;
+            case 3: hipLaunchKernelGGL((conv_igemm3_kernel<3, false, true>), grid, dim3(256), 0, s, a); break;
+            case 4: hipLaunchKernelGGL((conv_igemm3_kernel<4, false, true>), grid, dim3(256), 0, s, a); break;
+            case 5: hipLaunchKernelGGL((conv_igemm3_kernel<5, false, true>), grid, dim3(256), 0, s, a); break;
+            case 6: hipLaunchKernelGGL((conv_igemm3_kernel<6, false, true>), grid, dim3(256), 0, s, a); break;
+            default: hipLaunchKernelGGL((conv_igemm3_kernel<7, false, true>), grid, dim3(256), 0, s, a); break;
+        }
+        return og_launch_status();
+    }
     switch (TM) {
         // TM = 1: the LDS-free form reads the filter rows directly, which only pays while the bank is tiny
         case 1: if (a.M <= 32) hipLaunchKernelGGL((conv_igemm3_kernel<1, true>), grid, dim3(256), 0, s, a);
@@ -1569,7 +1668,7 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed) {
     int TM, full_rows, rest;                             // block rows of height TM + one of height rest
     og_row_plan(groups, tiles_n * nph, 0, &TM, &full_rows, &rest);
     const int tiles = (full_rows + (rest ? 1 : 0)) * tiles_n;
-    const int nk = a.Kpad / 16;
+    const int nk = a.math == 1 ? a.Krow / 32 : a.Kpad / 16;      // loop iterations of the kernel
     const bool full_cover = (a.osh == 1 && a.osw == 1 && a.PH == a.OHf && a.PW == a.OWf);
     int splits = 1;
     if (tiles < 128 && nk >= 16 && (full_cover || y_prezeroed) && nph == 1) {
@@ -1615,7 +1714,31 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed) {
     return OG_OK;
 }
 
+// Which packed-bank layout (PackArgs::m_major) a call with these arguments uses; MT_out = accumulator
+// count of the thin kernel when the answer is 2.  The single source of truth for
+// objgan_conv_igemm and objgan_conv_bank_layout.
+static int og_bank_layout(int N, int C, int H, int W, int M, int Tg, int PH, int PW, int act, int math,
+                          int* MT_out) {
+    const long Cp = ((long)C + 15) / 16 * 16;
+    const bool v2 = !og_igemm_v1() && (double)N * C * H * W * 4.0 < 4.0e9 && (double)M * Tg * Cp * 4.0 < 4.0e9;
+    const int MT = M <= 4 ? 4 : (M <= 12 ? 12 : (M <= 16 ? 16 : (M <= 24 ? 24 : 32)));
+    if (MT_out) *MT_out = MT;
+    if (!v2) return 0;
+    // thin outputs: direct VALU kernel (full-coverage or strided-phase launches alike), always fp32
+    const bool thin = !og_nothin() && M <= 32 && (Tg == 9 || Tg == 4) && (long)N * PH * PW >= 65536
+                      && (MT <= 4 || (act != OG_ACT_TANH && act != OG_ACT_SIGMOID));
+    if (thin) return 2;
+    return math == 1 ? 3 : 1;
+}
+
 extern "C" {
+
+// Layout class of the packed bank objgan_conv_igemm would write / expect for these arguments (0..3).
+// A caller that keeps packed banks (wt_packed = 1) must key them on this value as well: the same
+// filter can be served by different kernels -- hence different bank layouts -- at different sizes.
+int objgan_conv_bank_layout(int N, int C, int H, int W, int M, int Tg, int PH, int PW, int act, int math) {
+    return og_bank_layout(N, C, H, W, M, Tg, PH, PW, act, math, nullptr);
+}
 
 // Size (in floats) of the packed-weight scratch for an M x K GEMM.
 long objgan_conv_packed_floats(int M, int C, int T) {
@@ -1635,8 +1758,9 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
                       int Tg, const int* dh, const int* dw, const int* src_tap,
                       int PH, int PW, int stride,
                       int OHf, int OWf, int osh, int osw, int ooh, int oow,
-                      int act, int y_prezeroed, int wt_packed, void* stream) {
+                      int act, int y_prezeroed, int wt_packed, int math, void* stream) {
     if (Tg < 1 || Tg > OG_MAX_TAPS) return OG_BAD_ARGS;
+    if (math != 0 && math != 1) return OG_BAD_ARGS;
     if (Torig < 1 || Torig > 127) return OG_BAD_ARGS;
     const int M = transpose ? Cin : Cout;
     const int Ck = transpose ? Cout : Cin;
@@ -1647,16 +1771,13 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
     p.w = w; p.wt = wt; p.Cout = Cout; p.Cin = Cin; p.Torig = Torig; p.Tg = Tg;
     p.M = M; p.Mpad = (M + 127) / 128 * 128; p.Ck = C; p.Cp = (C + 15) / 16 * 16;
     p.transpose = transpose;
-    const bool v2 = !og_igemm_v1() && (double)N * C * H * W * 4.0 < 4.0e9 && (double)M * Tg * p.Cp * 4.0 < 4.0e9;
-    p.m_major = v2 ? 1 : 0;
-    // thin outputs: direct VALU kernel (full-coverage or strided-phase launches alike)
-    const int MT = M <= 4 ? 4 : (M <= 12 ? 12 : (M <= 16 ? 16 : (M <= 24 ? 24 : 32)));
-    const bool thin = v2 && !og_nothin() && M <= 32 && (Tg == 9 || Tg == 4) && (long)N * PH * PW >= 65536
-                      && (MT <= 4 || (act != OG_ACT_TANH && act != OG_ACT_SIGMOID));
-    if (thin) { p.m_major = 2; p.Mpad = MT; }
+    int MT = 32;
+    p.m_major = og_bank_layout(N, C, H, W, M, Tg, PH, PW, act, math, &MT);
+    const bool v2 = p.m_major != 0, thin = p.m_major == 2, bf = p.m_major == 3;
+    if (thin) p.Mpad = MT;
     for (int t = 0; t < OG_MAX_TAPS; ++t) p.src_tap[t] = (signed char)(t < Tg ? src_tap[t] : -1);
     if (!wt_packed) {       // wt_packed: the caller kept wt from an earlier call with the same
-        const long ptotal = (long)Tg * p.Cp * p.Mpad;   // filter bank, taps and geometry class
+        const long ptotal = (long)Tg * p.Cp * p.Mpad;   // filter bank, taps, math and geometry class
         hipLaunchKernelGGL(pack_weights_kernel, dim3(og_stream_grid(ptotal, 256)), dim3(256), 0, s, p);
         int rc = og_launch_status();
         if (rc != OG_OK) return rc;
@@ -1667,6 +1788,8 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
     a.N = N; a.C = C; a.H = H; a.W = W;
     a.LH = upsample ? 2 * H : H; a.LW = upsample ? 2 * W : W;
     a.M = M; a.Mpad = p.Mpad; a.K = C * Tg; a.Kpad = Tg * p.Cp; a.T = Tg; a.Cp = p.Cp;
+    a.math = bf ? 1 : 0;
+    a.Krow = bf ? (a.Kpad + 31) / 32 * 32 : a.Kpad;
     a.m_begin = 0; a.m_end = M;
     a.PH = PH; a.PW = PW; a.OHf = OHf; a.OWf = OWf;
     a.osh = osh; a.osw = osw; a.ooh = ooh; a.oow = oow;
@@ -1690,23 +1813,27 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
 int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float* wt,
                                 int N, int Cout, int OH, int OW, int Cin, int Torig,
                                 int Tg, const int* dh, const int* dw, const int* src_tap,
-                                int PH, int PW, int wt_packed, void* stream) {
+                                int PH, int PW, int wt_packed, int math, void* stream) {
     if (Tg < 1 || Tg > 8) return OG_BAD_ARGS;
+    if (math != 0 && math != 1) return OG_BAD_ARGS;
     if (Torig < 1 || Torig > 127) return OG_BAD_ARGS;
     if (N <= 0 || PH <= 0 || PW <= 0 || Cin <= 0) return OG_OK;
     const int M = Cin, C = Cout;
     const int Cp = (C + 15) / 16 * 16;
     if ((double)N * C * OH * OW * 4.0 >= 4.0e9 || (double)M * Tg * Cp * 4.0 >= 4.0e9) return OG_BAD_ARGS;
     hipStream_t s = (hipStream_t)stream;
-    const long bank = (long)M * Tg * Cp;             // phase banks are stored back to back
+    const int Kpad = Tg * Cp;
+    const int Krow = math == 1 ? (Kpad + 31) / 32 * 32 : Kpad;
+    // phase banks are stored back to back: `bank` floats apart (a bf16 bank takes half of its slot)
+    const long bank = math == 1 ? (long)M * Krow / 2 : (long)M * Krow;
     if (!wt_packed) {
         for (int ph = 0; ph < 4; ++ph) {
             PackArgs p;
             p.w = w; p.wt = wt + ph * bank; p.Cout = Cout; p.Cin = Cin; p.Torig = Torig; p.Tg = Tg;
             p.M = M; p.Mpad = (M + 127) / 128 * 128; p.Ck = C; p.Cp = Cp;
-            p.transpose = 1; p.m_major = 1;
+            p.transpose = 1; p.m_major = math == 1 ? 3 : 1;
             for (int t = 0; t < OG_MAX_TAPS; ++t) p.src_tap[t] = (signed char)(t < Tg ? src_tap[ph * Tg + t] : -1);
-            hipLaunchKernelGGL(pack_weights_kernel, dim3(og_stream_grid(bank, 256)), dim3(256), 0, s, p);
+            hipLaunchKernelGGL(pack_weights_kernel, dim3(og_stream_grid((long)M * Krow, 256)), dim3(256), 0, s, p);
             int rc = og_launch_status();
             if (rc != OG_OK) return rc;
         }
@@ -1714,7 +1841,8 @@ int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float*
     IgemmArgs a;
     a.x = x; a.wt = wt; a.bias = nullptr; a.y = y;
     a.N = N; a.C = C; a.H = OH; a.W = OW; a.LH = OH; a.LW = OW;
-    a.M = M; a.Mpad = (M + 127) / 128 * 128; a.K = C * Tg; a.Kpad = Tg * Cp; a.T = Tg; a.Cp = Cp;
+    a.M = M; a.Mpad = (M + 127) / 128 * 128; a.K = C * Tg; a.Kpad = Kpad; a.T = Tg; a.Cp = Cp;
+    a.math = math; a.Krow = Krow;
     a.m_begin = 0; a.m_end = M;
     a.PH = PH; a.PW = PW; a.OHf = 2 * PH; a.OWf = 2 * PW;
     a.osh = 2; a.osw = 2; a.ooh = 0; a.oow = 0;
@@ -1732,8 +1860,9 @@ int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float*
 int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
                       int N, int Cin, int H, int W, int upsample, int pad_mode,
                       int Cout, int OH, int OW, int ksize, int stride, int pad,
-                      void* stream) {
+                      int math, void* stream) {
     if (ksize != 1 && ksize != 3 && ksize != 4) return OG_BAD_ARGS;
+    if (math != 0 && math != 1) return OG_BAD_ARGS;
     if (N <= 0 || Cout <= 0 || Cin <= 0) return OG_OK;
     hipStream_t s = (hipStream_t)stream;
     WgradArgs a;
@@ -1748,7 +1877,9 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
     const int OHW = OH * OW;
     const bool v2 = !og_igemm_v1() && (OW % 8 == 0) && (OHW % 16 == 0)
                     && (double)N * Cin * H * W * 4.0 < 4.0e9 && (double)N * Cout * OHW * 4.0 < 4.0e9;
+    a.math = math;
     if (v2) {
+        const bool bf = math == 1;
         const int groups = og_cdiv(Cout, 32);
         const int tiles_n = og_cdiv(a.ncol, 128);
         int TM, full_rows, rest;
@@ -1771,10 +1902,15 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
             splits = og_cdiv(Npix, pps);
             a.pix_per_split = pps;
             dim3 grid(rows * tiles_n, splits);
+            if (og_trace())
+                fprintf(stderr, "OGTRACE wgrad TM=%d Cout=%d Cin=%d k=%d N=%d OH=%d OW=%d stride=%d grid=%u,%u math=%d\n", tm, Cout, Cin,
+                        ksize, N, OH, OW, stride, grid.x, grid.y, math);
             ProfRec* pr = prof_begin(OG_CAT_WGRAD2(tm),
                                      2.0 * (a.m_end - a.m_begin) * (double)a.ncol * (double)Npix, s);
             // LDS-free register-fragment form for short tiles, LDS-staged form for tall ones
-#define OG_WG2(TMv) if (TMv <= 2) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv>), grid, dim3(256), 0, s, a, ksize); \
+#define OG_WG2(TMv) if (bf && TMv <= 2) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, true>), grid, dim3(256), 0, s, a, ksize); \
+                    else if (bf) hipLaunchKernelGGL((conv_wgrad2_kernel<TMv, true>), grid, dim3(256), 0, s, a, ksize); \
+                    else if (TMv <= 2) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv>), grid, dim3(256), 0, s, a, ksize); \
                     else hipLaunchKernelGGL((conv_wgrad2_kernel<TMv>), grid, dim3(256), 0, s, a, ksize);
             switch (tm) {
                 case 1: OG_WG2(1) break;
@@ -1793,6 +1929,8 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
         return OG_OK;
     }
 
+    if (og_trace())
+        fprintf(stderr, "OGTRACE wgrad(v1) Cout=%d Cin=%d k=%d N=%d OH=%d OW=%d stride=%d\n", Cout, Cin, ksize, N, OH, OW, stride);
     RowPart parts[3];
     const int np = og_row_parts(Cout, parts);
     for (int part = 0; part < np; ++part) {

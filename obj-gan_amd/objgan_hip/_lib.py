@@ -27,11 +27,11 @@ SIGNATURES = {
                           _c_int, _ptr, _ptr, _ptr,
                           _c_int, _c_int, _c_int,
                           _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                          _c_int, _c_int, _c_int, _ptr],
+                          _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_conv_dgrad_s2_phases": [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                                    _c_int, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _ptr],
+                                    _c_int, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_conv_wgrad": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                          _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr],
+                          _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_lstm_bidir_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                                   _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_norm_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
@@ -56,6 +56,7 @@ SIGNATURES = {
     "objgan_adam_step": [_ptr, _ptr, _ptr, _ptr, _c_long, _c_float, _c_float, _c_float, _c_float, _c_int, _c_float, _ptr],
     "objgan_ema_update": [_ptr, _ptr, _c_long, _c_float, _c_float, _ptr],
     "objgan_prof_enable": [_c_int],
+    "objgan_conv_bank_layout": [_c_int] * 10,
     "objgan_prof_collect": [_ptr, _ptr, _ptr],
 }
 LONG_RETURN = {"objgan_conv_packed_floats": [_c_int, _c_int, _c_int]}

@@ -47,6 +47,23 @@ def _iarr(vals):
 # ----------------------------------------------------------------------------------------------
 _ACT = {None: 0, "none": 0, "lrelu": 1, "tanh": 2, "sigmoid": 3, "relu": 4}
 
+# Arithmetic of the MFMA convolution kernels: "fp32" (default: exact fp32 fmaf chains, the parity
+# path) or "bf16" (mixed precision, BASELINE config 5: operands rounded to bf16 at the matrix-core
+# inputs, fp32 accumulation, fp32 tensors / master weights / norm statistics).
+import os as _os
+_MATH = {"mode": 1 if _os.environ.get("OBJGAN_CONV_MATH", "fp32") == "bf16" else 0}
+
+
+def set_conv_math(mode):
+    if mode not in ("fp32", "bf16"):
+        raise _lib.ObjganHipError("conv math must be 'fp32' or 'bf16'")
+    _MATH["mode"] = 1 if mode == "bf16" else 0
+
+
+def get_conv_math():
+    return "bf16" if _MATH["mode"] else "fp32"
+
+
 
 def _packed_scratch(M, C, T, device):
     n = _lib.load().objgan_conv_packed_floats(int(M), int(C), int(T))
@@ -72,15 +89,16 @@ def _pack_key(w, transpose, src_tap, big):
     if ep is None and w.requires_grad:
         return None
     return (w.data_ptr(), w._version, ep[0] if ep is not None else -1, tuple(w.shape), int(transpose),
-            tuple(src_tap), big)
+            tuple(src_tap), big, _MATH["mode"])
 
 
 def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, transpose,
            dh, dw, src_tap, PH, PW, stride, OHf, OWf, osh, osw, ooh, oow, act, y_prezeroed=0):
     Tg = len(dh)
     M = Cin if transpose else Cout
-    # the library picks the bank layout from the input size class (buffer-addressable or not)
-    key = _pack_key(w, transpose, src_tap, float(N) * C * H * W * 4.0 >= 4.0e9)
+    # the library picks the kernel -- hence the bank layout -- from sizes, taps and math: ask it
+    layout = _lib.load().objgan_conv_bank_layout(N, C, H, W, M, Tg, PH, PW, act, _MATH["mode"])
+    key = _pack_key(w, transpose, src_tap, layout)
     ent = _PACK_CACHE.get(key) if key is not None else None
     if ent is not None and ent[0] is w:
         wt, packed = ent[1], 1
@@ -93,7 +111,7 @@ def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, tran
     _lib.call("objgan_conv_igemm", _p(x), _p(w), _p(bias), _p(y), _p(wt),
               N, C, H, W, int(upsample), int(pad_mode), Cout, Cin, Torig, int(transpose),
               Tg, _iarr(dh), _iarr(dw), _iarr(src_tap), PH, PW, stride,
-              OHf, OWf, osh, osw, ooh, oow, act, int(y_prezeroed), packed, _stream())
+              OHf, OWf, osh, osw, ooh, oow, act, int(y_prezeroed), packed, _MATH["mode"], _stream())
 
 
 def _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad_h, pad_w, LH, LW):
@@ -128,7 +146,7 @@ def _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad_h, pad_w, LH, LW):
                 _PACK_CACHE.clear()
             _PACK_CACHE[key] = (w, wt)
     _lib.call("objgan_conv_dgrad_s2_phases", _p(g), _p(w), _p(dx), _p(wt), N, Cout, OH, OW, Cin, KH * KW,
-              Tg, _iarr(dh), _iarr(dw), _iarr(st), LH // 2, LW // 2, packed, _stream())
+              Tg, _iarr(dh), _iarr(dw), _iarr(st), LH // 2, LW // 2, packed, _MATH["mode"], _stream())
     return dx
 
 
@@ -233,7 +251,7 @@ class _Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw_ = torch.zeros_like(w)
             _lib.call("objgan_conv_wgrad", _p(x), _p(g), _p(dw_), N, Cin, H, W, int(upsample), refl,
-                      Cout, OH, OW, k, stride, pad, _stream())
+                      Cout, OH, OW, k, stride, pad, _MATH["mode"], _stream())
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(Cout, dtype=_F32, device=x.device)
             _lib.call("objgan_channel_sum", _p(g), _p(db), N, Cout, OH * OW, _stream())

@@ -440,6 +440,16 @@ def test_packed_filter_cache_follows_weight_updates(dev):
     with torch.no_grad():
         conv.weight.mul_(0.5)                   # torch-side update
     check()
+    # the same (cached) filter served by two kernels with different bank layouts: >= 65536 output pixels
+    # take the thin direct kernel, fewer take the MFMA kernel (the shape-discriminator stem at 64^2 with a
+    # full batch vs the valid-row subset of its "wrong" pass)
+    stem = torch.nn.Conv2d(20, 12, 3, padding=1).to(dev)
+    stem_arena = T.ParamArena(stem)
+    for n in (4, 3, 4, 3):
+        xs = torch.randn(n, 20, 128, 128, generator=g).to(dev)          # 65536 / 49152 pixels
+        ys = ops.conv2d(xs, stem.weight, stem.bias, 1, 1, "reflect")
+        want_s = tr.conv2d(xs.cpu(), stem.weight.detach().cpu(), stem.bias.detach().cpu(), 1, 1, "reflect")
+        assert rel_l2(ys, want_s) < TOL, n
     frozen = torch.randn(8, 40, 3, 3, generator=g).to(dev)
     y1 = ops.conv2d(x, frozen, None, 1, 1)
     frozen.add_(1.0)
@@ -473,3 +483,52 @@ def test_rnn_encoder_matches_oracle_and_reference_golden(dev):
     w_got, s_got = enc(caps.to(dev), lens.to(dev), 10)
     assert rel_l2(w_got, w_want) < 1e-5 and rel_l2(s_got, s_want) < 1e-5
     assert float(w_got[4, :, 1:].abs().sum()) == 0.0
+
+
+BF16_CASES = [
+    # N, Cin, H, W, Cout, k, stride, pad, pad_mode, upsample
+    (2, 194, 16, 16, 388, 3, 1, 1, "reflect", False),     # two block rows (7 + 6 groups), odd chunk count
+    (2, 194, 8, 8, 96, 3, 1, 1, "zeros", True),           # upBlock
+    (2, 96, 16, 16, 192, 4, 2, 1, "zeros", False),        # D encoder, phased dgrad
+    (2, 40, 16, 24, 40, 3, 1, 1, "zeros", False),         # short tiles (TM = 2): LDS-free weight-gradient form
+    (3, 256, 12, 1, 48, 1, 1, 0, "zeros", False),         # 1x1
+]
+
+
+@pytest.mark.parametrize("case", BF16_CASES)
+def test_conv2d_bf16_math_equals_fp32_conv_of_bf16_rounded_operands(dev, case):
+    """Mixed-precision mode (BASELINE config 5): the kernels round their operands to bf16 (RNE) at the
+    matrix-core inputs and accumulate in fp32 -- i.e. forward = conv(bf16(x), bf16(w)), data gradient =
+    conv_T(bf16(dy), bf16(w)), weight gradient = corr(bf16(x), bf16(dy)), each in fp32 arithmetic.  The
+    oracle evaluates exactly that, so the tolerance stays at fp32 level."""
+    ops, tr = _ops(), _tref()
+    N, Cin, H, W, Cout, k, s, p, pm, up = case
+    g = torch.Generator().manual_seed(4321)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    rnd = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    # forward + dgrad reference: everything from rounded x, w; gradient seed rounded as well
+    xr, wr = rnd(x).requires_grad_(), rnd(w).requires_grad_()
+    yr = tr.conv2d(xr, wr, None, s, p, pm, up, None)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(rnd(gy))
+    ops.set_conv_math("bf16")
+    try:
+        xd, wd = x.to(dev).requires_grad_(), w.to(dev).requires_grad_()
+        yd = ops.conv2d(xd, wd, None, s, p, pm, up, None)
+        yd.backward(gy.to(dev))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_conv_math("fp32")
+    assert rel_l2(yd, yr) < TOL, ("fwd", rel_l2(yd, yr))
+    assert rel_l2(xd.grad, xr.grad) < TOL, ("dgrad", rel_l2(xd.grad, xr.grad))
+    OW = yr.shape[3]
+    if OW % 8 == 0 and (yr.shape[2] * OW) % 16 == 0:
+        assert rel_l2(wd.grad, wr.grad) < TOL, ("wgrad", rel_l2(wd.grad, wr.grad))
+    else:       # maps narrower than 8 pixels take the first-generation fp32 weight-gradient kernel
+        xf, wf = x.clone().requires_grad_(), w.clone().requires_grad_()
+        tr.conv2d(xf, wf, None, s, p, pm, up, None).backward(gy)
+        assert rel_l2(wd.grad, wf.grad) < TOL, ("wgrad fp32 fallback", rel_l2(wd.grad, wf.grad))
+    # and it is a bf16-level approximation of the fp32 result
+    y32 = tr.conv2d(x, w, None, s, p, pm, up, None)
+    assert 1e-4 < rel_l2(yd, y32) < 2e-2

@@ -3,7 +3,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 tools/conv_bench.cpp -Iinclude -L obj-gan_amd/objgan_hip -lobjgan_hip \
 //         -Wl,-rpath,'$ORIGIN/../obj-gan_amd/objgan_hip' -o tools/conv_bench
-//   tools/conv_bench [filter] [iters]
+//   tools/conv_bench [filter] [iters] [math: 0 fp32 | 1 bf16 inputs]
 //
 // For every shape: forward, data gradient and weight gradient are timed with hipEvents and
 // reported as algorithmic TFLOP/s (2*N*OH*OW*Cout*Cin*k*k); a sample of output elements is
@@ -37,9 +37,13 @@ static const Shape SHAPES[] = {
     {"d_l4s    384->768 4x4 s2 @32", 16, 384, 32, 32, 768, 4, 2, 1, 0, 0},
     {"joint    1024->768 3x3 @16", 16, 1024, 16, 16, 768, 3, 1, 1, 0, 0},
     {"rgb_256  48->3 3x3", 16, 48, 256, 256, 3, 3, 1, 1, 0, 0},
+    {"outlogit 768->1 4x4 s2 @4", 13, 768, 4, 4, 1, 4, 2, 0, 0, 0},
+    {"roi_code 384->384 4x4 @5", 160, 384, 5, 5, 384, 4, 1, 1, 0, 0},
+    {"incep_17 192->192 1x7 (as 3x3)", 16, 192, 17, 17, 192, 3, 1, 1, 0, 0},
 };
 
 static unsigned g_seed = 12345u;
+static int g_math = 0;      // 0 fp32, 1 bf16 inputs (argv[3])
 static float frand() { g_seed = g_seed * 1664525u + 1013904223u; return ((g_seed >> 8) & 0xffff) / 32768.0f - 1.0f; }
 
 static int reflect(int i, int L) { if (i < 0) i = -i; if (i >= L) i = 2 * (L - 1) - i; return i; }
@@ -47,6 +51,7 @@ static int reflect(int i, int L) { if (i < 0) i = -i; if (i >= L) i = 2 * (L - 1
 int main(int argc, char** argv) {
     const char* filt = argc > 1 ? argv[1] : "";
     const int iters = argc > 2 ? atoi(argv[2]) : 5;
+    g_math = argc > 3 ? atoi(argv[3]) : 0;
     hipStream_t st;
     CK(hipStreamCreate(&st));
     hipEvent_t e0, e1;
@@ -79,7 +84,7 @@ int main(int argc, char** argv) {
         }
         auto fwd = [&]() {
             int rc = objgan_conv_igemm(dx, dw, nullptr, dy, wt, sh.N, sh.Cin, sh.H, sh.W, sh.up, sh.refl, sh.Cout, sh.Cin, T, 0,
-                                       T, dh.data(), dwv.data(), stp.data(), OH, OW, sh.s, OH, OW, 1, 1, 0, 0, 0, 0, 0, st);
+                                       T, dh.data(), dwv.data(), stp.data(), OH, OW, sh.s, OH, OW, 1, 1, 0, 0, 0, 0, 0, g_math, st);
             if (rc != 1) { fprintf(stderr, "fwd rc=%d\n", rc); exit(1); }
         };
         auto dgrad = [&]() {
@@ -88,7 +93,7 @@ int main(int argc, char** argv) {
                 std::vector<int> h2(T), w2(T);
                 for (int kh = 0; kh < sh.k; ++kh) for (int kw = 0; kw < sh.k; ++kw) { h2[kh * sh.k + kw] = pe - kh; w2[kh * sh.k + kw] = pe - kw; }
                 int rc = objgan_conv_igemm(dg, dw, nullptr, dgx, wt, sh.N, sh.Cout, OH, OW, 0, 0, sh.Cout, sh.Cin, T, 1,
-                                           T, h2.data(), w2.data(), stp.data(), TH, TW, 1, TH, TW, 1, 1, 0, 0, 0, 0, 0, st);
+                                           T, h2.data(), w2.data(), stp.data(), TH, TW, 1, TH, TW, 1, 1, 0, 0, 0, 0, 0, g_math, st);
                 if (rc != 1) { fprintf(stderr, "dgrad rc=%d\n", rc); exit(1); }
             } else if (sh.k % 2 == 0 && LH % 2 == 0 && sh.Cin > 32) {
                 std::vector<int> h2, w2, s2;
@@ -98,7 +103,7 @@ int main(int argc, char** argv) {
                             h2.push_back((ph + sh.p - kh) / 2); w2.push_back((pw + sh.p - kw) / 2); s2.push_back(kh * sh.k + kw);
                         }
                 int rc = objgan_conv_dgrad_s2_phases(dg, dw, dgx, wt, sh.N, sh.Cout, OH, OW, sh.Cin, T, (int)h2.size() / 4,
-                                                     h2.data(), w2.data(), s2.data(), LH / 2, LW / 2, 0, st);
+                                                     h2.data(), w2.data(), s2.data(), LH / 2, LW / 2, 0, g_math, st);
                 if (rc != 1) { fprintf(stderr, "dgrad phases rc=%d\n", rc); exit(1); }
             } else {
                 CK(hipMemsetAsync(dgx, 0, ngx * 4, st));
@@ -110,14 +115,14 @@ int main(int argc, char** argv) {
                         }
                     const int PHg = (LH - ph + 1) / 2, PWg = (LW - pw + 1) / 2;
                     int rc = objgan_conv_igemm(dg, dw, nullptr, dgx, wt, sh.N, sh.Cout, OH, OW, 0, 0, sh.Cout, sh.Cin, T, 1,
-                                               (int)h2.size(), h2.data(), w2.data(), s2.data(), PHg, PWg, 1, LH, LW, 2, 2, ph, pw, 0, 1, 0, st);
+                                               (int)h2.size(), h2.data(), w2.data(), s2.data(), PHg, PWg, 1, LH, LW, 2, 2, ph, pw, 0, 1, 0, g_math, st);
                     if (rc != 1) { fprintf(stderr, "dgrad2 rc=%d\n", rc); exit(1); }
                 }
             }
         };
         auto wgrad = [&]() {
             CK(hipMemsetAsync(dgw, 0, nw * 4, st));
-            int rc = objgan_conv_wgrad(dx, dg, dgw, sh.N, sh.Cin, sh.H, sh.W, sh.up, sh.refl, sh.Cout, OH, OW, sh.k, sh.s, sh.p, st);
+            int rc = objgan_conv_wgrad(dx, dg, dgw, sh.N, sh.Cin, sh.H, sh.W, sh.up, sh.refl, sh.Cout, OH, OW, sh.k, sh.s, sh.p, g_math, st);
             if (rc != 1) { fprintf(stderr, "wgrad rc=%d\n", rc); exit(1); }
         };
         auto timeit = [&](auto&& fn) {
