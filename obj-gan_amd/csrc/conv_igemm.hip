@@ -1967,7 +1967,17 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
 // ---- profiling control (see the note above the host section) ---------------------------------
 int objgan_prof_enable(int on) {
     g_prof_on = on ? 1 : 0;
-    if (on) g_prof_n = 0;
+    if (on) {
+        g_prof_n = 0;
+        // create the whole event pool up front: hipEventCreate inside the measured region would
+        // cost the host tens of milliseconds per step
+        if (!g_prof) g_prof = (ProfRec*)calloc(OG_PROF_MAX, sizeof(ProfRec));
+        while (g_prof && g_prof_made < OG_PROF_MAX) {
+            ProfRec* r = &g_prof[g_prof_made];
+            if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) break;
+            g_prof_made++;
+        }
+    }
     return OG_OK;
 }
 

@@ -14,6 +14,30 @@ from miscc.config import cfg
 from objgan_hip import ops
 
 
+# ---- host copies of the small box tensors ---------------------------------------------------------
+# The reference reads rois / num_rois on the host in several places per step (utils.py:466, 503-505,
+# model.py:549, 661): each read of a device tensor is a device->host copy that drains the stream.
+# The box tensors are inputs of the step and do not change, so the host copy is taken once per
+# tensor (keyed on the tensor object and its version counter) and reused by every caller.
+_HOST = []          # [(tensor, version, numpy)], most recent first, at most 8 entries
+
+
+def _host(t):
+    if not isinstance(t, torch.Tensor):
+        return np.asarray(t)
+    if not t.is_cuda:
+        return t.detach().numpy()
+    for i, (ref, ver, arr) in enumerate(_HOST):
+        if ref is t and ver == t._version:
+            if i:
+                _HOST.insert(0, _HOST.pop(i))
+            return arr
+    arr = t.detach().cpu().numpy()
+    _HOST.insert(0, (t, t._version, arr))
+    del _HOST[8:]
+    return arr
+
+
 # ---- ROI blob helpers (host/numpy API of the reference, kept for callers that use it) ----------
 def _project_im_rois(im_rois, scales):
     """R x 4 boxes -> (scaled boxes, batch index column); the batch index of row r is
@@ -47,8 +71,8 @@ def permute_seg(seg_conditions, rois, num_rois):
     Uses python's `random` exactly like the reference, so a seeded run draws the same permutations.
     Returns (new_seg_conditions, valid_mask) with valid_mask the list of changed sample indices."""
     new_seg = seg_conditions.clone()
-    rois_np = rois.detach().cpu().numpy() if isinstance(rois, torch.Tensor) else np.asarray(rois)
-    nr = num_rois.detach().cpu().numpy().tolist() if isinstance(num_rois, torch.Tensor) else list(num_rois)
+    rois_np = _host(rois)
+    nr = _host(num_rois).tolist()
     valid_mask = []
     for b in range(seg_conditions.size(0)):
         n = int(nr[b])
@@ -68,8 +92,8 @@ def feat_select(pooled_feat, raw_bt_c_codes, fm_rois, num_rois, is_large_scale=F
     utils.py:465-499): drop boxes with w < 1.25 and h < 1.25; small-scale keeps max(w, h) < 16,
     large-scale keeps >= 16.  Returns (features [K, C, h, w], classes [K] int64 (cpu),
     bt_c_codes [K, idf]); empty lists when nothing survives."""
-    rois_np = fm_rois.detach().cpu().numpy()
-    nr = num_rois.detach().cpu().numpy().tolist() if isinstance(num_rois, torch.Tensor) else list(num_rois)
+    rois_np = _host(fm_rois)
+    nr = _host(num_rois).tolist()
     thr = cfg.ROI.ROI_SIZE_THRS
     sel_b, sel_r, classes = [], [], []
     for b in range(len(nr)):
@@ -101,8 +125,8 @@ def feat_select(pooled_feat, raw_bt_c_codes, fm_rois, num_rois, is_large_scale=F
 
 def form_clabels_feat(clabels_emb, rois, num_rois):
     """Per-box class-label embeddings: batch x emb x max_num_roi x 1 (reference utils.py:502-522)."""
-    rois_np = rois.detach().cpu().numpy()
-    nr = num_rois.detach().cpu().numpy().tolist()
+    rois_np = _host(rois)
+    nr = _host(num_rois).tolist()
     B = rois_np.shape[0]
     max_num_roi = int(np.amax(nr))
     feat = torch.zeros((B, max_num_roi, clabels_emb.size(1)), dtype=clabels_emb.dtype,

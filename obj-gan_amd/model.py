@@ -282,9 +282,9 @@ class INIT_STAGE_G(nn.Module):
 
 
 def _max_rois(num_rois):
-    if isinstance(num_rois, torch.Tensor):
-        return int(num_rois.max().item()) if num_rois.numel() else 0
-    return int(np.amax(num_rois)) if len(num_rois) else 0
+    from miscc.utils import _host
+    nr = _host(num_rois)
+    return int(np.amax(nr)) if nr.size else 0
 
 
 class _BottomUpMixin(object):

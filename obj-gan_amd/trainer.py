@@ -29,7 +29,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from miscc.config import cfg
-from miscc.utils import mkdir_p, weights_init, form_clabels_feat
+from miscc.utils import mkdir_p, weights_init, form_clabels_feat, _host
 from miscc.losses import patD_loss, shpD_loss, objD_loss, G_loss, KL_loss
 from model import (G_NET, PAT_D_NET64, PAT_D_NET128, PAT_D_NET256, SHP_D_NET64, SHP_D_NET128,
                    SHP_D_NET256, OBJ_SS_D_NET, OBJ_LS_D_NET)
@@ -258,7 +258,7 @@ class condGANTrainer(object):
         if noise is None:
             self.noise.normal_(0, 1)
             noise = self.noise
-        glb_max_num_roi = int(torch.max(num_rois))
+        glb_max_num_roi = int(_host(num_rois).max())
         fake_imgs, bt_c_codes, _, _, mu, logvar = self.netG(
             noise, sent_emb, words_embs, glove_words_embs, clabels_feat, mask, hmaps, rois,
             fm_rois, num_rois, b["bt_masks"], b["fm_bt_masks"], glb_max_num_roi)
