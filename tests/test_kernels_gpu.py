@@ -532,3 +532,43 @@ def test_conv2d_bf16_math_equals_fp32_conv_of_bf16_rounded_operands(dev, case):
     # and it is a bf16-level approximation of the fp32 result
     y32 = tr.conv2d(x, w, None, s, p, pm, up, None)
     assert 1e-4 < rel_l2(yd, y32) < 2e-2
+
+
+def test_conv_never_consumes_memory_past_the_input_tensor(dev):
+    """The gather of the last 16-channel chunk addresses channels past C (their filter entries are
+    zero): inside the tensor that hits the next image, past the last image it must be cut off by the
+    buffer range check.  Put NaNs right behind the tensor: a read that slipped through would poison the
+    output (NaN x 0)."""
+    ops, tr = _ops(), _tref()
+    g = torch.Generator().manual_seed(11)
+    for (N, C, H, W, Cout, k) in ((2, 194, 16, 16, 70, 3), (1, 5, 8, 8, 40, 3), (3, 20, 8, 8, 12, 1)):
+        n = N * C * H * W
+        arena = torch.full((n + 64 * H * W,), float("nan"), device=dev)
+        x = arena[:n].view(N, C, H, W)
+        xc = torch.randn(N, C, H, W, generator=g)
+        x.copy_(xc)
+        w = torch.randn(Cout, C, k, k, generator=g) / (C * k * k) ** 0.5
+        for math in ("fp32", "bf16"):
+            ops.set_conv_math(math)
+            try:
+                y = ops.conv2d(x, w.to(dev), None, 1, k // 2)
+            finally:
+                ops.set_conv_math("fp32")
+            assert torch.isfinite(y).all(), (math, N, C)
+            if math == "fp32":
+                assert rel_l2(y, tr.conv2d(xc, w, None, 1, k // 2)) < TOL
+        # weight gradient reads x too (dy behind a NaN guard as well)
+        OH = H
+        ga = torch.full((N * Cout * OH * W + 4096,), float("nan"), device=dev)
+        dy = ga[:N * Cout * OH * W].view(N, Cout, OH, W)
+        dyc = torch.randn(N, Cout, OH, W, generator=g)
+        dy.copy_(dyc)
+        wd = w.to(dev).requires_grad_()
+        xd = x.detach().requires_grad_()
+        yd = ops.conv2d(xd, wd, None, 1, k // 2)
+        yd.backward(dy)
+        torch.cuda.synchronize()
+        assert torch.isfinite(wd.grad).all() and torch.isfinite(xd.grad).all()
+        xr, wr = xc.clone().requires_grad_(), w.clone().requires_grad_()
+        tr.conv2d(xr, wr, None, 1, k // 2).backward(dyc)
+        assert rel_l2(wd.grad, wr.grad) < TOL and rel_l2(xd.grad, xr.grad) < TOL
