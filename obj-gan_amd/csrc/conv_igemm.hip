@@ -1122,20 +1122,28 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
     load_b(rb0);
     if (ALDS) __syncthreads();
     int cur = 0;
-    for (int kt = kt0; kt < nk; ++kt) {
-        // fetch the fragments of step kt+1 (rb1 / ad1) behind the MFMAs of step kt (rb0 / ad0)
-        if (kt + 1 < nk) {
-            if (ALDS) store_a(cur ^ 1); else load_adir(ad1, kt + 1);
-            load_b(rb1);
-        }
+    // Two steps per trip with the fragment registers in fixed ping-pong roles (rb0/ad0 even, rb1/ad1
+    // odd): the gather of step k+1 is only waited for at its own MFMAs, i.e. it overlaps the MFMAs of
+    // step k.  (A single-step loop with a register copy at its end makes hipcc wait for the fresh
+    // loads BEFORE the MFMAs of the current step -- the whole memory latency exposed every step.)
+    int kt = kt0;
+    for (; kt + 1 < nk; kt += 2) {
+        if (ALDS) store_a(cur ^ 1); else load_adir(ad1, kt + 1);
+        load_b(rb1);
         if (ALDS && kt + 2 < nk) load_a(kt + 2);
         mma(rb0, ad0, cur);
         if (ALDS) __syncthreads();
         cur ^= 1;
-#pragma unroll
-        for (int i = 0; i < NB; ++i) rb0[i] = rb1[i];
-        if (!ALDS) { ad0[0] = ad1[0]; ad0[1] = ad1[1]; }
+        if (kt + 2 < nk) {
+            if (ALDS) store_a(cur ^ 1); else load_adir(ad0, kt + 2);
+            load_b(rb0);
+        }
+        if (ALDS && kt + 3 < nk) load_a(kt + 3);
+        mma(rb1, ad1, cur);
+        if (ALDS) __syncthreads();
+        cur ^= 1;
     }
+    if (kt < nk) mma(rb0, ad0, cur);                   // odd step count: last step
 
     // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
     if (!pix_ok) return;
@@ -1389,19 +1397,24 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, con
     load_b(rb0);
     if (ALDS) __syncthreads();
     int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) {
-            if (ALDS) store_a(cur ^ 1); else load_adir(ad1);
-            load_b(rb1);
-        }
+    int kt = 0;                                       // two steps per trip, see conv_igemm3_kernel
+    for (; kt + 1 < nk; kt += 2) {
+        if (ALDS) store_a(cur ^ 1); else load_adir(ad1);
+        load_b(rb1);
         if (ALDS && kt + 2 < nk) load_a();
         mma(rb0, ad0, cur);
         if (ALDS) __syncthreads();
         cur ^= 1;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) rb0[i] = rb1[i];
-        if (!ALDS) { ad0[0] = ad1[0]; ad0[1] = ad1[1]; }
+        if (kt + 2 < nk) {
+            if (ALDS) store_a(cur ^ 1); else load_adir(ad0);
+            load_b(rb0);
+        }
+        if (ALDS && kt + 3 < nk) load_a();
+        mma(rb1, ad1, cur);
+        if (ALDS) __syncthreads();
+        cur ^= 1;
     }
+    if (kt < nk) mma(rb0, ad0, cur);
 
     if (!col_ok) return;
 #pragma unroll
@@ -1908,6 +1921,8 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
             ProfRec* pr = prof_begin(OG_CAT_WGRAD2(tm),
                                      2.0 * (a.m_end - a.m_begin) * (double)a.ncol * (double)Npix, s);
             // LDS-free register-fragment form for short tiles, LDS-staged form for tall ones
+            // register-fragment form for short tiles, LDS-staged form for tall ones (measured equal or
+            // better there: the up-sampling / reflecting gathers keep their per-element address math)
 #define OG_WG2(TMv) if (bf && TMv <= 2) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, true>), grid, dim3(256), 0, s, a, ksize); \
                     else if (bf) hipLaunchKernelGGL((conv_wgrad2_kernel<TMv, true>), grid, dim3(256), 0, s, a, ksize); \
                     else if (TMv <= 2) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv>), grid, dim3(256), 0, s, a, ksize); \
