@@ -1127,6 +1127,29 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
     // step k.  (A single-step loop with a register copy at its end makes hipcc wait for the fresh
     // loads BEFORE the MFMAs of the current step -- the whole memory latency exposed every step.)
     int kt = kt0;
+    if (!ALDS) {
+        // LDS-free form: nothing couples the waves, so the only latency cover is the prefetch depth.
+        // Three fragment sets in fixed rotation keep the loads TWO steps (16 MFMAs) ahead; one step
+        // (8 MFMAs, ~0.25 us) is shorter than a loaded L2 round trip whenever fewer than ~5 waves
+        // share a SIMD, which is exactly the small-grid case this form serves.
+        float rb2[NB];
+        f32x4 ad2[2];
+        // (the loads run up to two steps past the end, unconditionally: a branch around them makes
+        // hipcc's wait-count insertion drain everything at the next MFMA block; the surplus reads
+        // land inside the buffers or on the range check and are never used)
+        load_adir(ad1, kt0 + 1); load_b(rb1);
+        for (; kt + 2 < nk; kt += 3) {
+            load_adir(ad2, kt + 2); load_b(rb2);
+            mma(rb0, ad0, 0);
+            load_adir(ad0, kt + 3); load_b(rb0);
+            mma(rb1, ad1, 0);
+            load_adir(ad1, kt + 4); load_b(rb1);
+            mma(rb2, ad2, 0);
+        }
+        if (kt < nk) mma(rb0, ad0, 0);
+        if (kt + 1 < nk) mma(rb1, ad1, 0);
+        kt = nk;
+    }
     for (; kt + 1 < nk; kt += 2) {
         if (ALDS) store_a(cur ^ 1); else load_adir(ad1, kt + 1);
         load_b(rb1);
@@ -1559,6 +1582,11 @@ static int og_igemm_tmmax() {
 // ~ (workgroups per CU) x TM: whole rounds while the grid is small (quantisation is what decides
 // there), fractional once it spans many rounds; short tiles re-read the pixel operand more (pen).
 // The weight gradient always takes the tallest tiles: its gather is the expensive part.
+static int og_pen_old() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OG_PEN_OLD"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v;
+}
 static double og_rounds(long blocks) {
     if (blocks <= 256) return 1.25;                 // one workgroup per CU: nothing to overlap with
     if (blocks < 1024) return (double)og_cdiv(blocks, 256);
@@ -1572,7 +1600,11 @@ static void og_row_plan(int groups, int tiles_n, int tall, int* TM_out, int* ful
         const int brows = og_cdiv(groups, tmmax);
         bt = og_cdiv(groups, brows);
     } else {
-        static const double pen[8] = {0, 1.12, 1.05, 1.02, 1.0, 1.0, 1.0, 1.0};
+        // TM = 1 re-reads the pixel operand once per 32 rows and runs against the L2 (~7 TB/s of
+        // fills, 86 TFLOP/s at best -- profiles/r01_tm1_l2_bound.txt); TM = 3 reaches ~114, TM >= 4 ~120
+        static const double pen_new[8] = {0, 1.40, 1.15, 1.06, 1.02, 1.0, 1.0, 1.0};
+        static const double pen_old[8] = {0, 1.12, 1.05, 1.02, 1.0, 1.0, 1.0, 1.0};
+        const double* pen = og_pen_old() ? pen_old : pen_new;
         double best = -1;
         for (int tm = 1; tm <= tmmax && tm <= groups; ++tm) {
             const int full = groups / tm, rest = groups - full * tm;
@@ -1637,6 +1669,22 @@ static int og_trace() {
     return v;
 }
 
+static int og_adirect() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OG_ADIRECT"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v;
+}
+static int og_wgrad3_maxtm() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OG_WGRAD3_MAXTM"); v = e ? atoi(e) : 2; }
+    return v;
+}
+static int og_split_target() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OG_SPLIT_TARGET"); v = e ? atoi(e) : 1024; }
+    return v;
+}
+
 static int launch_igemm2(const IgemmArgs& a, int TM, dim3 grid, hipStream_t s) {
     if (og_trace())
         fprintf(stderr, "OGTRACE igemm TM=%d M=%d rows=%d C=%d T=%d Npix=%d grid=%u,%u,%u H=%d W=%d stride=%d\n", TM, a.M,
@@ -1657,7 +1705,7 @@ static int launch_igemm2(const IgemmArgs& a, int TM, dim3 grid, hipStream_t s) {
     }
     switch (TM) {
         // TM = 1: the LDS-free form reads the filter rows directly, which only pays while the bank is tiny
-        case 1: if (a.M <= 32) hipLaunchKernelGGL((conv_igemm3_kernel<1, true>), grid, dim3(256), 0, s, a);
+        case 1: if (a.M <= 32 || og_adirect()) hipLaunchKernelGGL((conv_igemm3_kernel<1, true>), grid, dim3(256), 0, s, a);
                 else hipLaunchKernelGGL((conv_igemm3_kernel<1, false>), grid, dim3(256), 0, s, a);
                 break;
         case 2: hipLaunchKernelGGL((conv_igemm3_kernel<2>), grid, dim3(256), 0, s, a); break;
@@ -1687,6 +1735,11 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed) {
     if (tiles < 128 && nk >= 16 && (full_cover || y_prezeroed) && nph == 1) {
         splits = og_cdiv(512, tiles);
         if (splits > nk / 4) splits = nk / 4;
+    } else if (og_split_target() > 0 && TM == 1 && rest == 0 && tiles < og_split_target() && nk >= 16 &&
+               (full_cover || y_prezeroed) && nph == 1) {
+        splits = og_cdiv(og_split_target(), tiles);
+        if (splits > nk / 8) splits = nk / 8;
+        if (splits < 1) splits = 1;
     }
     const float* bias = a.bias;
     const int act = a.act;
@@ -1925,7 +1978,7 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
             // better there: the up-sampling / reflecting gathers keep their per-element address math)
 #define OG_WG2(TMv) if (bf && TMv <= 2) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, true>), grid, dim3(256), 0, s, a, ksize); \
                     else if (bf) hipLaunchKernelGGL((conv_wgrad2_kernel<TMv, true>), grid, dim3(256), 0, s, a, ksize); \
-                    else if (TMv <= 2) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv>), grid, dim3(256), 0, s, a, ksize); \
+                    else if (TMv <= og_wgrad3_maxtm()) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv>), grid, dim3(256), 0, s, a, ksize); \
                     else hipLaunchKernelGGL((conv_wgrad2_kernel<TMv>), grid, dim3(256), 0, s, a, ksize);
             switch (tm) {
                 case 1: OG_WG2(1) break;

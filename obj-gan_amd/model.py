@@ -628,20 +628,27 @@ def _rois_blob(fm_rois, boxes_num):
     return blob.to(torch.float32).contiguous()
 
 
-# One-entry memo of the bilinear lift of a layout map (80 channels, 256^2 -> 512^2: 1.3 GB at B=16).
-# The entry holds the source tensor itself, so its address cannot be recycled while cached; an
-# in-place torch edit of the source changes `_version` and misses.
-_LIFT = {"src": None, "ver": -1, "size": 0, "out": None}
+# Two-entry memo (least recently used out) of the bilinear lift of a layout map (80 channels,
+# 256^2 -> 512^2: 1.3 GB at B=16).  One step lifts two kinds of map: the batch's own layout
+# (both object discriminators, D and G phase: one lift serves all of them) and the permuted
+# "wrong layout" maps of each discriminator loss (fresh tensors every time) -- with a single entry
+# the latter evict the former between its uses.  An entry holds the source tensor itself, so its
+# address cannot be recycled while cached; an in-place torch edit of the source changes `_version`
+# and misses.
+_LIFT = []
 
 
 def _lift_cached(s_var, img_size):
     if s_var.requires_grad:
         return ops.bilinear_resize(s_var, img_size, img_size)
-    c = _LIFT
-    if c["src"] is s_var and c["ver"] == s_var._version and c["size"] == img_size:
-        return c["out"]
+    for i, (src, ver, size, out) in enumerate(_LIFT):
+        if src is s_var and ver == s_var._version and size == img_size:
+            if i:
+                _LIFT.insert(0, _LIFT.pop(i))
+            return out
     out = ops.bilinear_resize(s_var, img_size, img_size)
-    c["src"], c["ver"], c["size"], c["out"] = s_var, s_var._version, img_size, out
+    _LIFT.insert(0, (s_var, s_var._version, img_size, out))
+    del _LIFT[2:]
     return out
 
 
