@@ -385,6 +385,7 @@ extern "C" {
 int objgan_attn_general_forward(const float* x, const float* src, const unsigned char* mask,
                                 float* wc, float* attn, int B, int idf, int Q, int L,
                                 void* stream) {
+    OG_ENTRY();
     if (L < 1 || L > 16) return OG_BAD_ARGS;
     if (B <= 0 || Q <= 0) return OG_OK;
     dim3 grid(og_cdiv(Q, 256), B);
@@ -400,6 +401,7 @@ int objgan_attn_general_forward(const float* x, const float* src, const unsigned
 int objgan_attn_general_backward(const float* x, const float* src, const float* attn,
                                  const float* dwc, const float* dattn, float* dx, float* dsrc,
                                  int B, int idf, int Q, int L, void* stream) {
+    OG_ENTRY();
     if (L < 1 || L > 16) return OG_BAD_ARGS;
     if (B <= 0 || Q <= 0) return OG_OK;
     // pixels per wave: enough chunks that the 576 atomics per wave are amortised, while the
@@ -420,6 +422,7 @@ int objgan_attn_bu_forward(const float* tgt, const float* ctx1, const float* src
                            const unsigned char* mask, float* wc, float* attn,
                            int B, int d2, int idf, int R, int L, int normalize, float eps,
                            void* stream) {
+    OG_ENTRY();
     if (B <= 0 || R <= 0 || L <= 0) return OG_OK;
     const size_t shm = sizeof(float) * ((size_t)R * L + R + L);
     if (shm > 60000) return OG_BAD_ARGS;
@@ -430,6 +433,7 @@ int objgan_attn_bu_forward(const float* tgt, const float* ctx1, const float* src
 
 int objgan_attn_bu_backward(const float* dwc, const float* attn, float* dsrc,
                             int B, int idf, int R, int L, void* stream) {
+    OG_ENTRY();
     if (B <= 0 || R <= 0 || L <= 0) return OG_OK;
     hipLaunchKernelGGL(attn_bu_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dwc, attn,
                        dsrc, idf, R, L);
@@ -440,6 +444,7 @@ int objgan_attn_bu_backward(const float* dwc, const float* attn, float* dsrc,
 int objgan_masked_max_forward(const float* f, const float* m, float* out, int B, int num, int R,
                               int P, long m_stride_b, long m_stride_r, long m_stride_c,
                               void* stream) {
+    OG_ENTRY();
     if (R < 1 || R > MM_RMAX) return OG_BAD_ARGS;
     if (B <= 0 || num <= 0 || P <= 0) return OG_OK;
     const size_t shm = sizeof(float) * (size_t)num * R;
@@ -454,6 +459,7 @@ int objgan_masked_max_forward(const float* f, const float* m, float* out, int B,
 int objgan_masked_max_backward(const float* f, const float* m, const float* dout, float* df,
                                int B, int num, int R, int P, long m_stride_b, long m_stride_r,
                                long m_stride_c, void* stream) {
+    OG_ENTRY();
     if (R < 1 || R > MM_RMAX) return OG_BAD_ARGS;
     if (B <= 0 || num <= 0 || P <= 0) return OG_OK;
     const size_t shm = sizeof(float) * (size_t)num * R * 2;
@@ -467,6 +473,7 @@ int objgan_masked_max_backward(const float* f, const float* m, const float* dout
 int objgan_softmax_strided_forward(const float* x, float* y, long outer, int dim, long inner,
                                    float scale, const int* lens, int nlens,
                                    const unsigned char* rowvalid, void* stream) {
+    OG_ENTRY();
     const long total = outer * inner;
     if (total <= 0 || dim <= 0) return OG_OK;
     hipLaunchKernelGGL(softmax_strided_fwd_kernel, dim3(og_stream_grid(total, 256)), dim3(256), 0,
@@ -476,6 +483,7 @@ int objgan_softmax_strided_forward(const float* x, float* y, long outer, int dim
 
 int objgan_softmax_strided_backward(const float* y, const float* dy, float* dx, long outer, int dim,
                                     long inner, float scale, void* stream) {
+    OG_ENTRY();
     const long total = outer * inner;
     if (total <= 0 || dim <= 0) return OG_OK;
     hipLaunchKernelGGL(softmax_strided_bwd_kernel, dim3(og_stream_grid(total, 256)), dim3(256), 0,

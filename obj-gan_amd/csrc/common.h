@@ -12,6 +12,11 @@
 #define OG_OK 1
 #define OG_BAD_ARGS 0
 
+// First statement of every exported entry point: HIP's last-error slot is per thread and sticky, so
+// an error left behind by somebody else's call (torch probing devices, a profiler attaching) would
+// otherwise be reported as the failure of our next launch.
+#define OG_ENTRY() ((void)hipGetLastError())
+
 static inline int og_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? OG_OK : -(int)e;

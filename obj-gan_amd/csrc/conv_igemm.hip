@@ -1825,6 +1825,7 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
                       int PH, int PW, int stride,
                       int OHf, int OWf, int osh, int osw, int ooh, int oow,
                       int act, int y_prezeroed, int wt_packed, int math, void* stream) {
+    OG_ENTRY();
     if (Tg < 1 || Tg > OG_MAX_TAPS) return OG_BAD_ARGS;
     if (math != 0 && math != 1) return OG_BAD_ARGS;
     if (Torig < 1 || Torig > 127) return OG_BAD_ARGS;
@@ -1880,6 +1881,7 @@ int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float*
                                 int N, int Cout, int OH, int OW, int Cin, int Torig,
                                 int Tg, const int* dh, const int* dw, const int* src_tap,
                                 int PH, int PW, int wt_packed, int math, void* stream) {
+    OG_ENTRY();
     if (Tg < 1 || Tg > 8) return OG_BAD_ARGS;
     if (math != 0 && math != 1) return OG_BAD_ARGS;
     if (Torig < 1 || Torig > 127) return OG_BAD_ARGS;
@@ -1927,6 +1929,7 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
                       int N, int Cin, int H, int W, int upsample, int pad_mode,
                       int Cout, int OH, int OW, int ksize, int stride, int pad,
                       int math, void* stream) {
+    OG_ENTRY();
     if (ksize != 1 && ksize != 3 && ksize != 4) return OG_BAD_ARGS;
     if (math != 0 && math != 1) return OG_BAD_ARGS;
     if (N <= 0 || Cout <= 0 || Cin <= 0) return OG_OK;
@@ -2034,6 +2037,7 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
 
 // ---- profiling control (see the note above the host section) ---------------------------------
 int objgan_prof_enable(int on) {
+    OG_ENTRY();
     g_prof_on = on ? 1 : 0;
     if (on) {
         g_prof_n = 0;
@@ -2052,6 +2056,7 @@ int objgan_prof_enable(int on) {
 // Sums the recorded launches per category (the caller must have synchronised the device).
 // ms, flops, count: arrays of 32.  Categories = kernel instances (see OG_CAT_* above).
 int objgan_prof_collect(double* ms, double* flops, long* count) {
+    OG_ENTRY();
     for (int i = 0; i < OG_PROF_CATS; ++i) { ms[i] = 0; flops[i] = 0; count[i] = 0; }
     for (int i = 0; i < g_prof_n; ++i) {
         float t = 0.f;

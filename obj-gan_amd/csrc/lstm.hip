@@ -79,6 +79,7 @@ int objgan_lstm_bidir_forward(const float* table, const long* captions, const in
                               const float* wt_ih, const float* wt_hh, const float* b_ih, const float* b_hh,
                               float* out, float* hn, int B, int L, int Lout, int I, int H, int ntoken,
                               void* stream) {
+    OG_ENTRY();
     if (4 * H > 1024 || H < 1 || I < 1 || L < 1 || Lout < 1 || ntoken < 1) return OG_BAD_ARGS;
     if (B <= 0) return OG_OK;
     const int threads = (4 * H + 63) / 64 * 64;

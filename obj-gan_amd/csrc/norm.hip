@@ -453,6 +453,7 @@ int objgan_norm_forward(const float* x, float* y, const float* residual,
                         float* sums, float* mean, float* rstd,
                         int N, int C, int HW, int per_channel, int mode,
                         float eps, float momentum, void* stream) {
+    OG_ENTRY();
     if (mode == OG_NORM_GLU && (C & 1)) return OG_BAD_ARGS;
     if (N <= 0 || C <= 0 || HW <= 0) return OG_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -492,6 +493,7 @@ int objgan_norm_forward(const float* x, float* y, const float* residual,
 int objgan_norm_apply(const float* x, float* y, const float* residual, const float* gamma, const float* beta,
                       const float* mean, const float* rstd, int N, int C, int HW, int per_channel, int mode,
                       void* stream) {
+    OG_ENTRY();
     if (mode == OG_NORM_GLU && (C & 1)) return OG_BAD_ARGS;
     if (N <= 0 || C <= 0 || HW <= 0) return OG_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -519,6 +521,7 @@ int objgan_norm_backward(const float* x, const float* dy, const float* mean, con
                          const float* gamma, const float* beta, float* bsums,
                          float* dx, float* dgamma, float* dbeta,
                          int N, int C, int HW, int per_channel, int mode, void* stream) {
+    OG_ENTRY();
     if (mode == OG_NORM_GLU && (C & 1)) return OG_BAD_ARGS;
     if (N <= 0 || C <= 0 || HW <= 0) return OG_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -553,6 +556,7 @@ int objgan_norm_backward(const float* x, const float* dy, const float* mean, con
 
 int objgan_act_backward(const float* dy, const float* y, float* dz, long total, int kind,
                         void* stream) {
+    OG_ENTRY();
     if (kind < 1 || kind > 4) return OG_BAD_ARGS;
     if (total <= 0) return OG_OK;
     hipLaunchKernelGGL(act_bwd_kernel, dim3(og_stream_grid(total, 256)), dim3(256), 0,
@@ -562,6 +566,7 @@ int objgan_act_backward(const float* dy, const float* y, float* dz, long total, 
 
 // out [C] is zeroed here, then out[c] = sum over n, i of x[n, c, i]
 int objgan_channel_sum(const float* x, float* out, int N, int C, int HW, void* stream) {
+    OG_ENTRY();
     if (N <= 0 || C <= 0 || HW <= 0) return OG_OK;
     hipStream_t s = (hipStream_t)stream;
     hipMemsetAsync(out, 0, sizeof(float) * C, s);

@@ -164,6 +164,7 @@ extern "C" {
 
 int objgan_bilinear_forward(const float* x, float* y, long planes, int ih, int iw, int oh, int ow,
                             void* stream) {
+    OG_ENTRY();
     if (planes <= 0 || oh <= 0 || ow <= 0) return OG_OK;
     const float sh = oh > 1 ? (float)(ih - 1) / (float)(oh - 1) : 0.f;
     const float sw = ow > 1 ? (float)(iw - 1) / (float)(ow - 1) : 0.f;
@@ -175,6 +176,7 @@ int objgan_bilinear_forward(const float* x, float* y, long planes, int ih, int i
 
 int objgan_bilinear_backward(const float* dy, float* dx, long planes, int ih, int iw, int oh,
                              int ow, void* stream) {
+    OG_ENTRY();
     if (planes <= 0 || ih <= 0 || iw <= 0) return OG_OK;
     const float sh = oh > 1 ? (float)(ih - 1) / (float)(oh - 1) : 0.f;
     const float sw = ow > 1 ? (float)(iw - 1) / (float)(ow - 1) : 0.f;
@@ -186,6 +188,7 @@ int objgan_bilinear_backward(const float* dy, float* dx, long planes, int ih, in
 
 // dy [planes, 2H, 2W] -> dx [planes, H, W]
 int objgan_sum2x2(const float* dy, float* dx, long planes, int h, int w, void* stream) {
+    OG_ENTRY();
     const long total = planes * h * w;
     if (total <= 0) return OG_OK;
     hipLaunchKernelGGL(sum2x2_kernel, dim3(og_stream_grid(total, 256)), dim3(256), 0,
@@ -195,6 +198,7 @@ int objgan_sum2x2(const float* dy, float* dx, long planes, int h, int w, void* s
 
 // dxp [planes, H+2, W+2] -> dx [planes, H, W]   (requires H, W >= 3)
 int objgan_reflect_fold(const float* dxp, float* dx, long planes, int h, int w, void* stream) {
+    OG_ENTRY();
     if (h < 3 || w < 3) return OG_BAD_ARGS;
     const long total = planes * h * w;
     if (total <= 0) return OG_OK;
@@ -205,6 +209,7 @@ int objgan_reflect_fold(const float* dxp, float* dx, long planes, int h, int w, 
 
 int objgan_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
                      float beta2, float eps, int step, float grad_scale, void* stream) {
+    OG_ENTRY();
     if (n <= 0) return OG_OK;
     if (step < 1) return OG_BAD_ARGS;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
@@ -216,6 +221,7 @@ int objgan_adam_step(float* p, const float* g, float* m, float* v, long n, float
 
 int objgan_ema_update(float* avg, const float* p, long n, float decay, float one_minus_decay,
                       void* stream) {
+    OG_ENTRY();
     if (n <= 0) return OG_OK;
     hipLaunchKernelGGL(ema_kernel, dim3(og_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream,
                        avg, p, n, decay, one_minus_decay);

@@ -242,6 +242,7 @@ int objgan_roi_align_forward(const float* features, const float* rois, float* ou
                              int num_rois, int roi_cols, int channels, int height, int width,
                              int aligned_height, int aligned_width, float spatial_scale,
                              void* stream) {
+    OG_ENTRY();
     if (roi_cols != 5) return OG_BAD_ARGS;                       // roi_align_cuda.c:18-22
     if (aligned_height * aligned_width > ROI_MAX_SAMPLES || aligned_height < 2 || aligned_width < 2)
         return OG_BAD_ARGS;
@@ -259,6 +260,7 @@ int objgan_roi_align_backward(const float* top_grad, const float* rois, float* b
                               int batch_size, int num_rois, int roi_cols, int channels,
                               int height, int width, int aligned_height, int aligned_width,
                               float spatial_scale, void* stream) {
+    OG_ENTRY();
     if (roi_cols != 5) return OG_BAD_ARGS;
     if (aligned_height * aligned_width > ROI_MAX_SAMPLES || aligned_height < 2 || aligned_width < 2)
         return OG_BAD_ARGS;
@@ -282,6 +284,7 @@ int objgan_roi_align_backward(const float* top_grad, const float* rois, float* b
 
 int objgan_avgpool2s1_forward(const float* in, float* out, long planes, int ih, int iw,
                               void* stream) {
+    OG_ENTRY();
     if (ih < 2 || iw < 2) return OG_BAD_ARGS;
     const long total = planes * (ih - 1) * (iw - 1);
     if (total <= 0) return OG_OK;
@@ -292,6 +295,7 @@ int objgan_avgpool2s1_forward(const float* in, float* out, long planes, int ih, 
 
 int objgan_avgpool2s1_backward(const float* grad_out, float* grad_in, long planes, int ih,
                                int iw, void* stream) {
+    OG_ENTRY();
     if (ih < 2 || iw < 2) return OG_BAD_ARGS;
     const long total = planes * ih * iw;
     if (total <= 0) return OG_OK;

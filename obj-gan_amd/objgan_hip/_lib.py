@@ -82,6 +82,10 @@ def load(build_if_missing=True):
         if not build_if_missing:
             raise ObjganHipError("libobjgan_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
         _build.build(verbose=False)
+    # torch first: it ships its own libamdhip64, and the library's launches go to torch's streams.
+    # Loaded the other way round, libobjgan_hip.so binds the system HIP runtime, the process ends up
+    # with two runtimes, and every launch on a torch stream fails with hipErrorNoDevice (100).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(path)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError if the symbol is missing: loud by design

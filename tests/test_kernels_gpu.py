@@ -572,3 +572,25 @@ def test_conv_never_consumes_memory_past_the_input_tensor(dev):
         xr, wr = xc.clone().requires_grad_(), w.clone().requires_grad_()
         tr.conv2d(xr, wr, None, 1, k // 2).backward(dyc)
         assert rel_l2(wd.grad, wr.grad) < TOL and rel_l2(xd.grad, xr.grad) < TOL
+
+
+def test_library_loaded_before_torch_still_launches(dev):
+    """`python __graft_entry__.py --smoke` loads libobjgan_hip.so (build()) before anything touches
+    torch.cuda.  The loader must bring torch's HIP runtime in first: with the system runtime bound
+    instead, every launch on a torch stream fails with hipErrorNoDevice."""
+    import subprocess
+    import sys
+    from conftest import ROOT, PKG
+    code = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "from objgan_hip import _lib\n"
+        "_lib.load(build_if_missing=False)\n"
+        "import torch\n"
+        "from objgan_hip import ops\n"
+        "x = torch.ones(1, 4, 8, 8, device='cuda')\n"
+        "y = ops.bilinear_resize(x, 16, 16)\n"
+        "torch.cuda.synchronize()\n"
+        "assert float((y - 1).abs().max()) == 0.0\n"
+        "print('ok')\n" % (ROOT, PKG))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
