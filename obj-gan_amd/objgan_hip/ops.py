@@ -114,7 +114,7 @@ def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, tran
               OHf, OWf, osh, osw, ooh, oow, act, int(y_prezeroed), packed, _MATH["mode"], _stream())
 
 
-def _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad_h, pad_w, LH, LW):
+def _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad_h, pad_w, LH, LW, cacheable=True):
     """dX of a stride-2 conv in ONE launch when every output parity phase has the same tap count
     (k even, even sizes); returns None when the shape does not qualify."""
     KH, KW = (k, k) if isinstance(k, int) else k
@@ -135,7 +135,7 @@ def _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad_h, pad_w, LH, LW):
         return None
     dx = torch.empty((N, Cin, LH, LW), dtype=_F32, device=g.device)
     n = 4 * Cin * Tg * ((Cout + 15) // 16 * 16)
-    key = _pack_key(w, 2, st, False)
+    key = _pack_key(w, 2, st, False) if cacheable else None
     ent = _PACK_CACHE.get(key) if key is not None else None
     if ent is not None and ent[0] is w:
         wt, packed = ent[1], 1
@@ -154,6 +154,79 @@ def conv_out_size(L, k, s, p):
     return (L + 2 * p - k) // s + 1
 
 
+def _conv_fwd(x, w, bias, stride, pad, refl, upsample, act):
+    """y = act(conv(x, w) + bias); x [N, Cin, H, W] (nearest x2 lifted when `upsample`), w [Cout, Cin, k, k]."""
+    N, Cin, H, W = x.shape
+    Cout, k = w.shape[0], w.shape[2]
+    LH, LW = (2 * H, 2 * W) if upsample else (H, W)
+    OH, OW = conv_out_size(LH, k, stride, pad), conv_out_size(LW, k, stride, pad)
+    y = torch.empty((N, Cout, OH, OW), dtype=_F32, device=x.device)
+    dh = [kh - pad for kh in range(k) for kw in range(k)]
+    dw = [kw - pad for kh in range(k) for kw in range(k)]
+    st = list(range(k * k))
+    _igemm(x, w, bias, y, N, Cin, H, W, upsample, refl, Cout, Cin, k * k, 0,
+           dh, dw, st, OH, OW, stride, OH, OW, 1, 1, 0, 0, _ACT[act])
+    return y
+
+
+def _conv_dgrad(g, w, N, Cin, H, W, stride, pad, refl, upsample, cacheable=True):
+    """Gradient w.r.t. the input [N, Cin, H, W] of conv(x, w) given g = dL/d(conv output)."""
+    Cout, k = w.shape[0], w.shape[2]
+    OH, OW = g.shape[2], g.shape[3]
+    LH, LW = (2 * H, 2 * W) if upsample else (H, W)
+    if stride == 1:
+        pe = 0 if refl else pad            # reflect: gradient w.r.t. the padded tensor first
+        TH, TW = (LH + 2 * pad, LW + 2 * pad) if refl else (LH, LW)
+        dh = [pe - kh for kh in range(k) for kw in range(k)]
+        dw = [pe - kw for kh in range(k) for kw in range(k)]
+        st = list(range(k * k))
+        dxl = torch.empty((N, Cin, TH, TW), dtype=_F32, device=g.device)
+        _igemm(g, w, None, dxl, N, Cout, OH, OW, 0, 0, Cout, Cin, k * k, 1,
+               dh, dw, st, TH, TW, 1, TH, TW, 1, 1, 0, 0, 0)
+        if refl:
+            folded = torch.empty((N, Cin, LH, LW), dtype=_F32, device=g.device)
+            _lib.call("objgan_reflect_fold", _p(dxl), _p(folded), N * Cin, LH, LW, _stream())
+            dxl = folded
+    elif stride == 2:
+        if refl:
+            raise _lib.ObjganHipError("stride-2 reflect conv is not on the hot path")
+        dxl = _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad, pad, LH, LW, cacheable)
+        phases = range(2) if dxl is None else ()
+        if dxl is None:
+            dxl = torch.zeros((N, Cin, LH, LW), dtype=_F32, device=g.device)
+        for ph in phases:
+            khs = [kh for kh in range(k) if (ph + pad - kh) % 2 == 0]
+            PHg = (LH - ph + 1) // 2
+            for pw in range(2):
+                kws = [kw for kw in range(k) if (pw + pad - kw) % 2 == 0]
+                PWg = (LW - pw + 1) // 2
+                if PHg <= 0 or PWg <= 0:
+                    continue
+                dh = [(ph + pad - kh) // 2 for kh in khs for kw in kws]
+                dw = [(pw + pad - kw) // 2 for kh in khs for kw in kws]
+                st = [kh * k + kw for kh in khs for kw in kws]
+                if not st:      # no tap reaches this phase: gradient is zero there
+                    dh, dw, st = [0], [0], [-1]
+                _igemm(g, w, None, dxl, N, Cout, OH, OW, 0, 0, Cout, Cin, k * k, 1,
+                       dh, dw, st, PHg, PWg, 1, LH, LW, 2, 2, ph, pw, 0, y_prezeroed=1)
+    else:
+        raise _lib.ObjganHipError("conv2d backward: stride %d not supported" % stride)
+    if upsample:
+        dx = torch.empty((N, Cin, H, W), dtype=_F32, device=g.device)
+        _lib.call("objgan_sum2x2", _p(dxl), _p(dx), N * Cin, H, W, _stream())
+        return dx
+    return dxl
+
+
+def _conv_wgrad(x, g, Cout, k, stride, pad, refl, upsample):
+    """Gradient w.r.t. the filter bank [Cout, Cin, k, k] of conv(x, w) given g = dL/d(conv output)."""
+    N, Cin, H, W = x.shape
+    dw_ = torch.zeros((Cout, Cin, k, k), dtype=_F32, device=x.device)
+    _lib.call("objgan_conv_wgrad", _p(x), _p(g), _p(dw_), N, Cin, H, W, int(upsample), refl,
+              Cout, g.shape[2], g.shape[3], k, stride, pad, _MATH["mode"], _stream())
+    return dw_
+
+
 class _Conv2dFn(torch.autograd.Function):
     """conv2d with the gather-side fusions of the hot path.
 
@@ -168,23 +241,13 @@ class _Conv2dFn(torch.autograd.Function):
         _chk(x, w, bias)
         x = _c(x)
         w = _c(w)
-        N, Cin, H, W = x.shape
-        Cout, Cin2, KH, KW = w.shape
-        if Cin2 != Cin or KH != KW:
+        if w.shape[1] != x.shape[1] or w.shape[2] != w.shape[3]:
             raise _lib.ObjganHipError("conv2d: bad weight shape %s for input %s" % (tuple(w.shape), tuple(x.shape)))
-        k = KH
-        LH, LW = (2 * H, 2 * W) if upsample else (H, W)
-        OH, OW = conv_out_size(LH, k, stride, pad), conv_out_size(LW, k, stride, pad)
         refl = 1 if pad_mode == "reflect" else 0
         if refl and pad != 1:
             raise _lib.ObjganHipError("reflect padding is implemented for pad=1")
-        y = torch.empty((N, Cout, OH, OW), dtype=_F32, device=x.device)
-        dh = [kh - pad for kh in range(k) for kw in range(k)]
-        dw = [kw - pad for kh in range(k) for kw in range(k)]
-        st = list(range(k * k))
-        _igemm(x, w, bias, y, N, Cin, H, W, upsample, refl, Cout, Cin, k * k, 0,
-               dh, dw, st, OH, OW, stride, OH, OW, 1, 1, 0, 0, _ACT[act])
-        ctx.cfg = (stride, pad, refl, bool(upsample), act, k)
+        y = _conv_fwd(x, w, bias, stride, pad, refl, upsample, act)
+        ctx.cfg = (stride, pad, refl, bool(upsample), act, w.shape[2])
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, w, y if act not in (None, "none") else None)
         return y
@@ -197,68 +260,105 @@ class _Conv2dFn(torch.autograd.Function):
         Cout = w.shape[0]
         dy = _c(dy)
         _chk(dy)
-        OH, OW = dy.shape[2], dy.shape[3]
         if act not in (None, "none"):
             g = torch.empty_like(dy)
             _lib.call("objgan_act_backward", _p(dy), _p(y), _p(g), dy.numel(), _ACT[act], _stream())
         else:
             g = dy
         dx = dw_ = db = None
-        LH, LW = (2 * H, 2 * W) if upsample else (H, W)
         if ctx.needs_input_grad[0]:
-            if stride == 1:
-                pe = 0 if refl else pad            # reflect: gradient w.r.t. the padded tensor first
-                TH, TW = (LH + 2 * pad, LW + 2 * pad) if refl else (LH, LW)
-                dh = [pe - kh for kh in range(k) for kw in range(k)]
-                dw = [pe - kw for kh in range(k) for kw in range(k)]
-                st = list(range(k * k))
-                dxl = torch.empty((N, Cin, TH, TW), dtype=_F32, device=x.device)
-                _igemm(g, w, None, dxl, N, Cout, OH, OW, 0, 0, Cout, Cin, k * k, 1,
-                       dh, dw, st, TH, TW, 1, TH, TW, 1, 1, 0, 0, 0)
-                if refl:
-                    folded = torch.empty((N, Cin, LH, LW), dtype=_F32, device=x.device)
-                    _lib.call("objgan_reflect_fold", _p(dxl), _p(folded), N * Cin, LH, LW, _stream())
-                    dxl = folded
-            elif stride == 2:
-                if refl:
-                    raise _lib.ObjganHipError("stride-2 reflect conv is not on the hot path")
-                dxl = _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad, pad, LH, LW)
-                phases = range(2) if dxl is None else ()
-                if dxl is None:
-                    dxl = torch.zeros((N, Cin, LH, LW), dtype=_F32, device=x.device)
-                for ph in phases:
-                    khs = [kh for kh in range(k) if (ph + pad - kh) % 2 == 0]
-                    PHg = (LH - ph + 1) // 2
-                    for pw in range(2):
-                        kws = [kw for kw in range(k) if (pw + pad - kw) % 2 == 0]
-                        PWg = (LW - pw + 1) // 2
-                        if PHg <= 0 or PWg <= 0:
-                            continue
-                        dh = [(ph + pad - kh) // 2 for kh in khs for kw in kws]
-                        dw = [(pw + pad - kw) // 2 for kh in khs for kw in kws]
-                        st = [kh * k + kw for kh in khs for kw in kws]
-                        if not st:      # no tap reaches this phase: gradient is zero there
-                            dh, dw, st = [0], [0], [-1]
-                        _igemm(g, w, None, dxl, N, Cout, OH, OW, 0, 0, Cout, Cin, k * k, 1,
-                               dh, dw, st, PHg, PWg, 1, LH, LW, 2, 2, ph, pw, 0, y_prezeroed=1)
-            else:
-                raise _lib.ObjganHipError("conv2d backward: stride %d not supported" % stride)
-            if upsample:
-                dx = torch.empty((N, Cin, H, W), dtype=_F32, device=x.device)
-                _lib.call("objgan_sum2x2", _p(dxl), _p(dx), N * Cin, H, W, _stream())
-            else:
-                dx = dxl
+            dx = _conv_dgrad(g, w, N, Cin, H, W, stride, pad, refl, upsample)
         if ctx.needs_input_grad[1]:
-            dw_ = torch.zeros_like(w)
-            _lib.call("objgan_conv_wgrad", _p(x), _p(g), _p(dw_), N, Cin, H, W, int(upsample), refl,
-                      Cout, OH, OW, k, stride, pad, _MATH["mode"], _stream())
+            dw_ = _conv_wgrad(x, g, Cout, k, stride, pad, refl, upsample)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(Cout, dtype=_F32, device=x.device)
-            _lib.call("objgan_channel_sum", _p(g), _p(db), N, Cout, OH * OW, _stream())
+            _lib.call("objgan_channel_sum", _p(g), _p(db), N, Cout, g.shape[2] * g.shape[3], _stream())
         return dx, dw_, db, None, None, None, None, None
 
 
+# ---- nearest x2 upsample + 3x3 conv (upBlock, reference model.py:43-49) as its four output-parity
+# phases.  On the lifted map the three taps of an axis read only two distinct source rows:
+#   y[2i]   = w0 x[i-1] + (w1 + w2) x[i]        y[2i+1] = (w0 + w1) x[i] + w2 x[i+1]
+# so every phase is a 2x2 convolution of the LOW-resolution input with pre-summed filters: 16
+# MACs per source pixel and channel pair instead of 36.  Written with a 4x4 bank W4 = A w A^T
+# (A below), y is exactly the TRANSPOSED stride-2 4x4 convolution of x -- the one-launch phased
+# data-gradient kernel -- and the gradients are the forward / weight gradient of that stride-2
+# convolution: three kernels the discriminators already use, nothing new on the device.  The only
+# arithmetic difference to the lifted form is the pre-summation of filter taps (re-association at
+# the 1e-7 level).  fp32 math only: the bf16 mode is defined on the rounded ORIGINAL filters.
+_UP_A = ((0., 0., 1.), (0., 1., 1.), (1., 1., 0.), (1., 0., 0.))
+_UP4 = {}           # (weight address, shape) -> [w, _version, epoch, W4]
+
+
+def _up_matrix(device):
+    return torch.tensor(_UP_A, dtype=_F32, device=device)
+
+
+def _up_bank(w):
+    """W4 [Cin, Cout, 4, 4] of a [Cout, Cin, 3, 3] filter bank; rebuilt (in place) only when the
+    weights changed, so that its packed images stay cached as well."""
+    ep = getattr(w, "_og_epoch", None)
+    cacheable = ep is not None or not w.requires_grad
+    A = _up_matrix(w.device)
+    if not cacheable:
+        return torch.einsum("pk,mckl,ql->cmpq", A, w.detach(), A).contiguous(), False
+    key = (w.data_ptr(), tuple(w.shape))
+    ent = _UP4.get(key)
+    epv = ep[0] if ep is not None else -1
+    if ent is not None and ent[0] is w and ent[1] == w._version and ent[2] == epv:
+        return ent[3], True
+    W4 = ent[3] if ent is not None and ent[0] is w else torch.empty(
+        (w.shape[1], w.shape[0], 4, 4), dtype=_F32, device=w.device)
+    W4.copy_(torch.einsum("pk,mckl,ql->cmpq", A, w.detach(), A))      # in place: bumps W4._version
+    if len(_UP4) >= 256:
+        _UP4.clear()
+    _UP4[key] = [w, w._version, epv, W4]
+    return W4, True
+
+
+def _up_phased_ok(x, w, bias, stride, pad, pad_mode, upsample, act):
+    return (upsample and stride == 1 and pad == 1 and pad_mode != "reflect" and bias is None
+            and act in (None, "none") and w.shape[2] == 3 and w.shape[3] == 3 and w.shape[0] > 32
+            and x.shape[1] > 32 and x.shape[2] >= 2 and x.shape[3] >= 2 and _MATH["mode"] == 0
+            and float(x.shape[0]) * max(x.shape[1], 4 * w.shape[0]) * x.shape[2] * x.shape[3] * 4.0 < 4.0e9)
+
+
+class _UpConv3x3Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        _chk(x, w)
+        x = _c(x)
+        w = _c(w)
+        N, C, H, W = x.shape
+        M = w.shape[0]
+        if w.shape[1] != C:
+            raise _lib.ObjganHipError("conv2d: bad weight shape %s for input %s" % (tuple(w.shape), tuple(x.shape)))
+        W4, cacheable = _up_bank(w)
+        # transposed stride-2 conv of x: "input gradient" of the virtual conv [N, M, 2H, 2W] -> [N, C, H, W]
+        y = _conv_dgrad(x, W4, N, M, 2 * H, 2 * W, 2, 1, 0, False, cacheable)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        _chk(dy)
+        C, M = x.shape[1], w.shape[0]
+        dx = dw_ = None
+        if ctx.needs_input_grad[0]:
+            W4, _ = _up_bank(w)
+            dx = _conv_fwd(dy, W4, None, 2, 1, 0, False, None)
+        if ctx.needs_input_grad[1]:
+            dW4 = _conv_wgrad(dy, x, C, 4, 2, 1, 0, False)             # [C, M, 4, 4]
+            A = _up_matrix(x.device)
+            dw_ = torch.einsum("pk,cmpq,ql->mckl", A, dW4, A).contiguous()
+        return dx, dw_
+
+
 def conv2d(x, w, bias=None, stride=1, pad=0, pad_mode="zeros", upsample=False, act=None):
+    if _up_phased_ok(x, w, bias, stride, pad, pad_mode, upsample, act):
+        return _UpConv3x3Fn.apply(x, w)
     return _Conv2dFn.apply(x, w, bias, stride, pad, pad_mode, upsample, act)
 
 

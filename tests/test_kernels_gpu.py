@@ -49,6 +49,9 @@ CONV_CASES = [
     (2, 15, 384, 384, 40, 4, 2, 1, "zeros", False, False, "lrelu"),     # dgrad phases with M = 15: thin T=4
     # one-launch four-phase data gradient (Cin > 32, even sizes)
     (2, 48, 24, 40, 64, 4, 2, 1, "zeros", False, False, None),
+    # upBlock convs on the four-phase 2x2 form (pre-summed taps): ragged channel counts, odd height
+    (2, 48, 24, 40, 96, 3, 1, 1, "zeros", True, False, None),
+    (1, 194, 13, 16, 70, 3, 1, 1, "zeros", True, False, None),
 ]
 
 
@@ -594,3 +597,26 @@ def test_library_loaded_before_torch_still_launches(dev):
         "print('ok')\n" % (ROOT, PKG))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_upblock_conv_takes_the_phased_form_and_follows_weight_updates(dev):
+    """nearest x2 + 3x3 conv with more than 32 channels on both sides runs as the transposed
+    stride-2 4x4 convolution with pre-summed taps (16 instead of 36 MACs per source pixel); its 4x4
+    bank is cached per weight tensor and must be rebuilt after an in-place update."""
+    ops, tr = _ops(), _tref()
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 40, 8, 8, generator=g)
+    w = torch.randn(64, 40, 3, 3, generator=g) / 19.0
+    xd = x.to(dev)
+    wd = w.to(dev)                                    # frozen: cacheable
+    assert ops._up_phased_ok(xd, wd, None, 1, 1, "zeros", True, None)
+    assert not ops._up_phased_ok(xd, wd, None, 1, 1, "reflect", True, None)
+    assert not ops._up_phased_ok(xd, wd[:16], None, 1, 1, "zeros", True, None)
+    y1 = ops.conv2d(xd, wd, None, 1, 1, "zeros", True, None)
+    assert rel_l2(y1, tr.conv2d(x, w, None, 1, 1, "zeros", True, None)) < TOL
+    bank1, cached = ops._up_bank(wd)
+    assert cached and ops._up_bank(wd)[0] is bank1
+    wd.mul_(-0.5)                                     # in-place update: _version changes
+    y2 = ops.conv2d(xd, wd, None, 1, 1, "zeros", True, None)
+    torch.cuda.synchronize()
+    assert rel_l2(y2, tr.conv2d(x, -0.5 * w, None, 1, 1, "zeros", True, None)) < TOL
