@@ -219,7 +219,10 @@ def main():
                 traffic = None          # HBM bytes / launch from the committed rocprofv3 --pmc passes
                 if os.path.exists(PMC_TRAFFIC_JSON):
                     try:
-                        ent = json.load(open(PMC_TRAFFIC_JSON)).get("kernels", {}).get(name)
+                        kern = json.load(open(PMC_TRAFFIC_JSON)).get("kernels", {})
+                        # the profiler prints every template argument, the category names only the
+                        # leading ones: "conv_igemm3_kernel<6, false>" is "...<6, false, false>" (fp32)
+                        ent = kern.get(name) or kern.get(name[:-1] + ", false>" if name.endswith(">") else name)
                         traffic = ent["hbm_bytes_per_launch"] if ent else None
                     except (ValueError, KeyError, OSError):
                         traffic = None
