@@ -115,6 +115,23 @@ class ArenaAdam(object):
                 "exp_avg_sq": self.arena.exp_avg_sq}
 
 
+def category_embeddings(glove_weight, cat_labels, cat_label_lens, sorted_cat_label_indices, num_cats):
+    """Mean GloVe vector of one- and two-word category names; rows of longer names stay zero and
+    only the first `num_cats` rows are filled (both as in reference trainer.py:226-242).
+    `cat_labels` / `cat_label_lens` are sorted by name length, `sorted_cat_label_indices` is the
+    permutation back to file order (miscc/load.py load_cat_label)."""
+    w = glove_weight.detach()
+    labels = cat_labels.to(w.device)
+    lens = cat_label_lens.to(w.device)[:labels.size(0)]
+    raw = w[labels.reshape(-1)].view(labels.size(0), labels.size(1), -1)
+    first = raw[:, 0]
+    second = raw[:, 1] if raw.size(1) > 1 else torch.zeros_like(first)
+    out = torch.where((lens == 1).unsqueeze(1), first, torch.zeros_like(first))
+    out = torch.where((lens == 2).unsqueeze(1), (first + second) / 2., out)
+    out[num_cats:] = 0
+    return out[sorted_cat_label_indices.to(w.device)]
+
+
 def _dist_on():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
@@ -143,6 +160,10 @@ class condGANTrainer(object):
         self.image_encoder = getattr(dataset, "image_encoder", None)
         self.inception_model = getattr(dataset, "inception_model", None)
         self.glove_emb = getattr(dataset, "glove_embed", None)       # nn.Embedding(n, 50), frozen
+        # category-name tables of a real dataset (reference trainer.py:50-55); absent for synthetic batches
+        for name in ("n_words", "ixtoword", "cats_index_dict", "cat_labels", "cat_label_lens",
+                     "sorted_cat_label_indices"):
+            setattr(self, name, getattr(dataset, name, None))
         self.rank = dist.get_rank() if _dist_on() else 0
         self.world = dist.get_world_size() if _dist_on() else 1
         self.is_stream = torch.cuda.Stream(device=self.device) if self.inception_model is not None else None
@@ -199,6 +220,12 @@ class condGANTrainer(object):
     def prepare_labels(self):
         return torch.arange(self.batch_size, dtype=torch.long, device=self.device)
 
+    def prepare_cat_emb(self):
+        """[num categories, 50] GloVe embedding of every category name, in categories.txt order
+        (reference trainer.py:226-242)."""
+        return category_embeddings(self.glove_emb.weight, self.cat_labels, self.cat_label_lens,
+                                   self.sorted_cat_label_indices, len(self.cats_index_dict)).to(self.device)
+
     def setup(self):
         """Build networks, arenas, the EMA copy and the per-run constants."""
         (self.text_encoder, self.image_encoder, self.netG, self.netsPatD, self.netsShpD,
@@ -207,6 +234,9 @@ class condGANTrainer(object):
          self.optimizerObjLSD) = self.define_optimizers(self.netG, self.netsPatD, self.netsShpD,
                                                         self.netObjSSD, self.netObjLSD)
         self.avg_param_G = self.optimizerG.arena.flat.clone()      # EMA of G, flat
+        if self.glove_emb is not None:
+            self.glove_emb.to(self.device).eval()
+        self.clabels_emb = self.prepare_cat_emb() if self.cat_labels is not None else None
         self.match_labels = self.prepare_labels()
         self.noise = torch.empty(self.batch_size, cfg.GAN.Z_DIM, device=self.device)
         self.gen_iterations = 0
@@ -360,6 +390,9 @@ class condGANTrainer(object):
             start_t = time.time()
             predictions = []
             for step, batch in enumerate(self.data_loader):
+                if not isinstance(batch, dict):       # the reference loader's collated 12-tuple
+                    from trainDataset import prepare_data, batch_dict
+                    batch = batch_dict(prepare_data(batch, self.device, self.num_classes), self.clabels_emb)
                 log_now = (self.gen_iterations + 1) % self.print_interval == 0
                 out = self.train_step(batch, want_logs=log_now)
                 if "is_pred" in out:
