@@ -4,6 +4,8 @@ Each kernel is compared with the CPU oracle (oracle/torch_ref.py plain-PyTorch f
 C restatement) on the same seeded inputs.  Tolerance: fp32 rel-L2 <= 1e-4 for single operators
 (BASELINE.json allows 1e-3 end to end); ROIAlign forward is BIT-EXACT.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -620,3 +622,20 @@ def test_upblock_conv_takes_the_phased_form_and_follows_weight_updates(dev):
     y2 = ops.conv2d(xd, wd, None, 1, 1, "zeros", True, None)
     torch.cuda.synchronize()
     assert rel_l2(y2, tr.conv2d(x, -0.5 * w, None, 1, 1, "zeros", True, None)) < TOL
+
+
+@pytest.mark.skipif(os.environ.get("OG_TEST_EXPERIMENTAL") != "1",
+                    reason="experimental kernel variants are opt-in: OG_TEST_EXPERIMENTAL=1")
+@pytest.mark.parametrize("env", ["OG_KORDER=1", "OG_ADIRECT=1"])
+def test_experimental_conv_variants_in_a_subprocess(dev, env):
+    """The env-selected variants (chunk-major K order, LDS-free deep-prefetch 32-row form) are read
+    once per process, so they are exercised by re-running the conv tests in a child process."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    k, v = env.split("=")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels_gpu.py"),
+                          "-m", "gpu", "-x", "-q", "-k", "conv2d or upblock or inception or never_consumes"],
+                         env=dict(os.environ, **{k: v, "OG_TEST_EXPERIMENTAL": "0"}),
+                         capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stdout[-3000:]
