@@ -1,0 +1,86 @@
+"""Host-side logic of the conv wrappers that needs no GPU: the algebra of the phased upBlock
+convolution (ops._UpConv3x3Fn) with the three device kernels replaced by their torch CPU
+definitions, and the filter-bank caches."""
+import torch
+import torch.nn.functional as F
+
+
+def _cpu_kernels(ops, monkeypatch):
+    """conv forward / input gradient / weight gradient as torch defines them (same contracts as
+    ops._conv_fwd / _conv_dgrad / _conv_wgrad)."""
+    monkeypatch.setattr(ops, "_conv_fwd",
+                        lambda x, w, bias, stride, pad, refl, upsample, act: F.conv2d(x, w, None, stride, pad))
+    monkeypatch.setattr(ops, "_conv_dgrad",
+                        lambda g, w, N, Cin, H, W, stride, pad, refl, upsample, cacheable=True:
+                        torch.nn.grad.conv2d_input((N, Cin, H, W), w, g, stride=stride, padding=pad))
+    monkeypatch.setattr(ops, "_conv_wgrad",
+                        lambda x, g, Cout, k, stride, pad, refl, upsample:
+                        torch.nn.grad.conv2d_weight(x, (Cout, x.shape[1], k, k), g, stride=stride, padding=pad))
+    monkeypatch.setattr(ops, "_chk", lambda *a: None)
+
+
+def test_phased_upblock_conv_is_the_lifted_conv(monkeypatch):
+    """nearest x2 + 3x3 conv == transposed stride-2 4x4 conv with W4 = A w A^T (forward), and its
+    gradients are the stride-2 forward / weight gradient folded back with A^T . A."""
+    from objgan_hip import ops
+    _cpu_kernels(ops, monkeypatch)
+    g = torch.Generator().manual_seed(0)
+    for (N, C, H, W, M) in [(2, 40, 8, 8, 96), (1, 33, 5, 7, 34), (2, 48, 4, 4, 64)]:
+        x = torch.randn(N, C, H, W, generator=g)
+        w = torch.randn(M, C, 3, 3, generator=g) / (C * 9) ** 0.5
+        xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+        yr = F.conv2d(F.interpolate(xr, scale_factor=2, mode="nearest"), wr, padding=1)
+        gy = torch.randn(yr.shape, generator=g)
+        yr.backward(gy)
+        xd, wd = x.clone().requires_grad_(), w.clone().requires_grad_()
+        assert ops._up_phased_ok(xd, wd, None, 1, 1, "zeros", True, None)
+        yd = ops.conv2d(xd, wd, None, 1, 1, "zeros", True, None)
+        yd.backward(gy)
+        rel = lambda a, b: float((a - b).norm() / b.norm())   # noqa: E731
+        assert rel(yd.detach(), yr.detach()) < 2e-6
+        assert rel(xd.grad, xr.grad) < 2e-6 and rel(wd.grad, wr.grad) < 2e-6
+
+
+def test_phased_form_is_only_taken_where_it_is_defined():
+    from objgan_hip import ops
+    x = torch.zeros(2, 40, 8, 8)
+    w = torch.zeros(64, 40, 3, 3)
+    ok = lambda *a, **k: ops._up_phased_ok(*a, **k)          # noqa: E731
+    assert ok(x, w, None, 1, 1, "zeros", True, None)
+    assert not ok(x, w, None, 1, 1, "zeros", False, None)     # no upsample
+    assert not ok(x, w, torch.zeros(64), 1, 1, "zeros", True, None)
+    assert not ok(x, w, None, 1, 1, "zeros", True, "lrelu")
+    assert not ok(x, w, None, 2, 1, "zeros", True, None)
+    assert not ok(x, w, None, 1, 1, "reflect", True, None)
+    assert not ok(x, w[:32], None, 1, 1, "zeros", True, None)  # thin outputs stay on the VALU kernels
+    assert not ok(x[:, :32], w[:, :32], None, 1, 1, "zeros", True, None)
+    ops.set_conv_math("bf16")                                  # bf16 mode is defined on the original filters
+    try:
+        assert not ok(x, w, None, 1, 1, "zeros", True, None)
+    finally:
+        ops.set_conv_math("fp32")
+
+
+def test_up_bank_cache_follows_weight_updates():
+    from objgan_hip import ops
+    A = ops._up_matrix("cpu")
+    w = torch.randn(64, 40, 3, 3)
+    b1, cached = ops._up_bank(w)
+    assert cached and ops._up_bank(w)[0] is b1
+    assert torch.allclose(b1, torch.einsum("pk,mckl,ql->cmpq", A, w, A))
+    w.mul_(2.0)                                               # torch-side edit: _version
+    b2, _ = ops._up_bank(w)
+    assert b2 is b1 and torch.allclose(b2, torch.einsum("pk,mckl,ql->cmpq", A, w, A))
+    # optimizer-owned weights: the arena epoch vouches for raw-pointer updates
+    p = torch.nn.Parameter(torch.randn(64, 40, 3, 3))
+    p._og_epoch = [0]
+    b3, cached = ops._up_bank(p)
+    assert cached
+    with torch.no_grad():
+        p.data.add_(1.0)                                      # what the fused Adam kernel does: no version bump
+    p._og_epoch[0] += 1
+    b4, _ = ops._up_bank(p)
+    assert b4 is b3 and torch.allclose(b4, torch.einsum("pk,mckl,ql->cmpq", A, p.detach(), A))
+    # trainable tensors nobody vouches for are recomposed every call
+    q = torch.randn(64, 40, 3, 3, requires_grad=True)
+    assert ops._up_bank(q)[1] is False
