@@ -625,17 +625,22 @@ def test_upblock_conv_takes_the_phased_form_and_follows_weight_updates(dev):
 
 
 @pytest.mark.skipif(os.environ.get("OG_TEST_EXPERIMENTAL") != "1",
-                    reason="experimental kernel variants are opt-in: OG_TEST_EXPERIMENTAL=1")
-@pytest.mark.parametrize("env", ["OG_KORDER=1", "OG_ADIRECT=1"])
-def test_experimental_conv_variants_in_a_subprocess(dev, env):
-    """The env-selected variants (chunk-major K order, LDS-free deep-prefetch 32-row form) are read
-    once per process, so they are exercised by re-running the conv tests in a child process."""
+                    reason="experimental variants are opt-in: OG_TEST_EXPERIMENTAL=1")
+@pytest.mark.parametrize("env,tests,expr", [
+    ("OG_KORDER=1", "test_kernels_gpu.py", "conv2d or upblock or inception or never_consumes"),
+    ("OG_ADIRECT=1", "test_kernels_gpu.py", "conv2d or upblock or inception or never_consumes"),
+    ("OBJGAN_WGRAD_INPLACE=1", "test_modules_gpu.py", "training_step or discriminator or generator"),
+])
+def test_experimental_variants_in_a_subprocess(dev, env, tests, expr):
+    """The env-selected variants (chunk-major K order, LDS-free deep-prefetch 32-row form, weight
+    gradients accumulated straight into the optimizer arena) are read once per process, so they are
+    exercised by re-running the affected tests in a child process."""
     import subprocess
     import sys
     from conftest import ROOT
     k, v = env.split("=")
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels_gpu.py"),
-                          "-m", "gpu", "-x", "-q", "-k", "conv2d or upblock or inception or never_consumes"],
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", tests),
+                          "-m", "gpu", "-x", "-q", "-k", expr],
                          env=dict(os.environ, **{k: v, "OG_TEST_EXPERIMENTAL": "0"}),
-                         capture_output=True, text=True, timeout=1200)
+                         capture_output=True, text=True, timeout=1800)
     assert out.returncode == 0, out.stdout[-3000:]
