@@ -1227,7 +1227,10 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
 // Weight gradient on the v3 scheme: the gathered-x fragment goes straight to registers (lane =
 // (column l & 31 of the wave, pixel half l >> 5)), dy rows through LDS (TM > 1) or direct (TM = 1).
 // Requires OW % 8 == 0 and (OH*OW) % 16 == 0 like v2.
-template <int TM, bool BF = false>
+// B128 (experimental, OG_WGRAD_B128=1): on the stride-1 interior fast path the eight consecutive pixels
+// of a lane are fetched as two 16-byte loads (4-byte aligned) instead of eight dwords -- the lanes of a
+// wave sit on different (channel, tap) planes, so every gather instruction touches ~20 cache lines.
+template <int TM, bool BF = false, bool B128 = false>
 __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, const int KS) {
     constexpr int BM = 32 * TM;
     constexpr int BN = 128;
@@ -1309,7 +1312,12 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, con
         const bool interior = iw0 >= 0 && iw0 + 7 * a.stride < a.LW;
         if (!us && (a.stride == 1 || a.stride == 2) && __all(interior || !row_ok)) {
             const unsigned vo = row_ok ? (rbase + (unsigned)iw0) * 4u : OG_OOB;
-            if (a.stride == 1) {
+            if (B128 && a.stride == 1) {
+                const f32x4 q0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, vo, 0, 0));
+                const f32x4 q1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, vo + 16u, 0, 0));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { rb[i] = q0[i]; rb[4 + i] = q1[i]; }
+            } else if (a.stride == 1) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
                     rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, vo + 4u * i, 0, 0));
@@ -1703,6 +1711,11 @@ static int og_wgrad3_maxtm() {
     if (v < 0) { const char* e = getenv("OG_WGRAD3_MAXTM"); v = e ? atoi(e) : 2; }
     return v;
 }
+static int og_wgrad_b128() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OG_WGRAD_B128"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v;
+}
 static int og_split_target() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("OG_SPLIT_TARGET"); v = e ? atoi(e) : 1024; }
@@ -2027,6 +2040,7 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
             // better there: the up-sampling / reflecting gathers keep their per-element address math)
 #define OG_WG2(TMv) if (bf && TMv <= 2) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, true>), grid, dim3(256), 0, s, a, ksize); \
                     else if (bf) hipLaunchKernelGGL((conv_wgrad2_kernel<TMv, true>), grid, dim3(256), 0, s, a, ksize); \
+                    else if (TMv <= og_wgrad3_maxtm() && og_wgrad_b128()) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, false, true>), grid, dim3(256), 0, s, a, ksize); \
                     else if (TMv <= og_wgrad3_maxtm()) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv>), grid, dim3(256), 0, s, a, ksize); \
                     else hipLaunchKernelGGL((conv_wgrad2_kernel<TMv>), grid, dim3(256), 0, s, a, ksize);
             switch (tm) {

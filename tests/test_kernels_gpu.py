@@ -630,6 +630,7 @@ def test_upblock_conv_takes_the_phased_form_and_follows_weight_updates(dev):
     ("OG_KORDER=1", "test_kernels_gpu.py", "conv2d or upblock or inception or never_consumes"),
     ("OG_ADIRECT=1", "test_kernels_gpu.py", "conv2d or upblock or inception or never_consumes"),
     ("OBJGAN_WGRAD_INPLACE=1", "test_modules_gpu.py", "training_step or discriminator or generator"),
+    ("OG_WGRAD_B128=1 OG_WGRAD3_MAXTM=7", "test_kernels_gpu.py", "conv2d or upblock"),
 ])
 def test_experimental_variants_in_a_subprocess(dev, env, tests, expr):
     """The env-selected variants (chunk-major K order, LDS-free deep-prefetch 32-row form, weight
@@ -638,9 +639,9 @@ def test_experimental_variants_in_a_subprocess(dev, env, tests, expr):
     import subprocess
     import sys
     from conftest import ROOT
-    k, v = env.split("=")
+    extra = dict(kv.split("=") for kv in env.split())
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", tests),
                           "-m", "gpu", "-x", "-q", "-k", expr],
-                         env=dict(os.environ, **{k: v, "OG_TEST_EXPERIMENTAL": "0"}),
+                         env=dict(os.environ, OG_TEST_EXPERIMENTAL="0", **extra),
                          capture_output=True, text=True, timeout=1800)
     assert out.returncode == 0, out.stdout[-3000:]
