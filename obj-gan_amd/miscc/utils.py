@@ -167,3 +167,23 @@ def load_params(model, new_param):
 def mkdir_p(path):
     import os
     os.makedirs(path, exist_ok=True)
+
+
+def _split_scores(predictions, num_splits, fn):
+    scores = []
+    n = predictions.shape[0]
+    for i in range(num_splits):
+        part = predictions[i * n // num_splits:(i + 1) * n // num_splits, :]
+        scores.append(fn(part))
+    return np.mean(scores), np.std(scores)
+
+
+def compute_inception_score(predictions, num_splits=1):
+    """exp(mean KL(p(y|x) || p(y))) per split of the class posteriors (reference utils.py:417-428)."""
+    return _split_scores(predictions, num_splits, lambda part: np.exp(np.mean(np.sum(
+        part * (np.log(part) - np.log(np.expand_dims(np.mean(part, 0), 0))), 1))))
+
+
+def negative_log_posterior_probability(predictions, num_splits=1):
+    """mean -log max_y p(y|x) per split (reference utils.py:431-441)."""
+    return _split_scores(predictions, num_splits, lambda part: np.mean(-1. * np.log(np.max(part, 1))))

@@ -29,7 +29,8 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from miscc.config import cfg
-from miscc.utils import mkdir_p, weights_init, form_clabels_feat, _host
+from miscc.utils import (mkdir_p, weights_init, form_clabels_feat, _host, compute_inception_score,
+                         negative_log_posterior_probability)
 from miscc.losses import patD_loss, shpD_loss, objD_loss, G_loss, KL_loss
 from model import (G_NET, PAT_D_NET64, PAT_D_NET128, PAT_D_NET256, SHP_D_NET64, SHP_D_NET128,
                    SHP_D_NET256, OBJ_SS_D_NET, OBJ_LS_D_NET)
@@ -383,6 +384,20 @@ class condGANTrainer(object):
         torch.save(netObjSSD.state_dict(), '%s/netObjSSD.pth' % self.model_dir)
         torch.save(netObjLSD.state_dict(), '%s/netObjLSD.pth' % self.model_dir)
 
+    def write_scores(self, predictions, epoch):
+        """Per-epoch Inception score of the per-step monitor predictions -> Score/scores_<epoch>.txt
+        (reference trainer.py:495-506)."""
+        preds = np.concatenate([p.detach().cpu().numpy() if torch.is_tensor(p) else np.asarray(p)
+                                for p in predictions], 0)
+        splits = min(10, self.batch_size)
+        mean, std = compute_inception_score(preds, splits)
+        mean_conf, std_conf = negative_log_posterior_probability(preds, splits)
+        with open('%s/scores_%d.txt' % (self.score_dir, epoch), 'w') as fp:
+            fp.write('mean, std, mean_conf, std_conf \n')
+            fp.write('%f, %f, %f, %f' % (mean, std, mean_conf, std_conf))
+        print('inception_score: %f, %f, %f, %f' % (mean, std, mean_conf, std_conf))
+        return mean, std, mean_conf, std_conf
+
     # ---- epoch loop -------------------------------------------------------------------------------------
     def train(self):
         self.setup()
@@ -404,6 +419,8 @@ class condGANTrainer(object):
                                                  out.get("G_logs", "")))
             if self.rank == 0:
                 print('[%d/%d] time: %.2fs' % (epoch, self.max_epoch, time.time() - start_t))
+                if predictions:
+                    self.write_scores(predictions, epoch)
             if epoch % self.snapshot_interval == 0:
                 self.save_model(self.netG, self.avg_param_G, self.netsPatD, self.netsShpD,
                                 self.netObjSSD, self.netObjLSD, epoch)

@@ -84,3 +84,32 @@ def test_up_bank_cache_follows_weight_updates():
     # trainable tensors nobody vouches for are recomposed every call
     q = torch.randn(64, 40, 3, 3, requires_grad=True)
     assert ops._up_bank(q)[1] is False
+
+
+def test_inception_score_helpers_match_reference(tmp_path):
+    """compute_inception_score / negative_log_posterior_probability against the reference's own
+    functions (imported through the oracle harness where /root/reference exists) and a hand value."""
+    import numpy as np
+    from miscc import utils
+    rng = np.random.RandomState(0)
+    logits = rng.randn(37, 11)
+    p = np.exp(logits) / np.exp(logits).sum(1, keepdims=True)
+    m, s = utils.compute_inception_score(p, 4)
+    mc, sc = utils.negative_log_posterior_probability(p, 4)
+    uniform = np.full((8, 5), 0.2)
+    assert abs(utils.compute_inception_score(uniform, 2)[0] - 1.0) < 1e-12
+    assert abs(utils.negative_log_posterior_probability(uniform, 2)[0] - np.log(5.0)) < 1e-12
+    from oracle import ref_harness
+    if ref_harness.available():
+        ref = ref_harness.load_reference().utils
+        assert np.allclose((m, s), ref.compute_inception_score(p, 4), rtol=1e-12, atol=0)
+        assert np.allclose((mc, sc), ref.negative_log_posterior_probability(p, 4), rtol=1e-12, atol=0)
+    # the trainer's epoch file (reference trainer.py:495-506)
+    import types
+    import torch
+    import trainer
+    fake = types.SimpleNamespace(batch_size=4, score_dir=str(tmp_path))
+    out = trainer.condGANTrainer.write_scores(fake, [torch.from_numpy(p[:20]), torch.from_numpy(p[20:])], 3)
+    txt = open(str(tmp_path / "scores_3.txt")).read().split("\n")
+    assert txt[0] == "mean, std, mean_conf, std_conf " and len(txt[1].split(", ")) == 4
+    assert np.allclose(out[:2], utils.compute_inception_score(p, 4))
