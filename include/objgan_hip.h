@@ -146,6 +146,15 @@ int objgan_bilinear_backward(const float* dy, float* dx, long planes, int ih, in
                              void* stream);
 int objgan_sum2x2(const float* dy, float* dx, long planes, int h, int w, void* stream);
 int objgan_reflect_fold(const float* dxp, float* dx, long planes, int h, int w, void* stream);
+/* ---- Winograd F(2x2, 3x3) data transforms (experimental; the host side opts in) ---------------
+ * Replaces nothing in the reference: cuDNN picks its own algorithm behind nn.Conv2d (reference
+ * image_generation/model.py:36-39, 63-81); here the 3x3 stride-1 convolutions of the residual blocks can
+ * run as 16 1x1 convolutions between these two transforms.
+ * V:  [16][N][C][TH*TW] = B^T d B of the 4x4 patch starting at (2*ty - pad, 2*tx - pad); refl = 1
+ *     reflects out-of-range pixels, 0 reads zeros.   Mt: [16][N][M][TH*TW] -> y [N][M][2*TH][2*TW]. */
+int objgan_wino_input_f23(const float* x, float* V, int N, int C, int H, int W, int TH, int TW,
+                          int pad, int refl, void* stream);
+int objgan_wino_output_f23(const float* Mt, float* y, int N, int M, int TH, int TW, void* stream);
 /* torch.optim.Adam update over flat arenas; the gradient is pre-multiplied by grad_scale
  * (1/world_size under data parallelism: the RCCL all-reduce is a plain sum). */
 int objgan_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,

@@ -53,6 +53,8 @@ SIGNATURES = {
     "objgan_bilinear_backward": [_ptr, _ptr, _c_long, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_sum2x2": [_ptr, _ptr, _c_long, _c_int, _c_int, _ptr],
     "objgan_reflect_fold": [_ptr, _ptr, _c_long, _c_int, _c_int, _ptr],
+    "objgan_wino_input_f23": [_ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr],
+    "objgan_wino_output_f23": [_ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_adam_step": [_ptr, _ptr, _ptr, _ptr, _c_long, _c_float, _c_float, _c_float, _c_float, _c_int, _c_float, _ptr],
     "objgan_ema_update": [_ptr, _ptr, _c_long, _c_float, _c_float, _ptr],
     "objgan_prof_enable": [_c_int],
