@@ -1614,11 +1614,6 @@ static int og_igemm_tmmax() {
 // ~ (workgroups per CU) x TM: whole rounds while the grid is small (quantisation is what decides
 // there), fractional once it spans many rounds; short tiles re-read the pixel operand more (pen).
 // The weight gradient always takes the tallest tiles: its gather is the expensive part.
-static int og_pen_old() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("OG_PEN_OLD"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v;
-}
 static double og_rounds(long blocks) {
     if (blocks <= 256) return 1.25;                 // one workgroup per CU: nothing to overlap with
     if (blocks < 1024) return (double)og_cdiv(blocks, 256);
@@ -1634,9 +1629,7 @@ static void og_row_plan(int groups, int tiles_n, int tall, int* TM_out, int* ful
     } else {
         // TM = 1 re-reads the pixel operand once per 32 rows and runs against the L2 (~7 TB/s of
         // fills, 86 TFLOP/s at best -- profiles/r01_tm1_l2_bound.txt); TM = 3 reaches ~114, TM >= 4 ~120
-        static const double pen_new[8] = {0, 1.40, 1.15, 1.06, 1.02, 1.0, 1.0, 1.0};
-        static const double pen_old[8] = {0, 1.12, 1.05, 1.02, 1.0, 1.0, 1.0, 1.0};
-        const double* pen = og_pen_old() ? pen_old : pen_new;
+        static const double pen[8] = {0, 1.40, 1.15, 1.06, 1.02, 1.0, 1.0, 1.0};
         double best = -1;
         for (int tm = 1; tm <= tmmax && tm <= groups; ++tm) {
             const int full = groups / tm, rest = groups - full * tm;
@@ -1701,11 +1694,6 @@ static int og_trace() {
     return v;
 }
 
-static int og_adirect() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("OG_ADIRECT"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v;
-}
 static int og_wgrad3_maxtm() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("OG_WGRAD3_MAXTM"); v = e ? atoi(e) : 2; }
@@ -1763,7 +1751,7 @@ static int launch_igemm2(const IgemmArgs& a, int TM, dim3 grid, hipStream_t s) {
     }
     switch (TM) {
         // TM = 1: the LDS-free form reads the filter rows directly, which only pays while the bank is tiny
-        case 1: if (a.M <= 32 || og_adirect()) hipLaunchKernelGGL((conv_igemm3_kernel<1, true>), grid, dim3(256), 0, s, a);
+        case 1: if (a.M <= 32) hipLaunchKernelGGL((conv_igemm3_kernel<1, true>), grid, dim3(256), 0, s, a);
                 else hipLaunchKernelGGL((conv_igemm3_kernel<1, false>), grid, dim3(256), 0, s, a);
                 break;
         case 2: hipLaunchKernelGGL((conv_igemm3_kernel<2>), grid, dim3(256), 0, s, a); break;

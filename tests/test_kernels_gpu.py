@@ -628,15 +628,14 @@ def test_upblock_conv_takes_the_phased_form_and_follows_weight_updates(dev):
                     reason="experimental variants are opt-in: OG_TEST_EXPERIMENTAL=1")
 @pytest.mark.parametrize("env,tests,expr", [
     ("OG_KORDER=1", "test_kernels_gpu.py", "conv2d or upblock or inception or never_consumes"),
-    ("OG_ADIRECT=1", "test_kernels_gpu.py", "conv2d or upblock or inception or never_consumes"),
     ("OBJGAN_WGRAD_INPLACE=1", "test_modules_gpu.py", "training_step or discriminator or generator"),
     ("OG_WGRAD_B128=1 OG_WGRAD3_MAXTM=7", "test_kernels_gpu.py", "conv2d or upblock"),
     ("OBJGAN_WINOGRAD=1", "test_kernels_gpu.py", "conv2d_forward_backward or packed_filter_cache"),
     ("OBJGAN_WINOGRAD=1", "test_modules_gpu.py", "training_step or generator"),
 ])
 def test_experimental_variants_in_a_subprocess(dev, env, tests, expr):
-    """The env-selected variants (chunk-major K order, LDS-free deep-prefetch 32-row form, weight
-    gradients accumulated straight into the optimizer arena) are read once per process, so they are
+    """The env-selected variants (chunk-major K order, 16-byte weight-gradient gathers, weight
+    gradients accumulated straight into the optimizer arena, Winograd) are read once per process, so they are
     exercised by re-running the affected tests in a child process."""
     import subprocess
     import sys
