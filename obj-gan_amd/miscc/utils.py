@@ -187,3 +187,36 @@ def compute_inception_score(predictions, num_splits=1):
 def negative_log_posterior_probability(predictions, num_splits=1):
     """mean -log max_y p(y|x) per split (reference utils.py:431-441)."""
     return _split_scores(predictions, num_splits, lambda part: np.mean(-1. * np.log(np.max(part, 1))))
+
+
+def _unit_range(mask):
+    """(mask - min) / (max - min); a constant map is kept if its value is >= 0.6 and zeroed
+    otherwise (reference utils.py:544-549, 563-568) -- branch-free, no host sync."""
+    mn, mx = mask.min(), mask.max()
+    return torch.where(mx != mn, (mask - mn) / (mx - mn), torch.where(mx < 0.6, mask * 0, mask))
+
+
+def form_hmaps(raw_masks, num_rois, rois, hmap_size, num_classes):
+    """Generated instance masks [B, R, 64, 64] -> layout maps / per-slot masks at every branch
+    size and the 32x32 feature scale (reference utils.py:524-584): masks are rescaled to [0, 1],
+    merged per category with a running maximum, and resized bilinearly (align_corners=True)."""
+    num = _host(num_rois).tolist()
+    cats = _host(rois)[:, :, 4]
+    B = int(raw_masks.size(0))
+    S = hmap_size[-1]
+    re_raw_masks = ops.bilinear_resize(raw_masks, S, S).clone()
+    raw_gen_hmap = torch.zeros(B, num_classes, S, S, device=raw_masks.device)
+    for b in range(B):
+        cat_indices = [int(c) for c in cats[b, :int(num[b])].tolist()]
+        for count, cat in enumerate(cat_indices):
+            tmp = _unit_range(re_raw_masks[b, count])
+            re_raw_masks[b, count] = tmp
+            raw_gen_hmap[b, cat] = torch.max(tmp, raw_gen_hmap[b, cat])
+        for cat in cat_indices:
+            raw_gen_hmap[b, cat] = _unit_range(raw_gen_hmap[b, cat])
+    gen_hmaps, gen_bt_masks = [], []
+    for i in range(cfg.TREE.BRANCH_NUM):
+        gen_hmaps.append(ops.bilinear_resize(raw_gen_hmap, hmap_size[i], hmap_size[i]))
+        gen_bt_masks.append(ops.bilinear_resize(re_raw_masks, hmap_size[i], hmap_size[i]))
+    gen_fm_bt_masks = ops.bilinear_resize(re_raw_masks, hmap_size[0] // 2, hmap_size[0] // 2)
+    return gen_hmaps, gen_bt_masks, gen_fm_bt_masks

@@ -487,6 +487,129 @@ class _JointBlock(nn.Sequential):
         return _bn_act(y, bn, "lrelu")
 
 
+# ---------------------------------------------------------------------------------------------
+# shape generator of the sampling path (reference model.py:800-985; evaluator.py loads it from
+# cfg.TEST.NET_SHP_G to turn generated boxes into instance masks).  Forward only.
+# ---------------------------------------------------------------------------------------------
+def downBlock_3x3(in_planes, out_planes):
+    return _ActSeq(nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=2, padding=1, bias=False),
+                   nn.InstanceNorm2d(out_planes),
+                   nn.LeakyReLU(0.2, inplace=True))
+
+
+class _GluSeq(nn.Sequential):
+    """[conv3x3(in, 2*out), norm(2*out), GLU]: keeps the spatial size."""
+
+    def forward(self, x):
+        conv, norm = self[0], self[1]
+        y = ops.conv2d(x, conv.weight, None, 1, 1, "zeros")
+        if isinstance(norm, nn.InstanceNorm2d):
+            return _in_act(y, norm, "glu")
+        return _bn_act(y, norm, "glu")
+
+
+def Block3x3_relu(in_planes, out_planes, norm=nn.BatchNorm2d):
+    return _GluSeq(conv3x3(in_planes, out_planes * 2), norm(out_planes * 2), GLU())
+
+
+class CLSTMCell(nn.Module):
+    """Convolutional LSTM cell: one conv over [input, hidden] produces the four gates
+    (in, remember, out, cell), reference model.py:819-862."""
+
+    def __init__(self, input_size, hidden_size, kernel_size, padding):
+        super(CLSTMCell, self).__init__()
+        self.input_size = input_size
+        self.hidden_size = hidden_size
+        self.Gates = nn.Conv2d(input_size + hidden_size, 4 * hidden_size, kernel_size, padding=padding)
+
+    def forward(self, input_, prev_state):
+        if prev_state is None:
+            size = [input_.size(0), self.hidden_size] + list(input_.shape[2:])
+            prev_state = (torch.zeros(size, device=input_.device), torch.zeros(size, device=input_.device))
+        prev_hidden, prev_cell = prev_state
+        gates = ops.conv2d(torch.cat((input_, prev_hidden), 1), self.Gates.weight, self.Gates.bias,
+                           1, self.Gates.padding[0], "zeros")
+        in_gate, remember_gate, out_gate, cell_gate = gates.chunk(4, 1)
+        cell = torch.sigmoid(remember_gate) * prev_cell + torch.sigmoid(in_gate) * torch.tanh(cell_gate)
+        hidden = torch.sigmoid(out_gate) * torch.tanh(cell)
+        return hidden, cell
+
+
+class ResBlock(nn.Module):
+    """conv-norm-GLU x2 + conv3x3, plus the input (reference model.py:865-881)."""
+
+    def __init__(self, channel_num, norm=nn.BatchNorm2d):
+        super(ResBlock, self).__init__()
+        self.block = nn.Sequential(
+            conv3x3(channel_num, channel_num * 2), norm(channel_num * 2), GLU(),
+            conv3x3(channel_num, channel_num * 2), norm(channel_num * 2), GLU(),
+            conv3x3(channel_num, channel_num))
+
+    def forward(self, x):
+        out = x
+        for i in (0, 3):
+            y = ops.conv2d(out, self.block[i].weight, None, 1, 1, "zeros")
+            norm = self.block[i + 1]
+            out = _in_act(y, norm, "glu") if isinstance(norm, nn.InstanceNorm2d) else _bn_act(y, norm, "glu")
+        return ops.conv2d(out, self.block[6].weight, None, 1, 1, "zeros") + x
+
+
+class GET_SHAPE_G(nn.Module):
+    def __init__(self, nbf):
+        super(GET_SHAPE_G, self).__init__()
+        self.img = nn.Sequential(conv1x1(nbf, 1), nn.Sigmoid())
+
+    def forward(self, h_code):
+        return ops.conv2d(h_code, self.img[0].weight, None, 1, 0, "zeros", act="sigmoid")
+
+
+class SHP_G_NET(nn.Module):
+    """Box layouts -> per-box instance masks: bidirectional ConvLSTM over the box sequence at
+    16x16, residual blocks, two upBlocks back to 64x64 (reference model.py:898-985)."""
+
+    def __init__(self, num_classes):
+        super(SHP_G_NET, self).__init__()
+        self.nbf = num_classes
+        self.fm_size = cfg.ROI.FM_SIZE
+        self.downsample1 = downBlock_3x3(self.nbf, self.nbf * 2)
+        self.downsample2 = downBlock_3x3(self.nbf * 2, self.nbf * 4)
+        self.fwd_convlstm = CLSTMCell(self.nbf * 4, self.nbf * 2, 3, 1)
+        self.bwd_convlstm = CLSTMCell(self.nbf * 4, self.nbf * 2, 3, 1)
+        self.jointConv = Block3x3_relu(self.nbf * 8, self.nbf * 4, norm=nn.InstanceNorm2d)
+        self.residual = self._make_layer(ResBlock, self.nbf * 4)
+        self.upsample1 = upBlock(self.nbf * 4, self.nbf * 2, norm=nn.InstanceNorm2d)
+        self.upsample2 = upBlock(self.nbf * 2, self.nbf, norm=nn.InstanceNorm2d)
+        self.img_net = GET_SHAPE_G(self.nbf)
+
+    def _make_layer(self, block, channel_num):
+        return nn.Sequential(*[block(channel_num, norm=nn.InstanceNorm2d) for _ in range(cfg.GAN.R_NUM)])
+
+    def forward(self, z_code, bbox_maps_fwd, bbox_maps_bwd, bbox_fmaps):
+        """z_code [B, R, 4 * nbf] (evaluator.py:278-279); bbox_maps_fwd/bwd [B, R, nbf, S, S]; bbox_fmaps [B, R, 16, 16]
+        -> fake_hmaps [B, R, 1, S, S]"""
+        B, R = z_code.size(0), z_code.size(1)
+        fm = self.fm_size
+        z = z_code.unsqueeze(3).repeat(1, 1, 1, fm * fm).view(B, R, -1, fm, fm)
+        S = bbox_maps_fwd.size(3)
+
+        def down(maps):
+            h = self.downsample2(self.downsample1(maps.reshape(-1, self.nbf, S, S)))
+            return h.view(B, R, -1, fm, fm)
+        h_fwd, h_bwd = down(bbox_maps_fwd), down(bbox_maps_bwd)
+        state_fwd, state_bwd, fwd_lst, bwd_lst = None, None, [], []
+        for t in range(R):
+            state_fwd = self.fwd_convlstm(h_fwd[:, t], state_fwd)
+            fwd_lst.append(state_fwd[0].unsqueeze(1))
+            state_bwd = self.bwd_convlstm(h_bwd[:, t], state_bwd)
+            bwd_lst.append(state_bwd[0].unsqueeze(1))
+        h_code = torch.cat([torch.cat((fwd_lst[t], bwd_lst[R - t - 1], z[:, t:t + 1]), 2) for t in range(R)], 1)
+        h_code = self.jointConv(h_code.view(B * R, -1, fm, fm))
+        h_code = h_code * bbox_fmaps.reshape(B * R, 1, fm, fm)            # crop to the box
+        h_code = self.residual(h_code)
+        h_code = self.upsample2(self.upsample1(h_code))
+        return self.img_net(h_code).view(B, R, -1, S, S)
+
+
 def Block3x3_leakRelu(in_planes, out_planes):
     return _JointBlock(conv3x3(in_planes, out_planes),
                         nn.BatchNorm2d(out_planes),

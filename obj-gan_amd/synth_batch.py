@@ -109,3 +109,25 @@ def to_device(batch, device):
             return [mv(x) for x in v]
         return v
     return {k: mv(v) for k, v in batch.items()}
+
+
+def make_shape_inputs(seed=71, B_=2, R=3, nbf=8, S=64, fm=16):
+    """Seeded inputs of the shape generator: one-hot box maps (category channel = 1 inside the box),
+    their reversed sequence, the 16x16 box crops and the per-box noise [B, R, 4 * nbf]."""
+    rng = np.random.RandomState(seed)
+    g = torch.Generator().manual_seed(seed)
+    fwd = torch.zeros(B_, R, nbf, S, S)
+    fmaps = torch.zeros(B_, R, fm, fm)
+    rois = np.zeros((B_, 10, 6))
+    num = np.array([R, R - 1])[:B_]
+    for b in range(B_):
+        for r in range(int(num[b])):
+            x, y = rng.randint(0, 36, 2)
+            w, h = rng.randint(8, 26, 2)
+            c = int(rng.randint(0, nbf))
+            fwd[b, r, c, y:y + h, x:x + w] = 1
+            fmaps[b, r, y // 4:(y + h) // 4, x // 4:(x + w) // 4] = 1
+            rois[b, r] = [x, y, w, h, c, 0]
+    bwd = fwd.flip(1).clone()
+    z = torch.randn(B_, R, 4 * nbf, generator=g)        # evaluator.py:278-279: noise of 4 * num_classes
+    return z, fwd, bwd, fmaps, torch.from_numpy(rois), torch.from_numpy(num.astype(np.int64))

@@ -41,6 +41,35 @@ def make_rnn_golden():
     print("rnn golden", tuple(words.shape), tuple(sent.shape), float(words.abs().mean()))
 
 
+def make_shp_golden():
+    """Reference SHP_G_NET (model.py:898-985) and form_hmaps (utils.py:524-584) on CPU ->
+    tests/golden/shp_g_ref.pt.  The reference hard-codes .cuda() for the initial ConvLSTM state and
+    cfg.CUDA in form_hmaps: both are neutralised for the run (Tensor.cuda -> identity, cfg.CUDA False)."""
+    ref = rh.load_reference(branch_num=3, batch_size=2)
+    nbf = 8
+    net = rh.seeded_state_(ref.model.SHP_G_NET(nbf), 72).eval()
+    z, fwd, bwd, fmaps, rois, num = synth_batch.make_shape_inputs(nbf=nbf)
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        with torch.no_grad():
+            fake = net(z, fwd, bwd, fmaps)
+            ref.cfg.CUDA = False
+            hm, bt, fmbt = ref.utils.form_hmaps(fake.squeeze(2).clone(), num, rois, [64, 128, 256], nbf)
+    finally:
+        torch.Tensor.cuda = orig_cuda
+
+    def fp(t):
+        t = t.double()
+        return {"shape": tuple(t.shape), "sum": float(t.sum()), "sq": float((t * t).sum()),
+                "sample": t[..., ::8, ::8].float().clone()}
+    torch.save({"seed_inputs": 71, "seed_weights": 72, "nbf": nbf, "fake_hmaps": fake.clone(),
+                "state_keys": {k: tuple(v.shape) for k, v in net.state_dict().items()},
+                "gen_hmaps": [fp(t) for t in hm], "gen_bt_masks": [fp(t) for t in bt], "gen_fm_bt_masks": fmbt.clone()},
+               os.path.join(HERE, "shp_g_ref.pt"))
+    print("shp golden", tuple(fake.shape), float(fake.mean()), [tuple(t.shape) for t in hm])
+
+
 def main():
     torch.set_num_threads(8)
     ref = rh.load_reference(branch_num=3, batch_size=B)
@@ -148,7 +177,9 @@ def main():
 
 
 if __name__ == "__main__":
-    if "--rnn" in sys.argv:
+    if "--shp" in sys.argv:
+        make_shp_golden()
+    elif "--rnn" in sys.argv:
         make_rnn_golden()
     else:
         main()

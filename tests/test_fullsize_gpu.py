@@ -135,3 +135,19 @@ def test_fused_adam_over_a_generator_sized_arena(dev):
     want = ps - lr * (m1 / (1 - b1)) / ((v1 / (1 - b2)).sqrt() + eps)
     assert rel_l2(p[idx], want.float()) < 1e-6
     assert rel_l2(m[idx], m1.float()) < 1e-6 and rel_l2(v[idx], v1.float()) < 1e-6
+
+
+def test_shape_generator_forward_matches_reference_golden(dev):
+    """SHP_G_NET on the gfx950 kernels (ConvLSTM gates, InstanceNorm GLU blocks, phased upBlocks,
+    1x1 conv + sigmoid) against the unmodified reference's CPU output (tests/golden/shp_g_ref.pt)."""
+    from conftest import ROOT
+    import model as M
+    import synth_batch
+    from oracle import ref_harness as rh
+    gold = torch.load(os.path.join(ROOT, "tests", "golden", "shp_g_ref.pt"), weights_only=False)
+    net = rh.seeded_state_(M.SHP_G_NET(gold["nbf"]), gold["seed_weights"]).to(dev).eval()
+    z, fwd, bwd, fmaps, rois, num = synth_batch.make_shape_inputs(nbf=gold["nbf"])
+    with torch.no_grad():
+        fake = net(z.to(dev), fwd.to(dev), bwd.to(dev), fmaps.to(dev))
+    torch.cuda.synchronize()
+    assert fake.shape == gold["fake_hmaps"].shape and rel_l2(fake, gold["fake_hmaps"]) < 1e-3

@@ -184,3 +184,37 @@ def test_winograd_is_opt_in_and_restricted():
         assert not ops._wino_ok(x, w[:20], None, 1, 1, "zeros", False, None)
     finally:
         ops._WINOGRAD = False
+
+
+def test_shape_generator_mirror_and_form_hmaps(monkeypatch):
+    """Sampling path: SHP_G_NET has the reference's state-dict layout, and
+    form_hmaps reproduces the reference output (tests/golden/shp_g_ref.pt, generated by the unmodified
+    reference on CPU) when the bilinear kernel is replaced by its torch definition."""
+    import os
+    from conftest import ROOT
+    import model as M
+    import synth_batch
+    from miscc import utils
+    from miscc.config import cfg
+    cfg.TREE.BRANCH_NUM = 3
+    gold = torch.load(os.path.join(ROOT, "tests", "golden", "shp_g_ref.pt"), weights_only=False)
+    net = M.SHP_G_NET(gold["nbf"])
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == gold["state_keys"]
+    monkeypatch.setattr(utils.ops, "bilinear_resize",
+                        lambda x, oh, ow: F.interpolate(x, size=(oh, ow), mode="bilinear", align_corners=True))
+    z, fwd, bwd, fmaps, rois, num = synth_batch.make_shape_inputs(nbf=gold["nbf"])
+    assert z.shape == (2, 3, 4 * gold["nbf"])
+    hm, bt, fmbt = utils.form_hmaps(gold["fake_hmaps"].squeeze(2).clone(), num, rois, [64, 128, 256], gold["nbf"])
+
+    def check(t, fp):
+        t = t.double()
+        assert tuple(t.shape) == tuple(fp["shape"])
+        assert abs(float(t.sum()) - fp["sum"]) <= 1e-6 * max(1.0, abs(fp["sum"]))
+        assert abs(float((t * t).sum()) - fp["sq"]) <= 1e-6 * max(1.0, abs(fp["sq"]))
+        assert torch.allclose(t[..., ::8, ::8].float(), fp["sample"], atol=1e-6, rtol=0)
+    for t, fp in zip(hm, gold["gen_hmaps"]):
+        check(t, fp)
+    for t, fp in zip(bt, gold["gen_bt_masks"]):
+        check(t, fp)
+    assert torch.allclose(fmbt, gold["gen_fm_bt_masks"], atol=1e-6, rtol=0)
+    assert float(hm[0].max()) <= 1.0 + 1e-6 and float(hm[0].min()) >= 0.0
