@@ -160,8 +160,13 @@ def copy_G_params(model):
 
 
 def load_params(model, new_param):
-    for p, new_p in zip(model.parameters(), new_param):
-        p.data.copy_(new_p)
+    """Overwrite the parameters in place (reference utils.py: `p.data.copy_(new_p)`, used to swap the
+    EMA weights in and out).  Written through the parameter itself, not through `.data`: that keeps
+    the values identical and moves the tensors' version counters, which is what the packed-filter
+    caches of objgan_hip.ops key on -- a `.data` write would leave stale filter banks in use."""
+    with torch.no_grad():
+        for p, new_p in zip(model.parameters(), new_param):
+            p.copy_(new_p)
 
 
 def mkdir_p(path):

@@ -218,3 +218,23 @@ def test_shape_generator_mirror_and_form_hmaps(monkeypatch):
         check(t, fp)
     assert torch.allclose(fmbt, gold["gen_fm_bt_masks"], atol=1e-6, rtol=0)
     assert float(hm[0].max()) <= 1.0 + 1e-6 and float(hm[0].min()) >= 0.0
+
+
+def test_load_params_invalidates_filter_bank_caches():
+    """Swapping the EMA weights in (reference load_params) must change the cache keys of the packed
+    filter banks: the values are written through the parameter, so its version counter moves."""
+    from miscc.utils import load_params, copy_G_params
+    from objgan_hip import ops
+    net = torch.nn.Conv2d(40, 64, 3, bias=False)
+    w = net.weight
+    w._og_epoch = [0]                                     # as if owned by an optimizer arena
+    key0 = ops._pack_key(w, 0, (0,), 1)
+    bank0, _ = ops._up_bank(w)
+    ref0 = bank0.clone()
+    backup = copy_G_params(net)
+    load_params(net, [torch.full_like(w, 0.25)])
+    assert ops._pack_key(w, 0, (0,), 1) != key0
+    bank1, _ = ops._up_bank(w)
+    assert not torch.allclose(bank1, ref0) and float(bank1.max()) == 1.0   # 4 taps of 0.25 summed
+    load_params(net, backup)
+    assert torch.allclose(ops._up_bank(w)[0], ref0)
