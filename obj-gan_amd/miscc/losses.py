@@ -228,8 +228,10 @@ def _obj_g_term(netObjD, fake_img, seg, slabels_emb, raw_bt_c_codes, rois, num_r
 
 def G_loss(netsPatD, netsShpD, netObjSSD, netObjLSD, image_encoder, fake_imgs, seg_conditions,
            words_embs, sent_emb, slabels_emb, raw_bt_c_codes, match_labels, cap_lens, class_ids,
-           rois, fm_rois, num_rois, quiet=False):
-    """quiet=True skips the log string (every `.item()` in it is a device->host sync)."""
+           rois, fm_rois, num_rois, quiet=False, use_obj=True):
+    """quiet=True skips the log string (every `.item()` in it is a device->host sync);
+    use_obj=False leaves the two object-discriminator terms out (BASELINE.json configs 1-3: the
+    reference has no such switch, its stage-1 / no-ObjD runs are harness compositions)."""
     numDs = len(netsPatD)
     batch_size = fake_imgs[0].size(0)
     logs = ''
@@ -263,6 +265,8 @@ def G_loss(netsPatD, netsShpD, netObjSSD, netObjLSD, image_encoder, fake_imgs, s
             if not quiet:
                 logs += 'w_loss: %.2f s_loss: %.2f ' % (w_loss.item(), s_loss.item())
 
+    if not use_obj:
+        return errG_total, logs
     objss_g_loss = _obj_g_term(netObjSSD, fake_imgs[-1], seg_conditions[-1], slabels_emb,
                                raw_bt_c_codes, rois, num_rois, False)
     objls_g_loss = _obj_g_term(netObjLSD, fake_imgs[-1], seg_conditions[-1], slabels_emb,

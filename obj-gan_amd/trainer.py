@@ -168,6 +168,10 @@ class condGANTrainer(object):
         self.rank = dist.get_rank() if _dist_on() else 0
         self.world = dist.get_world_size() if _dist_on() else 1
         self.is_stream = torch.cuda.Stream(device=self.device) if self.inception_model is not None else None
+        # The object discriminators consume the second stage's bottom-up codes: a one-stage tree cannot
+        # have them (the reference raises IndexError there, SURVEY.md trap 8); `use_obj = False` also
+        # gives BASELINE.json config 3 "without the two object discriminators".
+        self.use_obj = cfg.TREE.BRANCH_NUM >= 2
 
     # ---- model / optimizer construction ---------------------------------------------------------
     def build_models(self):
@@ -308,8 +312,9 @@ class condGANTrainer(object):
                          lambda i=i: shpD_loss(self.netsShpD[i], imgs[i], fake_imgs[i], hmaps[i], rois[i], num_rois)))
         # the reference updates an object discriminator only `if float(err) > 0`, i.e. when at least one
         # box of the wanted scale exists (BCE of a sigmoid is > 0 otherwise)
-        for name, net, opt, r, large in (("errObjSSD", self.netObjSSD, self.optimizerObjSSD, rois[0], False),
-                                          ("errObjLSD", self.netObjLSD, self.optimizerObjLSD, fm_rois, True)):
+        obj_jobs = (("errObjSSD", self.netObjSSD, self.optimizerObjSSD, rois[0], False),
+                    ("errObjLSD", self.netObjLSD, self.optimizerObjLSD, fm_rois, True)) if self.use_obj else ()
+        for name, net, opt, r, large in obj_jobs:
             jobs.append((name, opt,
                          lambda net=net, r=r, large=large: objD_loss(net, imgs[-1], fake_imgs[-1], hmaps[-1],
                                                                      clabels_emb, bt_c_codes[-1], r, num_rois,
@@ -338,12 +343,13 @@ class condGANTrainer(object):
         for opt in d_opts:
             opt.arena.set_requires_grad(False)
         self.optimizerG.zero_grad()
+        bt_last = bt_c_codes[-1] if bt_c_codes else None
         errG_total, G_logs = G_loss(self.netsPatD, self.netsShpD, self.netObjSSD, self.netObjLSD,
                                     self.image_encoder, fake_imgs, hmaps, words_embs, sent_emb,
-                                    clabels_emb, bt_c_codes[-1], self.match_labels, b["cap_lens"],
-                                    b["class_ids"], rois[0], fm_rois, num_rois) \
+                                    clabels_emb, bt_last, self.match_labels, b["cap_lens"],
+                                    b["class_ids"], rois[0], fm_rois, num_rois, use_obj=self.use_obj) \
             if want_logs else _g_loss_quiet(self, fake_imgs, hmaps, words_embs, sent_emb, clabels_emb,
-                                            bt_c_codes[-1], b, rois, fm_rois, num_rois)
+                                            bt_last, b, rois, fm_rois, num_rois)
         kl = KL_loss(mu, logvar)
         errG_total = errG_total + kl
         errG_total.backward()
@@ -434,5 +440,6 @@ def _g_loss_quiet(tr, fake_imgs, hmaps, words_embs, sent_emb, clabels_emb, bt_c,
     import miscc.losses as L
     total, _ = L.G_loss(tr.netsPatD, tr.netsShpD, tr.netObjSSD, tr.netObjLSD, tr.image_encoder,
                         fake_imgs, hmaps, words_embs, sent_emb, clabels_emb, bt_c, tr.match_labels,
-                        b["cap_lens"], b["class_ids"], rois[0], fm_rois, num_rois, quiet=True)
+                        b["cap_lens"], b["class_ids"], rois[0], fm_rois, num_rois, quiet=True,
+                        use_obj=tr.use_obj)
     return total, ''

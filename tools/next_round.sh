@@ -6,7 +6,7 @@ TAG=${1:-r02a}
 mkdir -p gpurun_out; export TMPDIR=/tmp
 # 1. opt-in tests: full-size properties, Winograd transforms, SHP_G_NET forward, env-selected variants
 ( time OG_TEST_EXPERIMENTAL=1 timeout 1500 python -m pytest tests -m gpu -q \
-    -k "fullsize or full_size or winograd or shape_generator or experimental or adjoint or arena or distributions or statistics" ) \
+    -k "fullsize or full_size or winograd or shape_generator or experimental or adjoint or arena or distributions or statistics or without_object" ) \
     > gpurun_out/${TAG}_exp_pytest.log 2>&1
 tail -15 gpurun_out/${TAG}_exp_pytest.log
 # 2. conv micro-benchmark: default vs chunk-major K order vs 16-byte weight-gradient gathers
