@@ -1,0 +1,125 @@
+"""TEST INFRASTRUCTURE: the `objgan_hip.ops` API with every kernel replaced by its CPU definition
+(oracle/torch_ref.py, oracle/roi.py, torch.nn.functional).  Installed by tests only
+(`install(monkeypatch)`), it lets the host side of the product -- model.py, GlobalAttention.py,
+miscc/losses.py, miscc/utils.py, trainer.py with its flat arenas -- run on CPU tensors, so that the
+wiring around the kernels is checked against the oracle without a GPU.  The product never imports
+this module; on a GPU box the same host code runs on libobjgan_hip.so (and refuses CPU tensors)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import torch_ref as tr, roi as oroi
+
+conv2d = tr.conv2d
+norm_act = tr.norm_act
+attn_general = tr.attn_general
+attn_bu = tr.attn_bu
+masked_max = tr.masked_max
+bilinear_resize = tr.bilinear_resize
+avgpool2s1 = tr.avgpool2s1
+
+
+def _act(y, act):
+    if act in (None, "none"):
+        return y
+    if act == "lrelu":
+        return F.leaky_relu(y, 0.2)
+    if act == "relu":
+        return F.relu(y)
+    return torch.tanh(y) if act == "tanh" else torch.sigmoid(y)
+
+
+def conv2d_frozen(x, w, bias=None, stride=1, pad=(0, 0), act=None):
+    return _act(F.conv2d(x, w, bias, stride, pad), act)
+
+
+def linear(x, w, bias=None, act=None):
+    return _act(F.linear(x, w, bias), act)
+
+
+def norm_act_eval(x, gamma, beta, running_mean, running_var, mode=None, eps=1e-5):
+    y = F.batch_norm(x, running_mean, running_var, gamma, beta, False, 0.0, eps)
+    if mode == "glu":
+        return tr.glu(y)
+    return F.leaky_relu(y, 0.2) if mode == "lrelu" else y
+
+
+def softmax_strided(x, dim, scale=1.0, lens=None, rowvalid=None):
+    d = dim % x.dim()
+    outer = int(np.prod(x.shape[:d])) if d else 1
+    n = x.shape[d]
+    xs = (scale * x).reshape(outer, n, -1)
+    keep = torch.ones(outer, n, 1, dtype=torch.bool)
+    if lens is not None:
+        span = lens.to(torch.long).clamp(max=n)[torch.arange(outer) % lens.numel()]
+        keep = torch.arange(n).view(1, n, 1) < span.view(outer, 1, 1)
+    y = torch.softmax(xs.masked_fill(~keep, float("-inf")), dim=1)
+    y = torch.where(keep, y, torch.zeros_like(y))
+    if rowvalid is not None:
+        y = y * rowvalid.reshape(outer, 1, 1).to(y.dtype)
+    return y.reshape(x.shape)
+
+
+class _RoiFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, rois, ah, aw, scale):
+        out = oroi.forward(features.detach().numpy(), rois.detach().numpy(), ah, aw, scale)
+        ctx.save_for_backward(rois)
+        ctx.meta = (tuple(features.shape), scale)
+        return torch.from_numpy(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        (rois,) = ctx.saved_tensors
+        shape, scale = ctx.meta
+        return torch.from_numpy(oroi.backward(g.contiguous().numpy(), rois.numpy(), shape, scale)), None, None, None, None
+
+
+def roi_align(features, rois, aligned_height, aligned_width, spatial_scale):
+    return _RoiFn.apply(features, rois, int(aligned_height), int(aligned_width), float(spatial_scale))
+
+
+def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, n=None):
+    n = p.numel() if n is None else int(n)
+    pn, mn, vn = tr.adam_step(p[:n], g[:n] * grad_scale, m[:n], v[:n], lr, beta1, beta2, eps, step)
+    p[:n].copy_(pn)
+    m[:n].copy_(mn)
+    v[:n].copy_(vn)
+
+
+def ema_update_(avg, p, decay):
+    avg.mul_(decay).add_(p, alpha=1.0 - decay)
+
+
+def set_conv_math(mode):
+    pass
+
+
+def get_conv_math():
+    return "fp32"
+
+
+API = ("conv2d", "conv2d_frozen", "linear", "norm_act", "norm_act_eval", "attn_general", "attn_bu", "masked_max",
+       "softmax_strided", "roi_align", "avgpool2s1", "bilinear_resize", "adam_step_", "ema_update_")
+
+
+def install(monkeypatch):
+    """Point the `ops` name of every host module at this shim (and undo it after the test)."""
+    import sys
+    import types
+    import GlobalAttention
+    import model
+    import trainer
+    from miscc import losses, utils
+    shim = types.SimpleNamespace(**{k: globals()[k] for k in API})
+    shim.set_conv_math, shim.get_conv_math = set_conv_math, get_conv_math
+    for mod in (model, GlobalAttention, trainer, losses, utils):
+        if hasattr(mod, "ops"):
+            monkeypatch.setattr(mod, "ops", shim)
+    for name in ("models.roi_align.modules.roi_align", "models.roi_align.functions.roi_align"):
+        m = sys.modules.get(name)
+        if m is not None and hasattr(m, "ops"):
+            monkeypatch.setattr(m, "ops", shim)
+    monkeypatch.setattr(model, "_LIFT", [])
+    monkeypatch.setattr(utils, "_HOST", [])
+    return shim

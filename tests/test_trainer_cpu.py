@@ -1,0 +1,110 @@
+"""The product's HOST code (model.py wiring, losses, roi / feature selection helpers, flat-arena
+trainer with its update order, EMA, use_obj switch) executed on CPU with every kernel replaced by its
+CPU definition (tests/cpu_ops_shim.py) and compared with the oracle's train_step on the same seeded
+inputs and weights.  What this cannot see -- the kernels themselves -- is what the `-m gpu` tests
+cover; what it does see on every CPU-only round is everything around them."""
+import random
+
+import pytest
+import torch
+
+import cpu_ops_shim
+from conftest import rel_l2
+
+
+class _ConstEncoder(object):
+    """Constant image encoder: the DAMSM terms get fixed region features (see tests/test_modules_gpu.py)."""
+
+    def __init__(self, regions, code):
+        self.regions, self.code = regions.detach(), code.detach()
+
+    def __call__(self, x):
+        return self.regions, self.code
+
+    def parameters(self):
+        return []
+
+    def eval(self):
+        return self
+
+
+def _sd_of(m):
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running_" not in k:
+            v.requires_grad_(True)
+    return sd
+
+
+@pytest.mark.parametrize("branch_num,B,use_obj", [(1, 2, False), (2, 2, True)])
+def test_product_trainer_host_logic_matches_oracle(monkeypatch, branch_num, B, use_obj):
+    import model as M
+    import synth_batch
+    import trainer as T
+    from oracle import ref_harness as rh, torch_model as tm
+    from miscc.config import cfg
+    cpu_ops_shim.install(monkeypatch)
+    monkeypatch.setattr(cfg.TREE, "BRANCH_NUM", branch_num)
+    monkeypatch.setattr(cfg.TRAIN, "BATCH_SIZE", B)
+    monkeypatch.setattr(cfg.TRAIN, "NET_G", '')
+    torch.set_num_threads(8)
+    dev = torch.device("cpu")
+
+    class DS(object):
+        num_classes = 80
+    ds = DS()
+    g0 = torch.Generator().manual_seed(321)
+    regions_c, code_c = torch.randn(B, 256, 17, 17, generator=g0), torch.randn(B, 256, generator=g0)
+    ds.image_encoder = _ConstEncoder(regions_c, code_c)
+    tr = T.condGANTrainer('', None, ds, device=dev)
+    tr.batch_size = B
+    assert tr.use_obj == (branch_num >= 2)
+    pat_cls = (M.PAT_D_NET64, M.PAT_D_NET128, M.PAT_D_NET256)[:branch_num]
+    shp_cls = (M.SHP_D_NET64, M.SHP_D_NET128, M.SHP_D_NET256)[:branch_num]
+    nets = [None, ds.image_encoder, rh.seeded_state_(M.G_NET(80), 161),
+            [rh.seeded_state_(c(), 162 + i) for i, c in enumerate(pat_cls)],
+            [rh.seeded_state_(c(80), 165 + i) for i, c in enumerate(shp_cls)],
+            rh.seeded_state_(M.OBJ_SS_D_NET(80), 168), rh.seeded_state_(M.OBJ_LS_D_NET(80), 169), 0]
+    sds = {"G": _sd_of(nets[2]), "pat": [_sd_of(m) for m in nets[3]], "shp": [_sd_of(m) for m in nets[4]],
+           "objss": _sd_of(nets[5]), "objls": _sd_of(nets[6])}
+    adam = lambda sd: torch.optim.Adam(tm.params_of(sd), lr=2e-4, betas=(0.5, 0.999))   # noqa: E731
+    opts = {"G": adam(sds["G"]), "pat": [adam(s) for s in sds["pat"]], "shp": [adam(s) for s in sds["shp"]],
+            "objss": adam(sds["objss"]), "objls": adam(sds["objls"])}
+    ema = [p.detach().clone() for p in tm.params_of(sds["G"])]
+    for m in [nets[2], nets[5], nets[6]] + nets[3] + nets[4]:
+        m.train()
+    tr.build_models = lambda: nets
+    tr.setup()
+    b = synth_batch.make_batch(B, seed=78, branch_num=branch_num)
+    b2 = synth_batch.make_batch(B, seed=78, branch_num=branch_num)      # independent copy for the product
+    tr.netG.ca_net.fixed_eps = b2["ca_eps"]
+
+    random.seed(9)
+    want = tm.train_step(sds, opts, ema, b, image_encoder=_ConstEncoder(regions_c, code_c), use_obj=use_obj)
+    random.seed(9)
+    got = tr.train_step(b2, noise=b2["noise"])
+
+    keys = ["errPatD%d" % i for i in range(branch_num)] + ["errShpD%d" % i for i in range(branch_num)] + ["errG", "kl"]
+    if use_obj:
+        keys += [k for k in ("errObjSSD", "errObjLSD") if k in want]
+    for k in keys:
+        assert k in got, k
+        assert abs(got[k].item() - want[k].item()) < 1e-4 * abs(want[k].item()) + 1e-6, (k, got[k].item(), want[k].item())
+    if not use_obj:
+        assert "errObjSSD" not in got and "errObjLSD" not in got
+    assert len(got["fake_imgs"]) == branch_num
+    assert rel_l2(got["fake_imgs"][-1], want["fake_imgs"][-1]) < 1e-5
+    # parameters after the nine (or three) Adam steps, and the EMA buffer
+    for name, module, sd in [("G", tr.netG, sds["G"]), ("pat0", tr.netsPatD[0], sds["pat"][0]),
+                             ("shp0", tr.netsShpD[0], sds["shp"][0])]:
+        num = den = 0.0
+        for k, p in module.named_parameters():
+            num += float((p.detach() - sd[k].detach()).double().pow(2).sum())
+            den += float(sd[k].detach().double().pow(2).sum())
+        # first Adam step = lr * g / (|g| + eps): elements whose gradient is at rounding level flip by
+        # 2 * lr when the summation order differs (the product evaluates the layout stem once for the
+        # real and the fake pass), hence 1e-4 on the parameters while losses and images agree to 1e-5
+        assert (num / den) ** 0.5 < 1e-4, (name, (num / den) ** 0.5)
+    order = [k for k, _ in tr.netG.named_parameters()]
+    ema_sorted = {k: a for k, a in zip(sorted(k for k in sds["G"] if sds["G"][k].requires_grad), ema)}
+    assert rel_l2(tr.avg_param_G, torch.cat([ema_sorted[k].reshape(-1) for k in order])) < 1e-6
