@@ -79,6 +79,19 @@ def roi_align(features, rois, aligned_height, aligned_width, spatial_scale):
     return _RoiFn.apply(features, rois, int(aligned_height), int(aligned_width), float(spatial_scale))
 
 
+def lstm_bidir_forward(table, captions, lens, wt_ih, wt_hh, b_ih, b_hh, max_len):
+    """The fused embedding + bidirectional LSTM kernel's contract on the oracle's cell loops
+    (wt_* are the transposed [2][I or H][4H] copies the product hands to the kernel)."""
+    from oracle import torch_model as tm
+    sd = {"encoder.weight": table}
+    for d, suffix in enumerate(("", "_reverse")):
+        sd["rnn.weight_ih_l0" + suffix] = wt_ih[d].t()
+        sd["rnn.weight_hh_l0" + suffix] = wt_hh[d].t()
+        sd["rnn.bias_ih_l0" + suffix] = b_ih[d]
+        sd["rnn.bias_hh_l0" + suffix] = b_hh[d]
+    return tm.rnn_encoder_forward(sd, captions, lens, int(max_len))
+
+
 def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, n=None):
     n = p.numel() if n is None else int(n)
     pn, mn, vn = tr.adam_step(p[:n], g[:n] * grad_scale, m[:n], v[:n], lr, beta1, beta2, eps, step)
@@ -100,7 +113,8 @@ def get_conv_math():
 
 
 API = ("conv2d", "conv2d_frozen", "linear", "norm_act", "norm_act_eval", "attn_general", "attn_bu", "masked_max",
-       "softmax_strided", "roi_align", "avgpool2s1", "bilinear_resize", "adam_step_", "ema_update_")
+       "softmax_strided", "roi_align", "avgpool2s1", "bilinear_resize", "lstm_bidir_forward", "adam_step_",
+       "ema_update_")
 
 
 def install(monkeypatch):

@@ -108,3 +108,73 @@ def test_product_trainer_host_logic_matches_oracle(monkeypatch, branch_num, B, u
     order = [k for k, _ in tr.netG.named_parameters()]
     ema_sorted = {k: a for k, a in zip(sorted(k for k in sds["G"] if sds["G"][k].requires_grad), ema)}
     assert rel_l2(tr.avg_param_G, torch.cat([ema_sorted[k].reshape(-1) for k in order])) < 1e-6
+
+
+def test_real_data_directory_through_the_training_step(monkeypatch):
+    """tests/golden/data_tiny -> TrainDataset -> default collate -> prepare_data -> batch_dict ->
+    condGANTrainer.train_step with the frozen caption encoder and the GloVe table (stage-1 tree):
+    the whole real-data contract of reference trainer.py:357-472 on CPU, against the oracle step fed
+    with the embeddings the oracle's own RNN_ENCODER restatement computes."""
+    import os
+    import numpy as np
+    from torch.utils.data.dataloader import default_collate
+    from conftest import ROOT
+    import model as M
+    import trainDataset
+    import trainer as T
+    from oracle import ref_harness as rh, torch_model as tm
+    from miscc.config import cfg
+    cpu_ops_shim.install(monkeypatch)
+    monkeypatch.setattr(cfg.TREE, "BRANCH_NUM", 1)
+    monkeypatch.setattr(cfg.TRAIN, "BATCH_SIZE", 2)
+    monkeypatch.setattr(cfg.TRAIN, "NET_G", '')
+    torch.set_num_threads(8)
+    ds = trainDataset.TrainDataset(os.path.join(ROOT, "tests", "golden", "data_tiny"), "train", base_size=64,
+                                   device_hmaps=True)
+    nc = ds.num_classes
+    B = 2
+    g0 = torch.Generator().manual_seed(11)
+    regions_c, code_c = torch.randn(B, 256, 17, 17, generator=g0), torch.randn(B, 256, generator=g0)
+    ds.image_encoder = _ConstEncoder(regions_c, code_c)
+    ds.text_encoder = rh.seeded_state_(M.RNN_ENCODER(ds.n_words, nhidden=cfg.TEXT.EMBEDDING_DIM), 91).eval()
+    for p in ds.text_encoder.parameters():
+        p.requires_grad_(False)
+    tr = T.condGANTrainer('', None, ds, device=torch.device("cpu"))
+    tr.batch_size = B
+    nets = [ds.text_encoder, ds.image_encoder, rh.seeded_state_(M.G_NET(nc), 92),
+            [rh.seeded_state_(M.PAT_D_NET64(), 93)], [rh.seeded_state_(M.SHP_D_NET64(nc), 94)],
+            rh.seeded_state_(M.OBJ_SS_D_NET(nc), 95), rh.seeded_state_(M.OBJ_LS_D_NET(nc), 96), 0]
+    sds = {"G": _sd_of(nets[2]), "pat": [_sd_of(nets[3][0])], "shp": [_sd_of(nets[4][0])]}
+    adam = lambda sd: torch.optim.Adam(tm.params_of(sd), lr=2e-4, betas=(0.5, 0.999))   # noqa: E731
+    opts = {"G": adam(sds["G"]), "pat": [adam(sds["pat"][0])], "shp": [adam(sds["shp"][0])]}
+    ema = [p.detach().clone() for p in tm.params_of(sds["G"])]
+    for m in [nets[2], nets[5], nets[6]] + nets[3] + nets[4]:
+        m.train()
+    tr.build_models = lambda: nets
+    tr.setup()
+    assert tr.clabels_emb.shape == (nc, 50)
+
+    np.random.seed(4)
+    collated = default_collate([ds[0], ds[1]])                        # two images with boxes
+    prepared = trainDataset.prepare_data(collated, None, nc)
+    batch = trainDataset.batch_dict(prepared, tr.clabels_emb)
+    noise = torch.randn(B, cfg.GAN.Z_DIM, generator=g0)
+    eps = torch.randn(B, cfg.GAN.CONDITION_DIM, generator=g0)
+    tr.netG.ca_net.fixed_eps = eps
+
+    # the oracle's inputs: embeddings from its own encoder restatement (reference trainer.py:367-383)
+    enc_sd = {k: v.detach() for k, v in ds.text_encoder.state_dict().items()}
+    caps, lens = batch["captions"], batch["cap_lens"]
+    words, sent = tm.rnn_encoder_forward(enc_sd, caps, lens, int(lens.max()))
+    nw = words.size(2)
+    glove = ds.glove_embed.weight.detach()[batch["glove_captions"].reshape(-1)].view(B, -1, 50)[:, :nw].transpose(1, 2)
+    ob = dict(batch, words_embs=words, sent_emb=sent, glove_words_embs=glove, mask=(caps == 0)[:, :nw],
+              noise=noise, ca_eps=eps)
+    random.seed(5)
+    want = tm.train_step(sds, opts, ema, ob, image_encoder=_ConstEncoder(regions_c, code_c), use_obj=False)
+    random.seed(5)
+    got = tr.train_step(batch, noise=noise)
+    for k in ("errPatD0", "errShpD0", "errG", "kl"):
+        assert abs(got[k].item() - want[k].item()) < 1e-4 * abs(want[k].item()) + 1e-6, (k, got[k].item(), want[k].item())
+    assert rel_l2(got["fake_imgs"][0], want["fake_imgs"][0]) < 1e-5
+    assert all(torch.isfinite(v).all() for v in got.values() if torch.is_tensor(v))
