@@ -178,3 +178,53 @@ def test_real_data_directory_through_the_training_step(monkeypatch):
         assert abs(got[k].item() - want[k].item()) < 1e-4 * abs(want[k].item()) + 1e-6, (k, got[k].item(), want[k].item())
     assert rel_l2(got["fake_imgs"][0], want["fake_imgs"][0]) < 1e-5
     assert all(torch.isfinite(v).all() for v in got.values() if torch.is_tensor(v))
+
+
+def test_train_loop_checkpoints_and_resume(monkeypatch, tmp_path):
+    """condGANTrainer.train() over a DataLoader of the committed data directory (reference loader
+    tuples), one epoch of two steps on the CPU shim: the checkpoint files have the reference's names,
+    the generator is saved with the EMA weights swapped in, and cfg.TRAIN.NET_G resumes from them
+    (reference trainer.py:155-193, 251-273)."""
+    import os
+    from conftest import ROOT
+    import model as M
+    import trainDataset
+    import trainer as T
+    from oracle import ref_harness as rh
+    from miscc.config import cfg
+    cpu_ops_shim.install(monkeypatch)
+    monkeypatch.setattr(cfg.TREE, "BRANCH_NUM", 1)
+    monkeypatch.setattr(cfg.TRAIN, "BATCH_SIZE", 2)
+    monkeypatch.setattr(cfg.TRAIN, "NET_G", '')
+    monkeypatch.setattr(cfg.TRAIN, "MAX_EPOCH", 1)
+    monkeypatch.setattr(cfg.TRAIN, "FLAG", True)
+    torch.set_num_threads(8)
+    ds = trainDataset.TrainDataset(os.path.join(ROOT, "tests", "golden", "data_tiny"), "train", base_size=64,
+                                   device_hmaps=True)
+    g0 = torch.Generator().manual_seed(12)
+    ds.image_encoder = _ConstEncoder(torch.randn(2, 256, 17, 17, generator=g0), torch.randn(2, 256, generator=g0))
+    ds.text_encoder = rh.seeded_state_(M.RNN_ENCODER(ds.n_words, nhidden=cfg.TEXT.EMBEDDING_DIM), 91).eval()
+    for p in ds.text_encoder.parameters():
+        p.requires_grad_(False)
+    torch.manual_seed(0)
+    loader = trainDataset.build_loader(ds, 2, workers=0, shuffle=False)
+    tr = T.condGANTrainer(str(tmp_path), loader, ds, device=torch.device("cpu"))
+    tr.train()
+    assert tr.gen_iterations == 2
+    model_dir = tmp_path / "Model"
+    names = sorted(os.listdir(str(model_dir)))
+    assert names == ["netG_epoch_0.pth", "netG_epoch_1.pth", "netObjLSD.pth", "netObjSSD.pth",
+                     "netPatD0.pth", "netShpD0.pth"]
+    saved = torch.load(str(model_dir / "netG_epoch_1.pth"))
+    assert list(saved.keys()) == list(tr.netG.state_dict().keys())
+    # saved generator = EMA weights (flat order = parameter order), live generator = raw weights
+    flat_saved = torch.cat([saved[k].reshape(-1) for k, _ in tr.netG.named_parameters()])
+    assert torch.allclose(flat_saved, tr.avg_param_G) and not torch.allclose(flat_saved, tr.optimizerG.arena.flat)
+    # resume
+    monkeypatch.setattr(cfg.TRAIN, "NET_G", str(model_dir / "netG_epoch_1.pth"))
+    tr2 = T.condGANTrainer(str(tmp_path), loader, ds, device=torch.device("cpu"))
+    tr2.setup()
+    assert tr2.start_epoch == 2
+    assert torch.allclose(tr2.optimizerG.arena.flat, tr.avg_param_G)
+    d0 = torch.load(str(model_dir / "netPatD0.pth"))
+    assert all(torch.equal(d0[k], v) for k, v in tr2.netsPatD[0].state_dict().items())
