@@ -137,3 +137,14 @@ def install(monkeypatch):
     monkeypatch.setattr(model, "_LIFT", [])
     monkeypatch.setattr(utils, "_HOST", [])
     return shim
+
+
+class _Patch(object):
+    """monkeypatch.setattr without pytest (spawned worker processes)."""
+
+    def setattr(self, obj, name, value):
+        setattr(obj, name, value)
+
+
+def install_plain():
+    return install(_Patch())

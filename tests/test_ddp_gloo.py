@@ -121,3 +121,97 @@ def test_param_arena_keeps_views_and_survives_zero_grad_none():
         assert p.grad.data_ptr() == gv.data_ptr()
     arena.flat.mul_(2.0)                                 # parameters are views of the arena
     assert torch.equal(torch.cat([p.detach().reshape(-1) for p in net.parameters()]), before * 2)
+
+
+def _trainer_worker(rank, world, port, q):
+    """One rank of the product trainer (stage-1 + stage-2 tree, both object discriminators) on the CPU
+    shim of the kernels; rank 1's boxes are all small, so its large-scale object discriminator sees no
+    box and contributes zeros -- it must still take the same update as rank 0."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "obj-gan_amd"), os.path.join(root, "tests")]
+    import random
+    import cpu_ops_shim
+    import model as M
+    import synth_batch
+    import trainer as T
+    from miscc.config import cfg
+    from oracle import ref_harness as rh
+    cpu_ops_shim.install_plain()
+    torch.set_num_threads(4)
+    cfg.TREE.BRANCH_NUM = 2
+    cfg.TRAIN.BATCH_SIZE = 2
+    cfg.TRAIN.NET_G = ''
+    B = 2
+
+    class Enc(object):
+        def __init__(self):
+            g0 = torch.Generator().manual_seed(5)
+            self.r, self.c = torch.randn(B, 256, 17, 17, generator=g0), torch.randn(B, 256, generator=g0)
+
+        def __call__(self, x):
+            return self.r, self.c
+
+    class DS(object):
+        num_classes = 80
+    ds = DS()
+    ds.image_encoder = Enc()
+    tr = T.condGANTrainer('', None, ds, device=torch.device("cpu"))
+    tr.batch_size = B
+    # rank-dependent initial weights: setup() must broadcast rank 0's
+    nets = [None, ds.image_encoder, rh.seeded_state_(M.G_NET(80), 200 + rank),
+            [rh.seeded_state_(c(), 210 + rank + i) for i, c in enumerate((M.PAT_D_NET64, M.PAT_D_NET128))],
+            [rh.seeded_state_(c(80), 220 + rank + i) for i, c in enumerate((M.SHP_D_NET64, M.SHP_D_NET128))],
+            rh.seeded_state_(M.OBJ_SS_D_NET(80), 230 + rank), rh.seeded_state_(M.OBJ_LS_D_NET(80), 240 + rank), 0]
+    for m in [nets[2], nets[5], nets[6]] + nets[3] + nets[4]:
+        m.train()
+    orig_build = T.condGANTrainer.build_models
+
+    def build(self):
+        for net in [nets[2], nets[5], nets[6]] + nets[3] + nets[4]:
+            for t in list(net.parameters()) + list(net.buffers()):
+                dist.broadcast(t.data, src=0)
+        return nets
+    tr.build_models = lambda: build(tr)
+    tr.setup()
+    init_ls = tr.optimizerObjLSD.arena.flat.clone()
+    b = synth_batch.make_batch(B, seed=300 + rank, branch_num=2)
+    if rank == 1:                                   # no box reaches the large-scale threshold on this rank
+        for r in b["rois"]:
+            r[:, :, 2:4] = r[:, :, 2:4].clamp(max=6.0 * r[:, :, 2:4].max() / 64.0)
+        b["rois"][0][:, :, 2:4] = b["rois"][0][:, :, 2:4].clamp(max=6.0)
+        b["rois"][1][:, :, 2:4] = b["rois"][1][:, :, 2:4].clamp(max=12.0)
+        b["fm_rois"][:, :, 2:4] = b["fm_rois"][:, :, 2:4].clamp(max=3.0)
+    tr.netG.ca_net.fixed_eps = b["ca_eps"]
+    random.seed(7 + rank)
+    out = tr.train_step(b, noise=b["noise"])
+    # numpy copies: a tensor put on the queue travels through shared memory owned by this process
+    q.put((rank, "errObjLSD" in out, tr.optimizerG.arena.flat.numpy().copy(),
+           tr.optimizersPatD[1].arena.flat.numpy().copy(), tr.optimizerObjLSD.arena.flat.numpy().copy(),
+           init_ls.numpy().copy(), tr.avg_param_G.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_trainer_step_keeps_replicas_identical():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (r0, ls0, g0, d0, objls0, init0, ema0), (r1, ls1, g1, d1, objls1, init1, ema1) = res
+    assert ls0 and not ls1, "rank 0 has large boxes, rank 1 must have none for this test to bite"
+    import numpy as np
+    assert np.array_equal(init0, init1), "setup() did not broadcast rank 0's weights"
+    assert np.array_equal(g0, g1) and np.array_equal(d0, d1) and np.array_equal(ema0, ema1), "replicas diverged"
+    assert np.array_equal(objls0, objls1), "conditional object-discriminator update diverged across ranks"
+    assert not np.array_equal(objls0, init0), "the large-scale object discriminator was not updated at all"
