@@ -18,50 +18,49 @@ class TrainDataset(data.Dataset):
     """`device_hmaps=True` is the lean hand-over: items carry empty layout maps and `prepare_data`
     rebuilds them on the device from the per-slot box masks (`hmaps_from_box_masks`).  The 80-channel
     float64 maps are 55 MB per sample on the host and 27 MB over PCIe, the ten box masks they are
-    sums of are 3.4 MB."""
+    sums of are 3.4 MB.
+
+    Attributes follow the reference class (trainer and evaluator read them): filenames, captions,
+    ixtoword / wordtoix / n_words, glove_captions / glove_ixtoword / glove_wordtoix / glove_embed,
+    cat_labels / cat_label_lens / sorted_cat_label_indices, class_id, cats_dict / cats_index_dict,
+    img_bytes, insanns_dict."""
 
     def __init__(self, data_dir, split='train', base_size=64, device_hmaps=False):
         self.device_hmaps = device_hmaps
-        self.embeddings_num = cfg.TEXT.CAPTIONS_PER_IMAGE
-        self.imsize = []
-        for _ in range(cfg.TREE.BRANCH_NUM):
-            self.imsize.append(base_size)
-            base_size = base_size * 2
-        self.fmsize = cfg.ROI.FM_SIZE
         self.data_dir = data_dir
-        split_dir = os.path.join(data_dir, split)
-
-        train_names = load_filenames(data_dir, 'train')
-        test_names = load_filenames(data_dir, 'test')
-        self.filenames, self.captions, self.ixtoword, self.wordtoix, self.n_words = \
-            load_text_data(data_dir, split, train_names, test_names)
-        self.glove_captions, self.glove_ixtoword, self.glove_wordtoix, self.glove_embed = \
-            load_glove_emb(data_dir, split, train_names, test_names)
+        self.embeddings_num = cfg.TEXT.CAPTIONS_PER_IMAGE
+        self.imsize = [base_size * (2 ** b) for b in range(cfg.TREE.BRANCH_NUM)]
+        self.fmsize = cfg.ROI.FM_SIZE
+        names = {s: load_filenames(data_dir, s) for s in ('train', 'test')}
+        text = load_text_data(data_dir, split, names['train'], names['test'])
+        self.filenames, self.captions, self.ixtoword, self.wordtoix, self.n_words = text
+        glove = load_glove_emb(data_dir, split, names['train'], names['test'])
+        self.glove_captions, self.glove_ixtoword, self.glove_wordtoix, self.glove_embed = glove
+        # third entry: the permutation from length-sorted rows back to categories.txt order
         self.cat_labels, self.cat_label_lens, self.sorted_cat_label_indices = \
             load_cat_label(data_dir, self.glove_wordtoix)
-        self.class_id = load_class_id(split_dir, len(self.filenames))
         self.number_example = len(self.filenames)
+        self.class_id = load_class_id(os.path.join(data_dir, split), self.number_example)
         self.cats_dict, self.cats_index_dict = load_cats(data_dir, self.wordtoix)
         self.num_classes = len(self.cats_index_dict)
         self.img_bytes = load_imgs_data(data_dir, split, self.filenames)
         self.insanns_dict = load_anns_data(data_dir, split, '_gt_insanns.pickle', 'gt', self.filenames,
                                            self.imsize, self.fmsize, self.cats_index_dict)
 
-    def __getitem__(self, index):
-        key = self.filenames[index]
-        cls_id = self.class_id[index]
-        imgs = get_imgs(self.img_bytes[index], self.imsize)
-        hmaps, _, _, _, rois, fm_rois, num_rois, bt_masks, fm_bt_masks = get_hmaps_rois(
-            self.insanns_dict[key], self.imsize, self.fmsize, self.cats_index_dict,
-            with_hmaps=not self.device_hmaps)
-        sent_ix = random.randint(0, self.embeddings_num)          # one of the image's captions
-        new_sent_ix = index * self.embeddings_num + sent_ix
-        caps, glove_caps, cap_len = get_caption(self.captions, self.glove_captions, new_sent_ix)
-        return imgs, caps, glove_caps, cap_len, hmaps, rois, fm_rois, num_rois, \
-            bt_masks, fm_bt_masks, cls_id, key
-
     def __len__(self):
-        return len(self.filenames)
+        return self.number_example
+
+    def __getitem__(self, index):
+        """-> (imgs[3], caption ids [12, 1], GloVe ids [12, 1], length, hmaps[3], rois[3], fm_rois,
+        num_rois, bt_masks[3], fm_bt_masks, class id, key) -- the reference item tuple."""
+        key = self.filenames[index]
+        maps = get_hmaps_rois(self.insanns_dict[key], self.imsize, self.fmsize, self.cats_index_dict,
+                              with_hmaps=not self.device_hmaps)
+        hmaps, rois, fm_rois, num_rois, bt_masks, fm_bt_masks = maps[0], maps[4], maps[5], maps[6], maps[7], maps[8]
+        pick = index * self.embeddings_num + random.randint(0, self.embeddings_num)    # one of the image's captions
+        caps, glove_caps, cap_len = get_caption(self.captions, self.glove_captions, pick)
+        return (get_imgs(self.img_bytes[index], self.imsize), caps, glove_caps, cap_len, hmaps, rois, fm_rois,
+                num_rois, bt_masks, fm_bt_masks, self.class_id[index], key)
 
 
 def hmaps_from_box_masks(bt_masks, rois0, num_classes):
@@ -77,36 +76,36 @@ def hmaps_from_box_masks(bt_masks, rois0, num_classes):
 
 
 def prepare_data(data, device=None, num_classes=None):
-    """Collated loader output -> the reference's 12-item list: everything sorted by caption
-    length (descending, torch.sort like the reference), float32 maps, tensors on `device`
-    (reference trainDataset.py:79-127; `device=None` keeps them where they are, the reference's
-    cfg.CUDA False branch)."""
-    imgs, captions, glove_captions, captions_lens, hmaps, rois, fm_rois, \
-        num_rois, bt_masks, fm_bt_masks, class_ids, keys = data
-    sorted_cap_lens, sorted_cap_indices = torch.sort(captions_lens, 0, True)
-    mv = (lambda t: t.to(device, non_blocking=True)) if device is not None else (lambda t: t)
+    """Collated loader output -> the reference's 12-item list: every per-sample tensor reordered by
+    caption length (descending; `torch.sort` like the reference, so ties fall the same way), maps as
+    float32, tensors moved to `device` (None keeps them where they are: the reference's cfg.CUDA False
+    branch).  Reference trainDataset.py:79-127."""
+    (imgs, captions, glove_captions, cap_lens, hmaps, rois, fm_rois, num_rois, bt_masks, fm_bt_masks,
+     class_ids, keys) = data
+    lens_sorted, order = torch.sort(cap_lens, 0, True)
 
-    num_rois = num_rois[sorted_cap_indices]
-    real_hmaps, real_imgs, real_bt_masks, real_rois = [], [], [], []
-    for i in range(len(imgs)):
-        real_imgs.append(mv(imgs[i][sorted_cap_indices]))
-        real_rois.append(mv(rois[i][sorted_cap_indices]))
-        bt = mv(bt_masks[i][sorted_cap_indices])
-        if hmaps[i].numel() == 0:           # lean hand-over: rebuild on the device, before the float32 cast
+    def put(t):
+        return t if device is None else t.to(device, non_blocking=True)
+
+    def take(t):
+        return put(t[order])
+    branches = range(len(imgs))
+    out_imgs = [take(imgs[b]) for b in branches]
+    out_rois = [take(rois[b]) for b in branches]
+    out_masks, out_hmaps = [], []
+    for b in branches:
+        masks = take(bt_masks[b])
+        if hmaps[b].numel() == 0:           # lean hand-over: rebuild on the device, before the float32 cast
             if num_classes is None:
                 raise ValueError("prepare_data: num_classes is needed to rebuild the layout maps")
-            real_hmaps.append(hmaps_from_box_masks(bt, mv(rois[0][sorted_cap_indices]), num_classes))
+            out_hmaps.append(hmaps_from_box_masks(masks, out_rois[0], num_classes))
         else:
-            real_hmaps.append(mv(hmaps[i][sorted_cap_indices].float()))
-        real_bt_masks.append(bt.float())
-    fm_rois = mv(fm_rois[sorted_cap_indices])
-    fm_bt_masks = mv(fm_bt_masks[sorted_cap_indices].float())
-    captions = mv(captions[sorted_cap_indices].squeeze())
-    glove_captions = mv(glove_captions[sorted_cap_indices].squeeze())
-    class_ids = class_ids[sorted_cap_indices].numpy()
-    keys = [keys[i] for i in sorted_cap_indices.numpy()]
-    return [real_imgs, captions, glove_captions, mv(sorted_cap_lens), real_hmaps, real_rois,
-            fm_rois, mv(num_rois), real_bt_masks, fm_bt_masks, class_ids, keys]
+            out_hmaps.append(take(hmaps[b].float()))
+        out_masks.append(masks.float())
+    order_list = order.tolist()
+    return [out_imgs, take(captions).squeeze(), take(glove_captions).squeeze(), put(lens_sorted), out_hmaps,
+            out_rois, take(fm_rois), take(num_rois), out_masks, take(fm_bt_masks).float(),
+            class_ids[order].numpy(), [keys[i] for i in order_list]]
 
 
 def batch_dict(prepared, clabels_emb):
