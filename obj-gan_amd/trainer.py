@@ -374,6 +374,36 @@ class condGANTrainer(object):
         self.gen_iterations += 1
         return out
 
+    # ---- sampling (reference trainer.py:275-283, evaluator.py:330-340) -----------------------------
+    @torch.no_grad()
+    def sample(self, batch, noise, words_embs, sent_emb, glove_words_embs, mask, use_ema=True):
+        """Generator inference in eval mode (BatchNorm on its running statistics), by default with the
+        EMA weights swapped into the arena for the duration of the call -- what the reference does with
+        copy_G_params / load_params around save_img_results.  The swap goes through the arena, so its
+        epoch is bumped on the way in and out: packed filter banks are keyed on it.
+        -> (fake_imgs, attention maps, bottom-up attention maps)"""
+        b = batch
+        arena = self.optimizerG.arena
+        backup = None
+        if use_ema:
+            backup = arena.flat.clone()
+            arena.flat.copy_(self.avg_param_G)
+            arena.epoch[0] += 1
+        was_training = self.netG.training
+        self.netG.eval()
+        try:
+            clabels_feat = form_clabels_feat(b["clabels_emb"], b["rois"][0], b["num_rois"])
+            glb = int(_host(b["num_rois"]).max())
+            fake_imgs, _, att, bt_att, _, _ = self.netG(
+                noise, sent_emb, words_embs, glove_words_embs, clabels_feat, mask, b["hmaps"], b["rois"],
+                b["fm_rois"], b["num_rois"], b["bt_masks"], b["fm_bt_masks"], glb)
+        finally:
+            self.netG.train(was_training)
+            if backup is not None:
+                arena.flat.copy_(backup)
+                arena.epoch[0] += 1
+        return fake_imgs, att, bt_att
+
     # ---- checkpoints (reference trainer.py:251-273) ---------------------------------------------------
     def save_model(self, netG, avg_param_G, netsPatD, netsShpD, netObjSSD, netObjLSD, epoch):
         if self.rank != 0:

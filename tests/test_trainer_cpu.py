@@ -228,3 +228,63 @@ def test_train_loop_checkpoints_and_resume(monkeypatch, tmp_path):
     assert torch.allclose(tr2.optimizerG.arena.flat, tr.avg_param_G)
     d0 = torch.load(str(model_dir / "netPatD0.pth"))
     assert all(torch.equal(d0[k], v) for k, v in tr2.netsPatD[0].state_dict().items())
+
+
+def test_sampling_with_ema_weights(monkeypatch):
+    """condGANTrainer.sample(): eval-mode generator with the EMA weights swapped in through the arena
+    (epoch bumped both ways, training weights restored) against the oracle's g_net under bn_eval()
+    on a state dict holding the EMA values."""
+    import model as M
+    import synth_batch
+    import trainer as T
+    from oracle import ref_harness as rh, torch_model as tm
+    from miscc.config import cfg
+    from miscc.utils import form_clabels_feat
+    cpu_ops_shim.install(monkeypatch)
+    monkeypatch.setattr(cfg.TREE, "BRANCH_NUM", 2)
+    monkeypatch.setattr(cfg.TRAIN, "BATCH_SIZE", 2)
+    monkeypatch.setattr(cfg.TRAIN, "NET_G", '')
+    torch.set_num_threads(8)
+    B = 2
+
+    class DS(object):
+        num_classes = 80
+    tr = T.condGANTrainer('', None, DS(), device=torch.device("cpu"))
+    tr.batch_size = B
+    G = rh.seeded_state_(M.G_NET(80), 31)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for k, v in G.state_dict().items():
+            if "running_mean" in k:
+                v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+            elif "running_var" in k:
+                v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+    nets = [None, None, G, [rh.seeded_state_(M.PAT_D_NET64(), 32), rh.seeded_state_(M.PAT_D_NET128(), 33)],
+            [rh.seeded_state_(M.SHP_D_NET64(80), 34), rh.seeded_state_(M.SHP_D_NET128(80), 35)],
+            rh.seeded_state_(M.OBJ_SS_D_NET(80), 36), rh.seeded_state_(M.OBJ_LS_D_NET(80), 37), 0]
+    tr.build_models = lambda: nets
+    tr.setup()
+    raw = tr.optimizerG.arena.flat.clone()
+    tr.avg_param_G.copy_(raw * 0.9 + 0.01)                      # an EMA buffer that differs from the live weights
+    epoch0 = tr.optimizerG.arena.epoch[0]
+    b = synth_batch.make_batch(B, seed=55, branch_num=2)
+    tr.netG.ca_net.fixed_eps = b["ca_eps"]
+    fake, att, bt_att = tr.sample(b, b["noise"], b["words_embs"], b["sent_emb"], b["glove_words_embs"], b["mask"])
+    assert torch.equal(tr.optimizerG.arena.flat, raw) and tr.netG.training
+    assert tr.optimizerG.arena.epoch[0] == epoch0 + 2
+    # oracle: the same state dict with the EMA values in place of the parameters
+    sd = {k: v.detach().clone() for k, v in tr.netG.state_dict().items()}
+    off = 0
+    for k, p in tr.netG.named_parameters():
+        sd[k] = tr.avg_param_G[off:off + p.numel()].view_as(p).clone()
+        off += p.numel()
+    cl = form_clabels_feat(b["clabels_emb"], b["rois"][0], b["num_rois"])
+    with tm.bn_eval(), torch.no_grad():
+        want = tm.g_net(sd, b["noise"], b["sent_emb"], b["words_embs"], b["glove_words_embs"], cl, b["mask"],
+                        b["hmaps"], b["rois"], b["fm_rois"], b["num_rois"], b["bt_masks"], b["fm_bt_masks"],
+                        int(b["num_rois"].max()), b["ca_eps"], branch_num=2)
+    assert len(fake) == 2
+    for i in range(2):
+        assert rel_l2(fake[i], want[0][i]) < 1e-5, i
+    live, _, _ = tr.sample(b, b["noise"], b["words_embs"], b["sent_emb"], b["glove_words_embs"], b["mask"], use_ema=False)
+    assert rel_l2(live[1], fake[1]) > 1e-3                      # the swap really changed the weights
