@@ -146,19 +146,19 @@ int objgan_bilinear_backward(const float* dy, float* dx, long planes, int ih, in
                              void* stream);
 int objgan_sum2x2(const float* dy, float* dx, long planes, int h, int w, void* stream);
 int objgan_reflect_fold(const float* dxp, float* dx, long planes, int h, int w, void* stream);
-/* ---- Winograd F(2x2, 3x3) data transforms (experimental; the host side opts in) ---------------
- * Replaces nothing in the reference: cuDNN picks its own algorithm behind nn.Conv2d (reference
- * image_generation/model.py:36-39, 63-81); here the 3x3 stride-1 convolutions of the residual blocks can
- * run as 16 1x1 convolutions between these two transforms.
- * V:  [16][N][C][TH*TW] = B^T d B of the 4x4 patch starting at (2*ty - pad, 2*tx - pad); refl = 1
- *     reflects out-of-range pixels, 0 reads zeros.   Mt: [16][N][M][TH*TW] -> y [N][M][2*TH][2*TW]. */
-int objgan_wino_input_f23(const float* x, float* V, int N, int C, int H, int W, int TH, int TW,
-                          int pad, int refl, void* stream);
-int objgan_wino_output_f23(const float* Mt, float* y, int N, int M, int TH, int TW, void* stream);
 /* torch.optim.Adam update over flat arenas; the gradient is pre-multiplied by grad_scale
- * (1/world_size under data parallelism: the RCCL all-reduce is a plain sum). */
-int objgan_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
-                     float beta2, float eps, int step, float grad_scale, void* stream);
+ * (1/world_size under data parallelism: the RCCL all-reduce is a plain sum).  Hyper-parameters are
+ * doubles like torch's python floats: 1 - beta and lr / (1 - beta1^t) are evaluated in double. */
+int objgan_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1,
+                     double beta2, double eps, int step, float grad_scale, void* stream);
+/* The same update, taken only when the DEVICE flag flag[0] > 0, with the step counter on the device
+ * (state: 3 doubles {steps, beta1^steps, beta2^steps}, initialised {0, 1, 1}; coef: 3 floats scratch).
+ * Replaces the host-side `if float(errObjSSD) > 0:` of reference image_generation/trainer.py:429,440
+ * under data parallelism: the flag rides behind the gradient arena through the all-reduce, so every
+ * rank takes or skips the same update without a device->host read. */
+int objgan_adam_step_gated(float* p, const float* g, float* m, float* v, long n, double lr, double beta1,
+                           double beta2, double eps, double* state, const float* flag, float* coef,
+                           float grad_scale, void* stream);
 int objgan_ema_update(float* avg, const float* p, long n, float decay, float one_minus_decay,
                       void* stream);
 

@@ -496,8 +496,6 @@ struct PackArgs {
                          // 2: wt[Ck][Tg][Mpad] with Mpad = MT (thin direct kernel)
                          // 3: bf16 wt[M][Krow], Krow = Kpad rounded up to 32 (bf16 MFMA kernels)
     signed char src_tap[OG_MAX_TAPS];
-    int korder;          // m_major 1 / 3 only.  0: k = tap * Cp + channel (tap-major);
-                         // 1: k = chunk * (Tg * 16) + tap * 16 + (channel & 15) (16-channel chunk-major)
 };
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
@@ -518,15 +516,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
             m = a.m_major ? (int)(i / Krow) : (int)(i % a.Mpad);
             const int k = a.m_major ? (int)(i % Krow) : (int)(i / a.Mpad);
             pad = k >= Kpad;
-            if (a.korder && a.m_major) {
-                const int per = a.Tg * 16;
-                const int chunk = k / per, r = k - chunk * per;
-                t = pad ? 0 : r >> 4;
-                ck = chunk * 16 + (r & 15);
-            } else {
-                t = pad ? 0 : k / a.Cp;
-                ck = k - t * a.Cp;
-            }
+            t = pad ? 0 : k / a.Cp;
+            ck = k - t * a.Cp;
         }
         float v = 0.f;
         if (!pad && m < a.M && ck < a.Ck) {
@@ -918,11 +909,9 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
 // dy), which all four waves share, is staged through LDS -- and for TM = 1 (thin outputs) it is read
 // straight from L1/L2 as two 16-byte loads per lane, so those launches run without LDS and without
 // barriers at all: waves are independent and latency is hidden by occupancy.
-// KORD (experimental, OG_KORDER=1): chunk-major K -- all taps of one 16-channel chunk back to back, so
-// that the shifted windows of a 3x3 / 4x4 filter re-read lines that are still in L1 (tap-major order
-// streams every channel between two taps of the same pixel: each tap is an L2 fill, which is what
-// bounds the short tiles).  The tap geometry is then re-evaluated every step.
-template <int TM, bool ADIRECT = false, bool BF = false, bool KORD = false>
+// (A chunk-major K order -- all taps of a 16-channel chunk back to back, hoping for L1 hits between the
+// shifted windows -- was measured in round 2 and lost on every shape: profiles/r02_ab_convbench_variants.txt.)
+template <int TM, bool ADIRECT = false, bool BF = false>
 __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
     constexpr int BM = 32 * TM;
     constexpr int BN = 128;
@@ -1007,17 +996,11 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, bvoff, (cb_ld + i) * HW * 4, 0));
-        if (KORD) {
+        cb_ld += BK;
+        if (cb_ld >= a.Cp) {
+            cb_ld = 0;
             t_ld += 1;
-            if (t_ld >= a.T) { t_ld = 0; cb_ld += BK; }
-            tap_geometry(t_ld);
-        } else {
-            cb_ld += BK;
-            if (cb_ld >= a.Cp) {
-                cb_ld = 0;
-                t_ld += 1;
-                if (t_ld < a.T) tap_geometry(t_ld);
-            }
+            if (t_ld < a.T) tap_geometry(t_ld);
         }
     };
     auto load_b = [&](float (&rb)[NB]) {
@@ -1058,13 +1041,8 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
     const int nk = a.ksplit_steps > 0 ? min(nk_all, kt0 + a.ksplit_steps) : nk_all;
     {
         const int sub0 = BF ? 2 * kt0 : kt0;            // first 16-channel chunk of this block
-        if (KORD) {
-            cb_ld = (sub0 / a.T) * BK;
-            t_ld = sub0 - (sub0 / a.T) * a.T;
-        } else {
-            t_ld = sub0 / spt;
-            cb_ld = (sub0 - t_ld * spt) * BK;
-        }
+        t_ld = sub0 / spt;
+        cb_ld = (sub0 - t_ld * spt) * BK;
     }
     tap_geometry(min(t_ld, a.T - 1));
 
@@ -1710,31 +1688,10 @@ static int og_split_target() {
     return v;
 }
 
-static int og_korder() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("OG_KORDER"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v;
-}
-
 static int launch_igemm2(const IgemmArgs& a, int TM, dim3 grid, hipStream_t s) {
     if (og_trace())
         fprintf(stderr, "OGTRACE igemm TM=%d M=%d rows=%d C=%d T=%d Npix=%d grid=%u,%u,%u H=%d W=%d stride=%d\n", TM, a.M,
                 a.m_end - a.m_begin, a.C, a.T, a.N * a.PH * a.PW, grid.x, grid.y, grid.z, a.H, a.W, a.stride);
-    if (og_korder()) {
-#define OG_K3(TMv, AD) do { if (a.math == 1) hipLaunchKernelGGL((conv_igemm3_kernel<TMv, AD, true, true>), grid, dim3(256), 0, s, a); \
-                            else hipLaunchKernelGGL((conv_igemm3_kernel<TMv, AD, false, true>), grid, dim3(256), 0, s, a); } while (0)
-        switch (TM) {
-            case 1: if (a.M <= 32) OG_K3(1, true); else OG_K3(1, false); break;
-            case 2: OG_K3(2, false); break;
-            case 3: OG_K3(3, false); break;
-            case 4: OG_K3(4, false); break;
-            case 5: OG_K3(5, false); break;
-            case 6: OG_K3(6, false); break;
-            default: OG_K3(7, false); break;
-        }
-#undef OG_K3
-        return og_launch_status();
-    }
     if (a.math == 1) {
         switch (TM) {
             case 1: if (a.M <= 32) hipLaunchKernelGGL((conv_igemm3_kernel<1, true, true>), grid, dim3(256), 0, s, a);
@@ -1884,7 +1841,6 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
     p.w = w; p.wt = wt; p.Cout = Cout; p.Cin = Cin; p.Torig = Torig; p.Tg = Tg;
     p.M = M; p.Mpad = (M + 127) / 128 * 128; p.Ck = C; p.Cp = (C + 15) / 16 * 16;
     p.transpose = transpose;
-    p.korder = og_korder();
     int MT = 32;
     p.m_major = og_bank_layout(N, C, H, W, M, Tg, PH, PW, act, math, &MT);
     const bool v2 = p.m_major != 0, thin = p.m_major == 2, bf = p.m_major == 3;
@@ -1946,7 +1902,7 @@ int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float*
             PackArgs p;
             p.w = w; p.wt = wt + ph * bank; p.Cout = Cout; p.Cin = Cin; p.Torig = Torig; p.Tg = Tg;
             p.M = M; p.Mpad = (M + 127) / 128 * 128; p.Ck = C; p.Cp = Cp;
-            p.transpose = 1; p.m_major = math == 1 ? 3 : 1; p.korder = og_korder();
+            p.transpose = 1; p.m_major = math == 1 ? 3 : 1;
             for (int t = 0; t < OG_MAX_TAPS; ++t) p.src_tap[t] = (signed char)(t < Tg ? src_tap[ph * Tg + t] : -1);
             hipLaunchKernelGGL(pack_weights_kernel, dim3(og_stream_grid((long)M * Krow, 256)), dim3(256), 0, s, p);
             int rc = og_launch_status();

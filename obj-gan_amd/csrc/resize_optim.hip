@@ -137,14 +137,58 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restri
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    long n, float lr, float beta1, float beta2,
-                                                   float eps, float bc1, float bc2_sqrt,
+                                                   float omb1, float omb2,
+                                                   float eps, float step_size, float bc2_sqrt,
                                                    float grad_scale) {
-    const float step_size = lr / bc1;
+    // omb = (float)(1.0 - beta) and step_size = (float)(lr / (1 - beta1^t)) are evaluated in double by the
+    // host, as torch does with its python-float hyper-parameters, and rounded once
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i] * grad_scale;   // 1/world_size folds the DDP average in here
-        const float mi = m[i] + (gi - m[i]) * (1.f - beta1);        // exp_avg.lerp_(grad, 1-beta1)
-        const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;    // mul_(beta2).addcmul_
+        const float mi = m[i] + (gi - m[i]) * omb1;                 // exp_avg.lerp_(grad, 1-beta1)
+        const float vi = v[i] * beta2 + omb2 * gi * gi;             // mul_(beta2).addcmul_
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+}
+
+// Gated Adam: the update is taken only when a DEVICE flag is positive, and the step counter lives on the
+// device as well.  This is what keeps the conditional object-discriminator update (reference
+// trainer.py:429,440: `if float(err) > 0`) consistent across data-parallel ranks without a host sync:
+// every rank adds 1 to a flag slot behind its gradient arena when its batch produced a loss, the slot
+// rides along in the gradient all-reduce, and all ranks then take -- or skip -- the same update.
+//   state[0] = steps taken, state[1] = beta1^steps, state[2] = beta2^steps  (doubles, device)
+//   coef[0] = take the update (0/1), coef[1] = lr / (1 - beta1^t), coef[2] = sqrt(1 - beta2^t)
+__global__ void adam_gate_kernel(double* __restrict__ state, const float* __restrict__ flag,
+                                 float* __restrict__ coef, double lr, double beta1, double beta2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool on = flag[0] > 0.f;
+    if (on) {
+        state[0] += 1.0;
+        state[1] *= beta1;
+        state[2] *= beta2;
+    }
+    coef[0] = on ? 1.f : 0.f;
+    coef[1] = (float)(lr / (1.0 - state[1]));
+    coef[2] = (float)sqrt(1.0 - state[2]);
+}
+
+__global__ __launch_bounds__(256) void adam_gated_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v,
+                                                         long n, float lr, float beta1, float beta2,
+                                                         float omb1, float omb2,
+                                                         float eps, const float* __restrict__ coef,
+                                                         float grad_scale) {
+    if (coef[0] <= 0.f) return;
+    const float step_size = coef[1];
+    const float bc2_sqrt = coef[2];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * grad_scale;
+        const float mi = m[i] + (gi - m[i]) * omb1;
+        const float vi = v[i] * beta2 + omb2 * gi * gi;
         m[i] = mi;
         v[i] = vi;
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
@@ -207,15 +251,32 @@ int objgan_reflect_fold(const float* dxp, float* dx, long planes, int h, int w, 
     return og_launch_status();
 }
 
-int objgan_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
-                     float beta2, float eps, int step, float grad_scale, void* stream) {
+int objgan_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1,
+                     double beta2, double eps, int step, float grad_scale, void* stream) {
     OG_ENTRY();
     if (n <= 0) return OG_OK;
     if (step < 1) return OG_BAD_ARGS;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3(og_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                       p, g, m, v, n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+                       p, g, m, v, n, (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1),
+                       (float)(1.0 - beta2), (float)eps, (float)(lr / bc1), (float)sqrt(bc2), grad_scale);
+    return og_launch_status();
+}
+
+// Adam step gated by the device flag `flag[0] > 0`; `state` = 3 doubles on the device initialised to
+// {0, 1, 1}, `coef` = 3 floats of device scratch (see adam_gate_kernel).  Nothing is read back.
+int objgan_adam_step_gated(float* p, const float* g, float* m, float* v, long n, double lr, double beta1,
+                           double beta2, double eps, double* state, const float* flag, float* coef,
+                           float grad_scale, void* stream) {
+    OG_ENTRY();
+    if (n <= 0) return OG_OK;
+    if (!state || !flag || !coef) return OG_BAD_ARGS;
+    hipLaunchKernelGGL(adam_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, flag, coef,
+                       lr, beta1, beta2);
+    hipLaunchKernelGGL(adam_gated_kernel, dim3(og_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       p, g, m, v, n, (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1),
+                       (float)(1.0 - beta2), (float)eps, coef, grad_scale);
     return og_launch_status();
 }
 

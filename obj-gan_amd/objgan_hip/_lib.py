@@ -13,6 +13,7 @@ from . import build as _build
 _c_int = ctypes.c_int
 _c_long = ctypes.c_long
 _c_float = ctypes.c_float
+_c_double = ctypes.c_double
 _ptr = ctypes.c_void_p
 
 # name -> argtypes  (every function returns int: 1 ok, 0 bad args, <0 -hipError)
@@ -53,9 +54,9 @@ SIGNATURES = {
     "objgan_bilinear_backward": [_ptr, _ptr, _c_long, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_sum2x2": [_ptr, _ptr, _c_long, _c_int, _c_int, _ptr],
     "objgan_reflect_fold": [_ptr, _ptr, _c_long, _c_int, _c_int, _ptr],
-    "objgan_wino_input_f23": [_ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr],
-    "objgan_wino_output_f23": [_ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr],
-    "objgan_adam_step": [_ptr, _ptr, _ptr, _ptr, _c_long, _c_float, _c_float, _c_float, _c_float, _c_int, _c_float, _ptr],
+    "objgan_adam_step": [_ptr, _ptr, _ptr, _ptr, _c_long, _c_double, _c_double, _c_double, _c_double, _c_int, _c_float, _ptr],
+    "objgan_adam_step_gated": [_ptr, _ptr, _ptr, _ptr, _c_long, _c_double, _c_double, _c_double, _c_double,
+                               _ptr, _ptr, _ptr, _c_float, _ptr],
     "objgan_ema_update": [_ptr, _ptr, _c_long, _c_float, _c_float, _ptr],
     "objgan_prof_enable": [_c_int],
     "objgan_conv_bank_layout": [_c_int] * 10,

@@ -381,114 +381,7 @@ class _UpConv3x3Fn(torch.autograd.Function):
         return dx, dw_
 
 
-# ---- 3x3 stride-1 convolution as Winograd F(2x2, 3x3) (EXPERIMENTAL, OBJGAN_WINOGRAD=1) ---------------
-# Y = A^T [(G g G^T) .* (B^T d B)] A: 16 multiplies per 2x2 outputs instead of 36.  The two data
-# transforms are HBM-bound kernels (csrc/winograd.hip), the 16 element-wise products are 16 1x1
-# convolutions [M x C] on the transformed tiles and run on the implicit-GEMM kernel unchanged; the
-# data gradient is the same pipeline with the flipped, transposed filters (zero padding 1, or 2
-# and a reflect fold for the reflect-padded form); the weight gradient stays on the direct kernel.
-_WINOGRAD = os.environ.get("OBJGAN_WINOGRAD") == "1"
-_WINO_G = ((1., 0., 0.), (.5, .5, .5), (.5, -.5, .5), (0., 0., 1.))
-_WINO_U = {}        # (weight address, shape, transposed) -> [w, _version, epoch, U, [16 views]]
-
-
-def _wino_bank(w, transposed):
-    """U[xi] = (G g G^T)[xi] as 16 contiguous [M, C, 1, 1] filter banks (g flipped and transposed for
-    the data gradient); rebuilt in place when the weights changed, like _up_bank."""
-    ep = getattr(w, "_og_epoch", None)
-    cacheable = ep is not None or not w.requires_grad
-    G = torch.tensor(_WINO_G, dtype=_F32, device=w.device)
-    g = w.detach()
-    if transposed:
-        g = g.flip(2, 3).transpose(0, 1)
-    if not cacheable:
-        U = torch.einsum("pk,mckl,ql->pqmc", G, g, G).reshape(16, g.shape[0], g.shape[1], 1, 1).contiguous()
-        return [U[i] for i in range(16)], False
-    key = (w.data_ptr(), tuple(w.shape), bool(transposed))
-    ent = _WINO_U.get(key)
-    epv = ep[0] if ep is not None else -1
-    if ent is not None and ent[0] is w and ent[1] == w._version and ent[2] == epv:
-        return ent[4], True
-    if ent is not None and ent[0] is w:
-        U, views = ent[3], ent[4]
-    else:
-        U = torch.empty((16, g.shape[0], g.shape[1], 1, 1), dtype=_F32, device=w.device)
-        views = [U[i] for i in range(16)]
-    U.copy_(torch.einsum("pk,mckl,ql->pqmc", G, g, G).reshape(U.shape))     # bumps the views' _version
-    if len(_WINO_U) >= 512:
-        _WINO_U.clear()
-    _WINO_U[key] = [w, w._version, epv, U, views]
-    return views, True
-
-
-def _wino_conv(x, banks, M, pad, refl, OH, OW):
-    """conv3x3 stride 1 of x [N, C, H, W] -> [N, M, OH, OW] (OH, OW even) through the transforms."""
-    N, C, H, W = x.shape
-    TH, TW = OH // 2, OW // 2
-    V = torch.empty((16, N, C, TH, TW), dtype=_F32, device=x.device)
-    _lib.call("objgan_wino_input_f23", _p(x), _p(V), N, C, H, W, TH, TW, int(pad), int(refl), _stream())
-    Mt = torch.empty((16, N, M, TH, TW), dtype=_F32, device=x.device)
-    for i in range(16):
-        _conv1x1_into(V[i], banks[i], Mt[i])
-    y = torch.empty((N, M, OH, OW), dtype=_F32, device=x.device)
-    _lib.call("objgan_wino_output_f23", _p(Mt), _p(y), N, M, TH, TW, _stream())
-    return y
-
-
-def _conv1x1_into(x, w, y):
-    N, C, H, W = x.shape
-    _igemm(x, w, None, y, N, C, H, W, 0, 0, w.shape[0], C, 1, 0, [0], [0], [0], H, W, 1, H, W, 1, 1, 0, 0, 0)
-
-
-def _wino_ok(x, w, bias, stride, pad, pad_mode, upsample, act):
-    return (_WINOGRAD and not upsample and stride == 1 and pad == 1 and bias is None and act in (None, "none")
-            and w.shape[2] == 3 and w.shape[3] == 3 and w.shape[0] > 32 and x.shape[1] > 32
-            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.shape[2] >= 4 and x.shape[3] >= 4
-            and _MATH["mode"] == 0
-            and 16.0 * x.shape[0] * max(x.shape[1], w.shape[0]) * (x.shape[2] + 2) * (x.shape[3] + 2) < 4.0e9)
-
-
-class _WinoConv3x3Fn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, w, refl):
-        _chk(x, w)
-        x = _c(x)
-        w = _c(w)
-        if w.shape[1] != x.shape[1]:
-            raise _lib.ObjganHipError("conv2d: bad weight shape %s for input %s" % (tuple(w.shape), tuple(x.shape)))
-        banks, _ = _wino_bank(w, False)
-        y = _wino_conv(x, banks, w.shape[0], 1, refl, x.shape[2], x.shape[3])
-        ctx.refl = refl
-        ctx.save_for_backward(x, w)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, w = ctx.saved_tensors
-        dy = _c(dy)
-        _chk(dy)
-        N, C, H, W = x.shape
-        refl = ctx.refl
-        dx = dw_ = None
-        if ctx.needs_input_grad[0]:
-            banks, _ = _wino_bank(w, True)
-            if refl:        # gradient w.r.t. the reflect-padded tensor (full correlation), then fold
-                dxp = _wino_conv(dy, banks, C, 2, 0, H + 2, W + 2)
-                dx = torch.empty((N, C, H, W), dtype=_F32, device=x.device)
-                _lib.call("objgan_reflect_fold", _p(dxp), _p(dx), N * C, H, W, _stream())
-            else:
-                dx = _wino_conv(dy, banks, C, 1, 0, H, W)
-        if ctx.needs_input_grad[1]:
-            slot = _grad_slot(w)
-            dw_ = _conv_wgrad(x, dy, w.shape[0], 3, 1, 1, 1 if refl else 0, False, into=slot)
-            if slot is not None:
-                dw_ = None
-        return dx, dw_, None
-
-
 def conv2d(x, w, bias=None, stride=1, pad=0, pad_mode="zeros", upsample=False, act=None):
-    if _wino_ok(x, w, bias, stride, pad, pad_mode, upsample, act):
-        return _WinoConv3x3Fn.apply(x, w, 1 if pad_mode == "reflect" else 0)
     if _up_phased_ok(x, w, bias, stride, pad, pad_mode, upsample, act):
         return _UpConv3x3Fn.apply(x, w)
     return _Conv2dFn.apply(x, w, bias, stride, pad, pad_mode, upsample, act)
@@ -925,6 +818,17 @@ def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, n=None):
     n = p.numel() if n is None else int(n)
     _lib.call("objgan_adam_step", _p(p), _p(g), _p(m), _p(v), n, float(lr), float(beta1),
               float(beta2), float(eps), int(step), float(grad_scale), _stream())
+
+
+def adam_step_gated_(p, g, m, v, lr, beta1, beta2, eps, state, flag, coef, grad_scale=1.0, n=None):
+    """Adam taken only if the device scalar `flag` is positive; `state` (3 float64 on the device:
+    steps, beta1^steps, beta2^steps) is advanced by the kernel, `coef` is 3 floats of scratch."""
+    _chk(p, g, m, v, flag, coef)
+    if not state.is_cuda or state.dtype != torch.float64 or state.numel() < 3:
+        raise _lib.ObjganHipError("adam_step_gated_: state must be 3 float64 values on the GPU")
+    n = p.numel() if n is None else int(n)
+    _lib.call("objgan_adam_step_gated", _p(p), _p(g), _p(m), _p(v), n, float(lr), float(beta1),
+              float(beta2), float(eps), _p(state), _p(flag), _p(coef), float(grad_scale), _stream())
 
 
 def ema_update_(avg, p, decay):

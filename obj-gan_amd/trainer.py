@@ -32,6 +32,7 @@ from miscc.config import cfg
 from miscc.utils import (mkdir_p, weights_init, form_clabels_feat, _host, compute_inception_score,
                          negative_log_posterior_probability)
 from miscc.losses import patD_loss, shpD_loss, objD_loss, G_loss, KL_loss
+import model as M
 from model import (G_NET, PAT_D_NET64, PAT_D_NET128, PAT_D_NET256, SHP_D_NET64, SHP_D_NET128,
                    SHP_D_NET256, OBJ_SS_D_NET, OBJ_LS_D_NET)
 from objgan_hip import ops
@@ -57,6 +58,10 @@ class ParamArena(object):
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.step_count = 0
+        # device-side step state of the gated update (ArenaAdam.step(gated=True)): steps, beta1^steps,
+        # beta2^steps as float64 + 3 floats of kernel scratch
+        self.gate_state = None
+        self.gate_coef = None
         self._views = []
         self.epoch = [0]      # bumped by every optimizer step: ops' packed-filter cache keys on it
         off = 0
@@ -102,17 +107,40 @@ class ArenaAdam(object):
     def zero_grad(self):
         self.arena.zero_grad()
 
-    def step(self, grad_scale=1.0):
+    def step(self, grad_scale=1.0, gated=False):
+        """gated=True: the update is taken only if the flag slot behind the gradient arena
+        (arena.grad[-1], summed over ranks by the gradient all-reduce) is positive -- decided on the
+        device, with the step counter on the device too: no host sync (reference trainer.py:429,440
+        tests `float(err) > 0` on the host)."""
         a = self.arena
         a.sync_grads()
-        a.step_count += 1
         a.epoch[0] += 1
-        ops.adam_step_(a.flat, a.grad, a.exp_avg, a.exp_avg_sq, self.param_groups[0]["lr"],
+        lr = self.param_groups[0]["lr"]
+        if gated:
+            if a.gate_state is None:
+                a.gate_state = torch.tensor([float(a.step_count), self.betas[0] ** a.step_count,
+                                             self.betas[1] ** a.step_count], dtype=torch.float64,
+                                            device=a.flat.device)
+                a.gate_coef = torch.zeros(3, dtype=torch.float32, device=a.flat.device)
+            ops.adam_step_gated_(a.flat, a.grad, a.exp_avg, a.exp_avg_sq, lr, self.betas[0], self.betas[1],
+                                 self.eps, a.gate_state, a.grad[a.n:], a.gate_coef, grad_scale=grad_scale,
+                                 n=a.n)
+            return
+        if a.gate_state is not None:        # leave gated mode: one read of the device counter
+            a.step_count = int(a.gate_state[0].item())
+            a.gate_state = None
+        a.step_count += 1
+        ops.adam_step_(a.flat, a.grad, a.exp_avg, a.exp_avg_sq, lr,
                        self.betas[0], self.betas[1], self.eps, a.step_count, grad_scale=grad_scale,
                        n=a.n)
 
+    @property
+    def steps_taken(self):
+        a = self.arena
+        return int(a.gate_state[0].item()) if a.gate_state is not None else a.step_count
+
     def state_dict(self):
-        return {"step": self.arena.step_count, "exp_avg": self.arena.exp_avg,
+        return {"step": self.steps_taken, "exp_avg": self.arena.exp_avg,
                 "exp_avg_sq": self.arena.exp_avg_sq}
 
 
@@ -167,7 +195,8 @@ class condGANTrainer(object):
             setattr(self, name, getattr(dataset, name, None))
         self.rank = dist.get_rank() if _dist_on() else 0
         self.world = dist.get_world_size() if _dist_on() else 1
-        self.is_stream = torch.cuda.Stream(device=self.device) if self.inception_model is not None else None
+        self.is_stream = torch.cuda.Stream(device=self.device) \
+            if self.inception_model is not None and self.device.type == "cuda" else None
         # The object discriminators consume the second stage's bottom-up codes: a one-stage tree cannot
         # have them (the reference raises IndexError there, SURVEY.md trap 8); `use_obj = False` also
         # gives BASELINE.json config 3 "without the two object discriminators".
@@ -179,6 +208,7 @@ class condGANTrainer(object):
         (reference trainer.py:75-195).  The frozen encoders come from the dataset object (they
         are outside the kernel scope of this round); checkpoints named like the reference's
         (netG_epoch_%d.pth, netPatD%d.pth, ...) are loaded when cfg.TRAIN.NET_G is set."""
+        self._build_encoders()
         nc = self.num_classes
         netG = G_NET(nc)
         netsPatD, netsShpD = [], []
@@ -212,6 +242,51 @@ class condGANTrainer(object):
                     dist.broadcast(t.data, src=0)
         return [self.text_encoder, self.image_encoder, netG, netsPatD, netsShpD, netObjSSD,
                 netObjLSD, epoch]
+
+    def _build_encoders(self):
+        """The frozen encoders of the step (reference trainer.py:62-100): caption encoder from
+        cfg.TRAIN.NET_E, image encoder from the sibling `image_encoder*.pth`, and the Inception-v3 of the
+        per-step Inception-score monitor.  A dataset object may hand in ready-made ones (bench, tests);
+        otherwise they are built and loaded here exactly as the reference does -- the monitor's ImageNet
+        weights, which the reference downloads, are read from cfg.TRAIN.NET_INCEPTION or the torch hub
+        cache (no network here): without that file the monitor is off."""
+        import encoders
+        from model import RNN_ENCODER
+        # a prepared data set (it has a vocabulary) gets its encoders here; synthetic batches may carry
+        # precomputed caption embeddings / their own encoder objects instead
+        real = self.n_words is not None
+        need_text = real and self.text_encoder is None
+        need_img = real and self.image_encoder is None
+        if (need_text or need_img) and cfg.TRAIN.NET_E == '':
+            raise RuntimeError('Error: no pretrained text-image encoders (cfg.TRAIN.NET_E)')
+        if need_img:
+            path = cfg.TRAIN.NET_E.replace('text_encoder', 'image_encoder')
+            enc = encoders.CNN_ENCODER(cfg.TEXT.EMBEDDING_DIM)
+            enc.load_state_dict(torch.load(path, map_location="cpu"))
+            print('Load image encoder from:', path)
+            self.image_encoder = enc
+        if need_text:
+            enc = RNN_ENCODER(self.n_words, nhidden=cfg.TEXT.EMBEDDING_DIM)
+            enc.load_state_dict(torch.load(cfg.TRAIN.NET_E, map_location="cpu"))
+            print('Load text encoder from:', cfg.TRAIN.NET_E)
+            self.text_encoder = enc
+        if real and self.inception_model is None:
+            path = getattr(cfg.TRAIN, "NET_INCEPTION", '') or os.path.join(
+                os.environ.get("TORCH_HOME", os.path.expanduser("~/.cache/torch")), "hub", "checkpoints",
+                "inception_v3_google-1a9a5a14.pth")
+            if os.path.exists(path):
+                net = encoders.inception_v3()
+                net.load_state_dict(torch.load(path, map_location="cpu"))
+                self.inception_model = encoders.INCEPTION_V3(net)
+            elif self.rank == 0:
+                print('Inception-score monitor off: no ImageNet weights at', path)
+        for enc in (self.text_encoder, self.image_encoder, self.inception_model):
+            if isinstance(enc, nn.Module):
+                for p in enc.parameters():
+                    p.requires_grad_(False)
+                enc.to(self.device).eval()
+        if self.inception_model is not None and self.is_stream is None and self.device.type == "cuda":
+            self.is_stream = torch.cuda.Stream(device=self.device)
 
     def define_optimizers(self, netG, netsPatD, netsShpD, netObjSSD, netObjLSD):
         d_lr, g_lr = cfg.TRAIN.DISCRIMINATOR_LR, cfg.TRAIN.GENERATOR_LR
@@ -287,6 +362,7 @@ class condGANTrainer(object):
             words_embs, sent_emb = b["words_embs"], b["sent_emb"]
         inv_world = 1.0 / self.world
         out = {}
+        M._LIFT.clear()          # the layout-lift memo never outlives a step (every step brings new tensors)
 
         clabels_feat = form_clabels_feat(clabels_emb, rois[0], num_rois)
         # (2) generate fake images
@@ -330,12 +406,14 @@ class condGANTrainer(object):
                 out[name] = err.detach()
             pending.append((opt, self._reduce_async(opt), active))
 
-        # discriminator Adam steps (after their reductions; they overlapped the later Ds)
+        # discriminator Adam steps (after their reductions; they overlapped the later Ds).  Under data
+        # parallelism a rank cannot know on the host whether ANOTHER rank had boxes of the wanted scale:
+        # the flag slot was summed by the all-reduce and gates the update on the device (no host read).
         for opt, handle, active in pending:
             if handle is not None:
-                handle.wait()
-                active = bool(opt.arena.grad[-1].item() > 0)     # any rank active -> all ranks step
-            if active:
+                handle.wait()                        # stream-side wait, the host runs on
+                opt.step(grad_scale=inv_world, gated=True)
+            elif active:
                 opt.step(grad_scale=inv_world)
 
         # (4) generator: maximise log(D(G(z))) + DAMSM + KL, discriminators frozen
@@ -368,9 +446,15 @@ class condGANTrainer(object):
 
         # (5) Inception-score monitor on a side stream (no data dependence on the update)
         if self.inception_model is not None:
+            img = out["fake_imgs"][-1]
             self.is_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.is_stream), torch.no_grad():
-                out["is_pred"] = self.inception_model(out["fake_imgs"][-1])
+                pred = self.inception_model(img)
+            # the image was allocated on the main stream and is read on the side stream; the prediction
+            # the other way round: tell the caching allocator, and remember where to wait before reading
+            img.record_stream(self.is_stream)
+            pred.record_stream(torch.cuda.current_stream())
+            out["is_pred"] = pred
         self.gen_iterations += 1
         return out
 
@@ -420,9 +504,18 @@ class condGANTrainer(object):
         torch.save(netObjSSD.state_dict(), '%s/netObjSSD.pth' % self.model_dir)
         torch.save(netObjLSD.state_dict(), '%s/netObjLSD.pth' % self.model_dir)
 
+    def join_monitor(self):
+        """Make the current stream wait for the Inception-score monitor's side stream: call before
+        reading any `is_pred` (write_scores does)."""
+        if getattr(self, "is_stream", None) is not None:
+            torch.cuda.current_stream().wait_stream(self.is_stream)
+
     def write_scores(self, predictions, epoch):
         """Per-epoch Inception score of the per-step monitor predictions -> Score/scores_<epoch>.txt
         (reference trainer.py:495-506)."""
+        join = getattr(self, "join_monitor", None)
+        if join is not None:
+            join()
         preds = np.concatenate([p.detach().cpu().numpy() if torch.is_tensor(p) else np.asarray(p)
                                 for p in predictions], 0)
         splits = min(10, self.batch_size)
@@ -439,6 +532,9 @@ class condGANTrainer(object):
         self.setup()
         for epoch in range(self.start_epoch, self.max_epoch):
             start_t = time.time()
+            sampler = getattr(self.data_loader, "sampler", None)
+            if hasattr(sampler, "set_epoch"):       # reshuffle the per-rank shards every epoch
+                sampler.set_epoch(epoch)
             predictions = []
             for step, batch in enumerate(self.data_loader):
                 if not isinstance(batch, dict):       # the reference loader's collated 12-tuple

@@ -125,27 +125,3 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step):
     denom = v.sqrt() / (bc2 ** 0.5) + eps
     p = p - (lr / bc1) * (m / denom)
     return p, m, v
-
-
-# ---- Winograd F(2x2, 3x3) data transforms (oracle of csrc/winograd.hip) ------------------------
-_WINO_BT = torch.tensor([[1., 0., -1., 0.], [0., 1., 1., 0.], [0., -1., 1., 0.], [0., 1., 0., -1.]])
-_WINO_AT = torch.tensor([[1., 1., 1., 0.], [0., 1., -1., -1.]])
-
-
-def wino_input_ref(x, TH, TW, pad, refl):
-    """[16, N, C, TH, TW] = B^T d B of the 4x4 patches starting at (2*ty - pad, 2*tx - pad)."""
-    need_h, need_w = 2 * TH + 2, 2 * TW + 2
-    H, W = x.shape[2], x.shape[3]
-    pads = (pad, need_w - W - pad, pad, need_h - H - pad)
-    xp = F.pad(x, pads, mode="reflect") if refl else F.pad(x, pads)
-    d = xp.unfold(2, 4, 2).unfold(3, 4, 2)                      # N, C, TH, TW, 4, 4
-    v = torch.einsum("pi,nctsij,qj->pqncts", _WINO_BT, d, _WINO_BT)
-    return v.reshape(16, *v.shape[2:]).contiguous()
-
-
-def wino_output_ref(Mt):
-    """[16, N, M, TH, TW] -> [N, M, 2*TH, 2*TW] = A^T m A per tile."""
-    m = Mt.reshape(4, 4, *Mt.shape[1:])
-    o = torch.einsum("ai,ijnmts,bj->nmtasb", _WINO_AT, m, _WINO_AT)
-    N, M, TH, _, TW, _ = o.shape
-    return o.reshape(N, M, 2 * TH, 2 * TW).contiguous()

@@ -100,6 +100,19 @@ def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, n=None):
     v[:n].copy_(vn)
 
 
+def adam_step_gated_(p, g, m, v, lr, beta1, beta2, eps, state, flag, coef, grad_scale=1.0, n=None):
+    """CPU definition of objgan_adam_step_gated: the update (and the step counter in `state`) only
+    moves when the flag is positive."""
+    if float(flag.reshape(-1)[0]) <= 0:
+        coef[0] = 0.0
+        return
+    state[0] += 1.0
+    state[1] *= beta1
+    state[2] *= beta2
+    coef[0] = 1.0
+    adam_step_(p, g, m, v, lr, beta1, beta2, eps, int(state[0].item()), grad_scale=grad_scale, n=n)
+
+
 def ema_update_(avg, p, decay):
     avg.mul_(decay).add_(p, alpha=1.0 - decay)
 
@@ -114,7 +127,7 @@ def get_conv_math():
 
 API = ("conv2d", "conv2d_frozen", "linear", "norm_act", "norm_act_eval", "attn_general", "attn_bu", "masked_max",
        "softmax_strided", "roi_align", "avgpool2s1", "bilinear_resize", "lstm_bidir_forward", "adam_step_",
-       "ema_update_")
+       "adam_step_gated_", "ema_update_")
 
 
 def install(monkeypatch):

@@ -9,8 +9,7 @@ need a CPU evaluation of the full-size operator:
     path; attention: the maps are distributions over the words; Adam: one fused step over a 77 M-element
     arena against the closed form on a strided sample.
 
-NOT YET RUN ON A GPU (written after this round's GPU budget was spent): opt-in with
-OG_TEST_EXPERIMENTAL=1 until one verified run, then the guard goes away.
+First hardware run: profiles/r02_fullsize_tests_first_run.log (round 2).
 """
 import os
 
@@ -20,9 +19,7 @@ import torch
 
 from conftest import rel_l2
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("OG_TEST_EXPERIMENTAL") != "1",
-                                 reason="full-size property tests: first GPU run pending (OG_TEST_EXPERIMENTAL=1)")]
+pytestmark = [pytest.mark.gpu]
 
 B = 16
 

@@ -115,77 +115,6 @@ def test_inception_score_helpers_match_reference(tmp_path):
     assert np.allclose(out[:2], utils.compute_inception_score(p, 4))
 
 
-# ---- Winograd F(2x2, 3x3) composition (experimental path), kernels replaced by torch definitions ----
-from oracle.torch_ref import wino_input_ref, wino_output_ref      # noqa: E402
-
-
-def _wino_cpu(ops, monkeypatch):
-    monkeypatch.setattr(ops, "_WINOGRAD", True)
-    monkeypatch.setattr(ops, "_chk", lambda *a: None)
-    monkeypatch.setattr(ops, "_p", lambda t: t)
-    monkeypatch.setattr(ops, "_stream", lambda: None)
-
-    def call(name, *a):
-        if name == "objgan_wino_input_f23":
-            x, V, N, C, H, W, TH, TW, pad, refl, _ = a
-            V.copy_(wino_input_ref(x, TH, TW, pad, refl))
-        elif name == "objgan_wino_output_f23":
-            Mt, y, N, M, TH, TW, _ = a
-            y.copy_(wino_output_ref(Mt))
-        elif name == "objgan_reflect_fold":
-            dxp, dx, planes, h, w, _ = a
-            with torch.enable_grad():
-                z = torch.zeros_like(dx, requires_grad=True)
-                (g,) = torch.autograd.grad(F.pad(z, (1, 1, 1, 1), mode="reflect"), z, dxp)
-            dx.copy_(g)
-        else:
-            raise AssertionError(name)
-    monkeypatch.setattr(ops._lib, "call", call)
-    monkeypatch.setattr(ops, "_conv1x1_into", lambda x, w, y: y.copy_(F.conv2d(x, w)))
-    monkeypatch.setattr(ops, "_conv_wgrad",
-                        lambda x, g, Cout, k, stride, pad, refl, upsample, into=None:
-                        torch.nn.grad.conv2d_weight(F.pad(x, (1, 1, 1, 1), mode="reflect") if refl else x,
-                                                    (Cout, x.shape[1], k, k), g, padding=0 if refl else pad))
-
-
-def test_winograd_conv_composition_matches_direct_conv(monkeypatch):
-    from objgan_hip import ops
-    _wino_cpu(ops, monkeypatch)
-    g = torch.Generator().manual_seed(3)
-    for refl in (0, 1):
-        for (N, C, H, W, M) in [(2, 40, 8, 12, 48), (1, 33, 4, 4, 70)]:
-            x = torch.randn(N, C, H, W, generator=g)
-            w = torch.randn(M, C, 3, 3, generator=g) / (C * 9) ** 0.5
-            xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
-            xin = F.pad(xr, (1, 1, 1, 1), mode="reflect") if refl else xr
-            yr = F.conv2d(xin, wr, padding=0 if refl else 1)
-            gy = torch.randn(yr.shape, generator=g)
-            yr.backward(gy)
-            xd, wd = x.clone().requires_grad_(), w.clone().requires_grad_()
-            mode = "reflect" if refl else "zeros"
-            assert ops._wino_ok(xd, wd, None, 1, 1, mode, False, None)
-            yd = ops.conv2d(xd, wd, None, 1, 1, mode, False, None)
-            yd.backward(gy)
-            rel = lambda a, b: float((a - b).norm() / b.norm())   # noqa: E731
-            assert rel(yd.detach(), yr.detach()) < 3e-6, (refl, rel(yd.detach(), yr.detach()))
-            assert rel(xd.grad, xr.grad) < 3e-6 and rel(wd.grad, wr.grad) < 3e-6
-
-
-def test_winograd_is_opt_in_and_restricted():
-    from objgan_hip import ops
-    x, w = torch.zeros(2, 40, 8, 8), torch.zeros(64, 40, 3, 3)
-    assert not ops._wino_ok(x, w, None, 1, 1, "zeros", False, None)          # default: off
-    ops._WINOGRAD = True
-    try:
-        assert ops._wino_ok(x, w, None, 1, 1, "reflect", False, None)
-        assert not ops._wino_ok(x, w, None, 1, 1, "zeros", True, None)       # upBlock has its own form
-        assert not ops._wino_ok(x, w, None, 2, 1, "zeros", False, None)
-        assert not ops._wino_ok(x[:, :, :7], w, None, 1, 1, "zeros", False, None)   # odd height
-        assert not ops._wino_ok(x, w[:20], None, 1, 1, "zeros", False, None)
-    finally:
-        ops._WINOGRAD = False
-
-
 def test_shape_generator_mirror_and_form_hmaps(monkeypatch):
     """Sampling path: SHP_G_NET has the reference's state-dict layout, and
     form_hmaps reproduces the reference output (tests/golden/shp_g_ref.pt, generated by the unmodified

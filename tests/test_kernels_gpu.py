@@ -622,49 +622,3 @@ def test_upblock_conv_takes_the_phased_form_and_follows_weight_updates(dev):
     y2 = ops.conv2d(xd, wd, None, 1, 1, "zeros", True, None)
     torch.cuda.synchronize()
     assert rel_l2(y2, tr.conv2d(x, -0.5 * w, None, 1, 1, "zeros", True, None)) < TOL
-
-
-@pytest.mark.skipif(os.environ.get("OG_TEST_EXPERIMENTAL") != "1",
-                    reason="experimental variants are opt-in: OG_TEST_EXPERIMENTAL=1")
-@pytest.mark.parametrize("env,tests,expr", [
-    ("OG_KORDER=1", "test_kernels_gpu.py", "conv2d or upblock or inception or never_consumes"),
-    ("OBJGAN_WGRAD_INPLACE=1", "test_modules_gpu.py", "training_step or discriminator or generator"),
-    ("OG_WGRAD_B128=1 OG_WGRAD3_MAXTM=7", "test_kernels_gpu.py", "conv2d or upblock"),
-    ("OBJGAN_WINOGRAD=1", "test_kernels_gpu.py", "conv2d_forward_backward or packed_filter_cache"),
-    ("OBJGAN_WINOGRAD=1", "test_modules_gpu.py", "training_step or generator"),
-])
-def test_experimental_variants_in_a_subprocess(dev, env, tests, expr):
-    """The env-selected variants (chunk-major K order, 16-byte weight-gradient gathers, weight
-    gradients accumulated straight into the optimizer arena, Winograd) are read once per process, so they are
-    exercised by re-running the affected tests in a child process."""
-    import subprocess
-    import sys
-    from conftest import ROOT
-    extra = dict(kv.split("=") for kv in env.split())
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", tests),
-                          "-m", "gpu", "-x", "-q", "-k", expr],
-                         env=dict(os.environ, OG_TEST_EXPERIMENTAL="0", **extra),
-                         capture_output=True, text=True, timeout=1800)
-    assert out.returncode == 0, out.stdout[-3000:]
-
-
-@pytest.mark.skipif(os.environ.get("OG_TEST_EXPERIMENTAL") != "1",
-                    reason="experimental variants are opt-in: OG_TEST_EXPERIMENTAL=1")
-def test_winograd_transforms_match_oracle(dev):
-    """csrc/winograd.hip against oracle/torch_ref.py: B^T d B with zero / reflection padding (pad 1
-    and the pad-2 form of the data gradient) and A^T m A; only additions, so the bar is 1e-6."""
-    from objgan_hip import _lib, ops
-    from oracle.torch_ref import wino_input_ref, wino_output_ref
-    g = torch.Generator().manual_seed(5)
-    for (N, C, H, W, pad, refl) in [(2, 7, 8, 12, 1, 0), (2, 7, 8, 12, 1, 1), (1, 5, 6, 4, 2, 0), (3, 40, 32, 32, 1, 1)]:
-        TH, TW = (H + 2 * pad - 2) // 2, (W + 2 * pad - 2) // 2
-        x = torch.randn(N, C, H, W, generator=g)
-        xd = x.to(dev)
-        V = torch.empty((16, N, C, TH, TW), device=dev)
-        _lib.call("objgan_wino_input_f23", ops._p(xd), ops._p(V), N, C, H, W, TH, TW, pad, refl, ops._stream())
-        assert rel_l2(V, wino_input_ref(x, TH, TW, pad, refl)) < 1e-6
-        Mt = torch.randn(16, N, C, TH, TW, generator=g)
-        y = torch.empty((N, C, 2 * TH, 2 * TW), device=dev)
-        _lib.call("objgan_wino_output_f23", ops._p(Mt.to(dev)), ops._p(y), N, C, TH, TW, ops._stream())
-        torch.cuda.synchronize()
-        assert rel_l2(y, wino_output_ref(Mt)) < 1e-6
