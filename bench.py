@@ -9,17 +9,19 @@ forward at 256x256 (fed by the frozen caption encoder and GloVe lookup), the thr
 shape discriminators, the two ROIAlign object discriminators, generator loss with DAMSM + KL, nine
 Adam updates and the generator EMA (and the per-step Inception-score monitor on a side stream, as in
 the reference).  Per-GPU batch 16; under
-`--gpus N` (launched by torch.distributed.run, one rank per GPU, RCCL) every rank steps its own
-batch and gradients are all-reduced: weak scaling, value = N * 16 * steps / time.
+`--gpus N` (launched by torch.distributed.run, one rank per GPU, RCCL; without a launcher in the
+environment bench.py starts the N ranks itself) every rank steps its own batches and gradients are
+all-reduced: weak scaling, value = N * 16 * steps / time.  Every step gets a new minibatch.
 
 One JSON line is printed by rank 0: the contract fields plus
   roofline      the dominant kernel instance (the MFMA implicit-GEMM conv with the largest share
                 of the step): algorithmic flops of its launches / their hipEvent-measured duration
-                (events recorded by the library on the launch stream), against the fp32 MFMA peak;
+                (events recorded by the library on the launch stream, in a second untimed pass so
+                that the headline carries no event overhead), against the fp32 MFMA peak;
                 traffic = HBM bytes per launch from the rocprofv3 --pmc passes kept in profiles/
-  cpu_baseline  the CPU oracle (oracle/torch_model.py, a port of the reference path) timed on this
-                host's cores on a bounded sample (one step at batch 8, <= 16 threads,
-                child process with a hard time limit)
+  cpu_baseline  the CPU oracle (oracle/torch_model.py, a port of the reference path) timed on ALL of this
+                host's cores at the BASELINE batch (1 warm-up + 1 timed step at batch 16; child process
+                with a hard time limit, batch-8 fallback)
 """
 import argparse
 import ctypes
@@ -42,7 +44,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0                  # dense bf16 MFMA peak (v_mfma_f
 CAT_NAMES = (["conv_igemm3_kernel<%d, false>" % tm for tm in range(1, 8)] +
              ["conv_wgrad2_kernel<%d>" % tm for tm in range(1, 8)] +
              ["conv_thin_kernel", "conv_thin3x3_kernel", "conv_igemm_kernel", "conv_wgrad_kernel",
-              "conv_igemm3_kernel<1, true>", "conv_wgrad3_kernel<1>", "conv_wgrad3_kernel<2>"])
+              "conv_igemm3_kernel<1, true>"] + ["conv_wgrad3_kernel<%d>" % tm for tm in range(1, 8)])
 PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
@@ -76,14 +78,26 @@ def build_trainer(device, batch_size, seed, with_is_monitor=True):
     return tr
 
 
-def _cpu_baseline_worker(sample_batch, threads, seed=1234):
-    """(child process) the oracle -- CPU port of the reference step -- on `threads` host threads."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_baseline_worker(sample_batch, threads, timed_steps, seed=1234):
+    """(child process) the oracle -- CPU port of the reference step (reference trainer.py:388-462 order) --
+    on `threads` host threads: one warm-up step, then `timed_steps` timed ones."""
     import model as M
     import encoders
     import synth_batch
     from miscc.config import cfg
     from miscc.utils import weights_init
     from oracle import torch_model as tm
+    from oracle import torch_encoders
     cfg.TREE.BRANCH_NUM = 3
     torch.set_num_threads(threads)
     torch.manual_seed(seed)
@@ -103,53 +117,114 @@ def _cpu_baseline_worker(sample_batch, threads, seed=1234):
     opts = {"G": adam(sds["G"]), "pat": [adam(s) for s in sds["pat"]], "shp": [adam(s) for s in sds["shp"]],
             "objss": adam(sds["objss"]), "objls": adam(sds["objls"])}
     ema = [p.detach().clone() for p in tm.params_of(sds["G"])]
-    enc = encoders.CNN_ENCODER(256, encoders.seeded_init_(encoders.inception_v3(), 1)).eval()
+    enc = torch_encoders.CpuImageEncoder(encoders.CNN_ENCODER(256, encoders.seeded_init_(encoders.inception_v3(), 1)).eval())
     batch = synth_batch.make_batch(sample_batch, seed=seed)
     t0 = time.time()
     tm.train_step(sds, opts, ema, batch, image_encoder=enc)
-    dt = time.time() - t0
+    warm = time.time() - t0
+    t0 = time.time()
+    for _ in range(timed_steps):
+        tm.train_step(sds, opts, ema, batch, image_encoder=enc)
+    dt = (time.time() - t0) / max(1, timed_steps)
     print("CPU_BASELINE " + json.dumps(
         {"value": round(sample_batch / dt, 4), "unit": "images/sec", "cores": threads, "kind": "port",
-         "sample": "1 full G+D step at batch %d (same networks, 256x256), %.1f s on %d threads of %d host cores"
-                   % (sample_batch, dt, threads, os.cpu_count() or 1)}), flush=True)
+         "cpu": _cpu_model(), "host_cores": os.cpu_count() or 1,
+         "sample": "full G+D step at batch %d (same networks, 256x256, fp32): 1 warm-up (%.1f s) + %d timed "
+                   "step(s) of %.1f s each on %d threads" % (sample_batch, warm, timed_steps, dt, threads)}),
+        flush=True)
 
 
-def cpu_baseline(sample_batch=8, max_threads=16, timeout_s=240):
-    """The oracle timed on the host cores, on a bounded sample (one step at a small batch), in a
-    child process with a hard time limit so that the default bench run always finishes."""
+def cpu_baseline(sample_batch=16, timed_steps=1, timeout_s=420):
+    """The oracle timed on ALL host cores at the BASELINE batch (1 warm-up + timed steps),
+    in a child process with a hard time limit so that the default bench run always finishes; if the
+    full-batch run does not fit the limit a batch-8 sample is reported instead."""
     import subprocess
-    threads = max(1, min(max_threads, os.cpu_count() or 1))
+    threads = max(1, os.cpu_count() or 1)
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads),
                HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(sample_batch), str(threads)]
-    try:
-        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
-                             timeout=timeout_s).stdout.decode(errors="replace")
-        for line in out.splitlines():
-            if line.startswith("CPU_BASELINE "):
-                return json.loads(line[len("CPU_BASELINE "):])
-        note = "worker produced no result"
-    except subprocess.TimeoutExpired:
-        note = "did not finish one batch-%d step within %d s on %d threads" % (sample_batch, timeout_s, threads)
-    return {"value": None, "unit": "images/sec", "cores": threads, "kind": "port", "sample": note}
+    note = ""
+    for batch, limit in ((sample_batch, timeout_s), (8, timeout_s // 2)):
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(batch), str(threads),
+               str(timed_steps)]
+        try:
+            out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                 timeout=limit).stdout.decode(errors="replace")
+            for line in out.splitlines():
+                if line.startswith("CPU_BASELINE "):
+                    return json.loads(line[len("CPU_BASELINE "):])
+            note += "batch %d: worker produced no result; " % batch
+        except subprocess.TimeoutExpired:
+            note += "batch %d: not finished within %d s on %d threads; " % (batch, limit, threads)
+    return {"value": None, "unit": "images/sec", "cores": threads, "kind": "port", "cpu": _cpu_model(),
+            "sample": note}
+
+
+def _respawn_under_torchrun(n):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start N ranks, one per GPU, over RCCL."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def _write_shape_table(lib, path, steps):
+    """Per-layer table of the profiling pass: (kind, tile, rows, K channels, taps, pixel grid) ->
+    launches/step, ms/step, algorithmic TFLOP/s."""
+    cap = 1 << 16
+    ms = (ctypes.c_float * cap)()
+    fl = (ctypes.c_double * cap)()
+    meta = (ctypes.c_int * (10 * cap))()
+    n = ctypes.c_int(0)
+    lib.objgan_prof_dump(ms, fl, meta, cap, ctypes.byref(n))
+    agg = {}
+    for i in range(n.value):
+        key = tuple(meta[10 * i + j] for j in range(10))
+        e = agg.setdefault(key, [0, 0.0, 0.0])
+        e[0] += 1
+        e[1] += ms[i]
+        e[2] += fl[i]
+    rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+    kinds = {0: "gemm", 1: "wgrad", 2: "thin"}
+    with open(path, "w") as f:
+        f.write("# per-shape conv launches of the profiling pass (%d steps); stride < 0: strided output phases; "
+                "wgrad stride x10: upsampled source, negative: reflect pad\n" % steps)
+        f.write("%-6s %3s %5s %5s %3s %3s %5s %5s %4s %4s %8s %9s %8s\n" % (
+            "kind", "TM", "rows", "C", "T", "N", "PH", "PW", "str", "spl", "n/step", "ms/step", "TFLOP/s"))
+        for key, (cnt, tms, tfl) in rows:
+            f.write("%-6s %3d %5d %5d %3d %3d %5d %5d %4d %4d %8.1f %9.3f %8.1f\n" % (
+                (kinds.get(key[0], "?"),) + key[1:] + (cnt / steps, tms / steps, tfl / (tms * 1e-3) / 1e12 if tms > 0 else 0)))
 
 
 def main():
-    if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-worker":
-        return _cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]))
+    if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-baseline-worker":
+        return _cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 16; 32 with --math bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-is-monitor", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--force-ddp", action="store_true",
+                    help="initialise the RCCL process group even at world size 1 (exercises the data-parallel "
+                         "code path -- arena all-reduces, gated optimizer steps -- on a single-GPU box)")
+    ap.add_argument("--shape-table", default=None, help="write the per-layer conv table of the profiling pass here")
     ap.add_argument("--math", choices=("fp32", "bf16"), default="fp32",
                     help="fp32: exact fp32 MFMA (headline, parity path); bf16: mixed precision of BASELINE "
                          "config 5 (bf16 matrix-core inputs, fp32 accumulation / storage / norms / optimizer)")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 16
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_respawn_under_torchrun(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -157,39 +232,62 @@ def main():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_ddp
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
 
     import synth_batch
     from objgan_hip import _lib, ops
     ops.set_conv_math(args.math)
     tr = build_trainer(device, args.batch, seed=1234, with_is_monitor=not args.no_is_monitor)
-    batch = synth_batch.make_batch(args.batch, seed=1234 + rank, device=device)   # per-rank data shard
+    # a new minibatch every step, like training: four distinct per-rank batches in rotation (the trainer
+    # drops its layout-lift memo at the start of every step, so nothing is carried from step to step)
+    nb = max(1, min(4, args.steps + args.warmup))
+    batches = [synth_batch.make_batch(args.batch, seed=1234 + rank + 1000 * i, device=device) for i in range(nb)]
+    it = [0]
+
+    def step():
+        out = tr.train_step(batches[it[0] % nb])
+        it[0] += 1
+        return out
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        tr.train_step(batch)
+        step()
     lib = _lib.load()
-    timing = (rank == 0) and not args.no_kernel_timing
     barrier()
-    if timing:
-        lib.objgan_prof_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        tr.train_step(batch)
+        step()
     barrier()
     dt = time.perf_counter() - t0
-    if timing:
-        lib.objgan_prof_enable(0)
     t = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+
+    # second, UNTIMED pass with every conv launch bracketed by hipEvents on its stream (the headline
+    # above carries no event overhead): per-kernel durations for the roofline leg
+    timing = (rank == 0) and not args.no_kernel_timing
+    prof_steps = max(1, min(args.steps, 10))
+    if timing:
+        lib.objgan_prof_enable(1)
+        t1 = time.perf_counter()
+        for _ in range(prof_steps):
+            step()
+        torch.cuda.synchronize()
+        prof_dt = (time.perf_counter() - t1) / prof_steps
+        lib.objgan_prof_enable(0)
+        if args.shape_table:
+            _write_shape_table(lib, args.shape_table, prof_steps)
+    if use_dist:
+        dist.barrier()
 
     if rank == 0:
         n_img = args.batch * world * args.steps
@@ -204,7 +302,8 @@ def main():
                                    "ObjSSD+ObjLSD(ROIAlign)+DAMSM+KL+Adam x9+EMA"
                                    + ("" if args.no_is_monitor else "+IS-monitor"),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                       "parallelism": "dp%d" % world},
+                       "parallelism": "dp%d" % world + (" (RCCL path forced)" if args.force_ddp and world == 1 else ""),
+                       "fresh_batch_every_step": True},
         }
         if timing:
             ms = (ctypes.c_double * 32)()
@@ -232,15 +331,24 @@ def main():
                                    "frac": round(ach / peak, 4), "traffic": traffic if args.math == "fp32" else None,
                                    "algorithmic_gflop_per_launch": round(tfl / n / 1e9, 2),
                                    "launches": int(n), "avg_launch_ms": round(tms / n, 4),
-                                   "share_of_step": round(tms / (1000.0 * dt), 4)}
+                                   "share_of_step": round(tms / prof_steps / (1000.0 * prof_dt), 4),
+                                   "measured_in": "second pass of %d steps with hipEvents around every conv launch "
+                                                  "(%.1f ms/step; the timed pass above runs without them)"
+                                                  % (prof_steps, 1000.0 * prof_dt)}
                 res["kernel_breakdown"] = [
-                    {"kernel": c[0], "ms_per_step": round(c[1] / args.steps, 3),
-                     "tflops": round(c[2] / (c[1] * 1e-3) / 1e12, 2), "launches_per_step": c[3] // args.steps}
-                    for c in cats[:8]]
+                    {"kernel": c[0], "ms_per_step": round(c[1] / prof_steps, 3),
+                     "tflops": round(c[2] / (c[1] * 1e-3) / 1e12, 2),
+                     "launches_per_step": round(c[3] / prof_steps, 1)}
+                    for c in cats[:10]]
+                conv_ms = sum(c[1] for c in cats) / prof_steps
+                conv_fl = sum(c[2] for c in cats) / prof_steps
+                res["conv_total"] = {"ms_per_step": round(conv_ms, 2), "tflop_per_step": round(conv_fl / 1e12, 3),
+                                     "tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
+                                     "frac_of_peak": round(conv_fl / (conv_ms * 1e-3) / 1e12 / peak, 4)}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

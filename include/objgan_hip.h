@@ -146,6 +146,14 @@ int objgan_bilinear_backward(const float* dy, float* dx, long planes, int ih, in
                              void* stream);
 int objgan_sum2x2(const float* dy, float* dx, long planes, int h, int w, void* stream);
 int objgan_reflect_fold(const float* dxp, float* dx, long planes, int h, int w, void* stream);
+/* Pooling layers of the frozen Inception-v3 encoder (reference image_generation/model.py:203-287:
+ * F.max_pool2d(k3, s2), F.avg_pool2d(k3, s1, p1), F.avg_pool2d(k8)); planes = N*C NCHW planes.
+ * mode 0 = max (no padding; idx receives the plane-local arg-max of every output for the backward pass,
+ * first maximum in row-major order like torch), 1 = average with divisor k*k (count_include_pad). */
+int objgan_pool2d_forward(const float* x, float* y, int* idx, long planes, int H, int W, int OH, int OW,
+                          int k, int s, int p, int mode, void* stream);
+int objgan_pool2d_backward(const float* dy, const int* idx, float* dx, long planes, int H, int W, int OH,
+                           int OW, int k, int s, int p, int mode, void* stream);
 /* torch.optim.Adam update over flat arenas; the gradient is pre-multiplied by grad_scale
  * (1/world_size under data parallelism: the RCCL all-reduce is a plain sum).  Hyper-parameters are
  * doubles like torch's python floats: 1 - beta and lr / (1 - beta1^t) are evaluated in double. */
@@ -165,6 +173,10 @@ int objgan_ema_update(float* avg, const float* p, long n, float decay, float one
 /* ---- measurement aid (bench.py roofline leg): hipEvent-bracketed conv launches ------------------ */
 int objgan_prof_enable(int on);
 int objgan_prof_collect(double* ms, double* flops, long* count);   /* arrays of 32 categories */
+/* per-launch records of the current window (call before objgan_prof_collect, which resets it):
+ * meta[10*i..] = {kind 0 GEMM / 1 weight gradient / 2 thin, tile height, rows, K channels, taps, images,
+ * pixel-grid rows, pixel-grid columns, stride (negative: strided output phases), K splits} */
+int objgan_prof_dump(float* ms, double* flops, int* meta, int max_records, int* n_out);
 
 #ifdef __cplusplus
 }

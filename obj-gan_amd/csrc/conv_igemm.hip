@@ -1205,9 +1205,9 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
 // Weight gradient on the v3 scheme: the gathered-x fragment goes straight to registers (lane =
 // (column l & 31 of the wave, pixel half l >> 5)), dy rows through LDS (TM > 1) or direct (TM = 1).
 // Requires OW % 8 == 0 and (OH*OW) % 16 == 0 like v2.
-// B128 (experimental, OG_WGRAD_B128=1): on the stride-1 interior fast path the eight consecutive pixels
-// of a lane are fetched as two 16-byte loads (4-byte aligned) instead of eight dwords -- the lanes of a
-// wave sit on different (channel, tap) planes, so every gather instruction touches ~20 cache lines.
+// B128: on the stride-1 interior fast path the eight consecutive pixels of a lane are fetched as two
+// 16-byte loads (4-byte aligned) instead of eight dwords -- the lanes of a wave sit on different
+// (channel, tap) planes, so every gather instruction touches ~20 cache lines.
 template <int TM, bool BF = false, bool B128 = false>
 __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, const int KS) {
     constexpr int BM = 32 * TM;
@@ -1465,8 +1465,10 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, con
 // category (kind, taps / ksize, tile config) and its ALGORITHMIC flops 2*M*K*Npix.  Off by default;
 // the only mutable global state of the library, touched by the host thread only.
 #define OG_PROF_CATS 32
-#define OG_PROF_MAX 16384
-struct ProfRec { hipEvent_t a, b; int cat; double flops; };
+#define OG_PROF_MAX 65536
+// meta: {kind (0 forward / data-gradient GEMM, 1 weight gradient, 2 thin VALU), tile height TM, rows M,
+//        K channels C, taps T, images N, pixel-grid rows, pixel-grid columns, stride, grid.y splits}
+struct ProfRec { hipEvent_t a, b; int cat; double flops; int meta[10]; };
 static int g_prof_on = 0;
 static ProfRec* g_prof = nullptr;
 static int g_prof_n = 0;
@@ -1475,9 +1477,10 @@ static int g_prof_made = 0;
 // categories = kernel instances, so that they line up with the kernel names rocprofv3 reports:
 //   0..6  conv_igemm3_kernel<1..7>     7..13 conv_wgrad2_kernel<1..7, false>
 //   14 conv_thin_kernel<*>   15 conv_thin3x3_kernel<*>   16 conv_igemm_kernel<*> (v1)   17 conv_wgrad_kernel<*> (v1)
-//   18 conv_igemm3_kernel<1, true> (LDS-free form for thin outputs)   19..20 conv_wgrad3_kernel<1..2>
+//   18 conv_igemm3_kernel<1, true> (LDS-free form for thin outputs)   19..25 conv_wgrad3_kernel<1..7>
 #define OG_CAT_IGEMM2(tm) (((tm) == 1 && a.M <= 32) ? 18 : ((tm) - 1))
-#define OG_CAT_WGRAD2(tm) (((tm) <= 2) ? 18 + (tm) : (7 + (tm) - 1))
+#define OG_CAT_WGRAD2(tm) (6 + (tm))
+#define OG_CAT_WGRAD3(tm) (18 + (tm))
 #define OG_CAT_THIN 14
 #define OG_CAT_THIN3 15
 #define OG_CAT_IGEMM1 16
@@ -1492,8 +1495,15 @@ static inline ProfRec* prof_begin(int cat, double flops, hipStream_t s) {
     }
     g_prof_n++;
     r->cat = cat; r->flops = flops;
+    for (int i = 0; i < 10; ++i) r->meta[i] = 0;
     (void)hipEventRecord(r->a, s);
     return r;
+}
+static inline void prof_meta(ProfRec* r, int kind, int tm, int M, int C, int T, int N, int ph, int pw, int stride,
+                             int splits) {
+    if (!r) return;
+    const int v[10] = {kind, tm, M, C, T, N, ph, pw, stride, splits};
+    for (int i = 0; i < 10; ++i) r->meta[i] = v[i];
 }
 static inline void prof_end(ProfRec* r, hipStream_t s) { if (r) (void)hipEventRecord(r->b, s); }
 
@@ -1639,6 +1649,7 @@ static int run_thin(IgemmArgs a, int MT, hipStream_t s) {
         dim3 g3(og_cdiv(threads, 256));
         a.m_begin = 0; a.m_end = a.M; a.ksplit_steps = 0;
         ProfRec* pr = prof_begin(OG_CAT_THIN3, 2.0 * a.M * (double)a.K * (double)Npix, s);
+        prof_meta(pr, 2, MT, a.M, a.C, a.T, a.N, a.PH, a.PW, a.stride, 1);
         switch (MT) {
             case 4: hipLaunchKernelGGL((conv_thin3x3_kernel<4, 4>), g3, dim3(256), 0, s, a); break;
             case 12: hipLaunchKernelGGL((conv_thin3x3_kernel<12, 4>), g3, dim3(256), 0, s, a); break;
@@ -1653,6 +1664,7 @@ static int run_thin(IgemmArgs a, int MT, hipStream_t s) {
     dim3 grid(og_cdiv(Npix, 256 * PX));
     a.m_begin = 0; a.m_end = a.M; a.ksplit_steps = 0;
     ProfRec* pr = prof_begin(OG_CAT_THIN, 2.0 * a.M * (double)a.K * (double)Npix, s);
+    prof_meta(pr, 2, MT, a.M, a.C, a.T, a.N, a.PH, a.PW, a.stride * (a.osh > 1 ? -1 : 1), 1);
 #define OG_THIN(MTv, Tv) hipLaunchKernelGGL((conv_thin_kernel<MTv, Tv, (MTv <= 16 ? 2 : 1)>), grid, dim3(256), 0, s, a)
     if (a.T == 9) {
         switch (MT) { case 4: OG_THIN(4, 9); break; case 12: OG_THIN(12, 9); break; case 16: OG_THIN(16, 9); break;
@@ -1677,9 +1689,9 @@ static int og_wgrad3_maxtm() {
     if (v < 0) { const char* e = getenv("OG_WGRAD3_MAXTM"); v = e ? atoi(e) : 2; }
     return v;
 }
-static int og_wgrad_b128() {
+static int og_wgrad_nob128() {      // development switch: OG_WGRAD_NOB128=1 restores the dword gathers
     static int v = -1;
-    if (v < 0) { const char* e = getenv("OG_WGRAD_B128"); v = (e && e[0] == '1') ? 1 : 0; }
+    if (v < 0) { const char* e = getenv("OG_WGRAD_NOB128"); v = (e && e[0] == '1') ? 1 : 0; }
     return v;
 }
 static int og_split_target() {
@@ -1762,6 +1774,7 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed) {
         a.m_begin = 0; a.m_end = min(a.M, full_rows * TM * 32);
         ProfRec* pr = prof_begin(OG_CAT_IGEMM2(TM),
                                  2.0 * (a.m_end - a.m_begin) * (double)a.K * (double)Npix * nph, s);
+        prof_meta(pr, 0, TM, a.m_end - a.m_begin, a.C, a.T, a.N, a.PH * nph, a.PW, a.stride * (a.osh > 1 ? -1 : 1), splits);
         rc = launch_igemm2(a, TM, dim3(full_rows * tiles_n, splits, nph), s);
         prof_end(pr, s);
         if (rc != OG_OK) return rc;
@@ -1770,6 +1783,7 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed) {
         a.m_begin = full_rows * TM * 32; a.m_end = a.M;
         ProfRec* pr = prof_begin(OG_CAT_IGEMM2(rest),
                                  2.0 * (a.m_end - a.m_begin) * (double)a.K * (double)Npix * nph, s);
+        prof_meta(pr, 0, rest, a.m_end - a.m_begin, a.C, a.T, a.N, a.PH * nph, a.PW, a.stride * (a.osh > 1 ? -1 : 1), splits);
         rc = launch_igemm2(a, rest, dim3(tiles_n, splits, nph), s);
         prof_end(pr, s);
         if (rc != OG_OK) return rc;
@@ -1977,15 +1991,24 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
             if (og_trace())
                 fprintf(stderr, "OGTRACE wgrad TM=%d Cout=%d Cin=%d k=%d N=%d OH=%d OW=%d stride=%d grid=%u,%u math=%d\n", tm, Cout, Cin,
                         ksize, N, OH, OW, stride, grid.x, grid.y, math);
-            ProfRec* pr = prof_begin(OG_CAT_WGRAD2(tm),
+            const bool wide_s1 = stride == 1 && !upsample && OW >= 64;
+            const bool b128 = wide_s1 && !og_wgrad_nob128() && !bf;
+            const bool use3 = bf ? tm <= 2 : (tm <= og_wgrad3_maxtm() || b128);
+            ProfRec* pr = prof_begin(use3 ? OG_CAT_WGRAD3(tm) : OG_CAT_WGRAD2(tm),
                                      2.0 * (a.m_end - a.m_begin) * (double)a.ncol * (double)Npix, s);
+            prof_meta(pr, 1, tm, a.m_end - a.m_begin, Cin, ksize * ksize, N, OH, OW,
+                      stride * (upsample ? 10 : 1) * (pad_mode ? -1 : 1), splits);
             // LDS-free register-fragment form for short tiles, LDS-staged form for tall ones
             // register-fragment form for short tiles, LDS-staged form for tall ones (measured equal or
             // better there: the up-sampling / reflecting gathers keep their per-element address math)
+            // Which form: the register-fragment kernel (wgrad3) with 16-byte gathers wins on wide stride-1
+            // maps without upsampling (r02 A/B: res1_128 100 -> 107 TF, shp_512 33 -> 37), the LDS-staged
+            // kernel (wgrad2) elsewhere: narrow maps spend half of their spans on the border path, the
+            // up-sampling gather keeps its per-element address math.
 #define OG_WG2(TMv) if (bf && TMv <= 2) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, true>), grid, dim3(256), 0, s, a, ksize); \
                     else if (bf) hipLaunchKernelGGL((conv_wgrad2_kernel<TMv, true>), grid, dim3(256), 0, s, a, ksize); \
-                    else if (TMv <= og_wgrad3_maxtm() && og_wgrad_b128()) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, false, true>), grid, dim3(256), 0, s, a, ksize); \
-                    else if (TMv <= og_wgrad3_maxtm()) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv>), grid, dim3(256), 0, s, a, ksize); \
+                    else if (use3 && b128) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, false, true>), grid, dim3(256), 0, s, a, ksize); \
+                    else if (use3) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv>), grid, dim3(256), 0, s, a, ksize); \
                     else hipLaunchKernelGGL((conv_wgrad2_kernel<TMv>), grid, dim3(256), 0, s, a, ksize);
             switch (tm) {
                 case 1: OG_WG2(1) break;
@@ -2030,6 +2053,7 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
         else hipLaunchKernelGGL((conv_wgrad_kernel<KS, 1, 1>), grid, dim3(256), 0, s, a);
         ProfRec* pr = prof_begin(OG_CAT_WGRAD1,
                                  2.0 * (a.m_end - a.m_begin) * (double)a.ncol * (double)Npix, s);
+        prof_meta(pr, 1, 0, a.m_end - a.m_begin, Cin, ksize * ksize, N, OH, OW, stride, splits);
         if (ksize == 1) { OG_WG(1) } else if (ksize == 3) { OG_WG(3) } else { OG_WG(4) }
         prof_end(pr, s);
 #undef OG_WG
@@ -2068,6 +2092,22 @@ int objgan_prof_collect(double* ms, double* flops, long* count) {
         ms[g_prof[i].cat] += t; flops[g_prof[i].cat] += g_prof[i].flops; count[g_prof[i].cat] += 1;
     }
     g_prof_n = 0;
+    return OG_OK;
+}
+
+// Per-launch records of the last profiling window (device must be idle): ms[i], flops[i], meta[10*i..]
+// (see ProfRec::meta), at most max_records; *n_out = number written.  Does not reset the window.
+int objgan_prof_dump(float* ms, double* flops, int* meta, int max_records, int* n_out) {
+    OG_ENTRY();
+    int n = 0;
+    for (int i = 0; i < g_prof_n && n < max_records; ++i) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b) != hipSuccess) continue;
+        ms[n] = t; flops[n] = g_prof[i].flops;
+        for (int j = 0; j < 10; ++j) meta[10 * n + j] = g_prof[i].meta[j];
+        ++n;
+    }
+    if (n_out) *n_out = n;
     return OG_OK;
 }
 

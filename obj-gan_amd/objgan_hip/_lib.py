@@ -54,6 +54,8 @@ SIGNATURES = {
     "objgan_bilinear_backward": [_ptr, _ptr, _c_long, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_sum2x2": [_ptr, _ptr, _c_long, _c_int, _c_int, _ptr],
     "objgan_reflect_fold": [_ptr, _ptr, _c_long, _c_int, _c_int, _ptr],
+    "objgan_pool2d_forward": [_ptr, _ptr, _ptr, _c_long, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr],
+    "objgan_pool2d_backward": [_ptr, _ptr, _ptr, _c_long, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_adam_step": [_ptr, _ptr, _ptr, _ptr, _c_long, _c_double, _c_double, _c_double, _c_double, _c_int, _c_float, _ptr],
     "objgan_adam_step_gated": [_ptr, _ptr, _ptr, _ptr, _c_long, _c_double, _c_double, _c_double, _c_double,
                                _ptr, _ptr, _ptr, _c_float, _ptr],
@@ -61,6 +63,7 @@ SIGNATURES = {
     "objgan_prof_enable": [_c_int],
     "objgan_conv_bank_layout": [_c_int] * 10,
     "objgan_prof_collect": [_ptr, _ptr, _ptr],
+    "objgan_prof_dump": [_ptr, _ptr, _ptr, _c_int, _ptr],
 }
 LONG_RETURN = {"objgan_conv_packed_floats": [_c_int, _c_int, _c_int]}
 

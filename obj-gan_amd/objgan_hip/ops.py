@@ -762,6 +762,44 @@ def avgpool2s1(x):
     return _AvgPool2s1Fn.apply(x)
 
 
+class _Pool2dFn(torch.autograd.Function):
+    """F.max_pool2d(x, k, s) / F.avg_pool2d(x, k, s, p) of the frozen Inception-v3 encoder."""
+
+    @staticmethod
+    def forward(ctx, x, k, s, p, mode):
+        _chk(x)
+        x = _c(x)
+        H, W = x.shape[-2], x.shape[-1]
+        OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        planes = x.numel() // (H * W) if x.numel() else 0
+        y = torch.empty(tuple(x.shape[:-2]) + (OH, OW), dtype=_F32, device=x.device)
+        need_idx = mode == 0 and ctx.needs_input_grad[0]
+        idx = torch.empty(y.shape, dtype=torch.int32, device=x.device) if need_idx else None
+        _lib.call("objgan_pool2d_forward", _p(x), _p(y), _p(idx), planes, H, W, OH, OW, k, s, p, mode, _stream())
+        ctx.geom = (tuple(x.shape), planes, H, W, OH, OW, k, s, p, mode)
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        shape, planes, H, W, OH, OW, k, s, p, mode = ctx.geom
+        dy = _c(dy)
+        _chk(dy)
+        dx = torch.empty(shape, dtype=_F32, device=dy.device)
+        _lib.call("objgan_pool2d_backward", _p(dy), _p(idx), _p(dx), planes, H, W, OH, OW, k, s, p, mode, _stream())
+        return dx, None, None, None, None
+
+
+def max_pool2d(x, kernel_size, stride):
+    return _Pool2dFn.apply(x, int(kernel_size), int(stride), 0, 0)
+
+
+def avg_pool2d(x, kernel_size, stride=None, padding=0):
+    k = int(kernel_size)
+    return _Pool2dFn.apply(x, k, k if stride is None else int(stride), int(padding), 1)
+
+
 class _BilinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, oh, ow):

@@ -162,7 +162,9 @@ def category_embeddings(glove_weight, cat_labels, cat_label_lens, sorted_cat_lab
 
 
 def _dist_on():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """A process group exists: the data-parallel path is taken, at any world size (a one-rank group runs
+    the same collectives -- that is how the RCCL path is exercised on a single-GPU box)."""
+    return dist.is_available() and dist.is_initialized()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -193,8 +195,9 @@ class condGANTrainer(object):
         for name in ("n_words", "ixtoword", "cats_index_dict", "cat_labels", "cat_label_lens",
                      "sorted_cat_label_indices"):
             setattr(self, name, getattr(dataset, name, None))
-        self.rank = dist.get_rank() if _dist_on() else 0
-        self.world = dist.get_world_size() if _dist_on() else 1
+        self.ddp = _dist_on()
+        self.rank = dist.get_rank() if self.ddp else 0
+        self.world = dist.get_world_size() if self.ddp else 1
         self.is_stream = torch.cuda.Stream(device=self.device) \
             if self.inception_model is not None and self.device.type == "cuda" else None
         # The object discriminators consume the second stage's bottom-up codes: a one-stage tree cannot
@@ -236,7 +239,7 @@ class condGANTrainer(object):
             netObjLSD.load_state_dict(torch.load('%s/netObjLSD.pth' % base, map_location="cpu"))
         for net in nets:
             net.to(self.device).train()
-        if self.world > 1:      # identical replicas: rank 0's weights everywhere
+        if self.ddp:            # identical replicas: rank 0's weights everywhere
             for net in nets:
                 for t in list(net.parameters()) + list(net.buffers()):
                     dist.broadcast(t.data, src=0)
@@ -329,7 +332,7 @@ class condGANTrainer(object):
     def _reduce_async(self, opt):
         """One RCCL all-reduce (sum) of a network's flat gradient arena; averaging is folded
         into the Adam kernel's grad_scale."""
-        if self.world == 1:
+        if not self.ddp:
             return None
         opt.arena.sync_grads()
         return dist.all_reduce(opt.arena.grad, op=dist.ReduceOp.SUM, async_op=True)

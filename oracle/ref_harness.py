@@ -106,8 +106,8 @@ def load_reference(branch_num=3, batch_size=4):
     pkg = os.path.join(os.path.dirname(here), "obj-gan_amd")
     if pkg not in sys.path:
         sys.path.append(pkg)
-    import encoders                      # the shared Inception-v3 stand-in (no torchvision here)
-    _install_stub_packages(encoders.inception_v3)
+    from oracle import torch_encoders    # the plain-PyTorch Inception-v3 stand-in (no torchvision here)
+    _install_stub_packages(torch_encoders.inception_v3)
     np.int = int
     np.float = float
     # the product package uses the same top-level module names as the reference: load the

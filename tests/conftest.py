@@ -30,3 +30,15 @@ def rel_l2(a, b):
     if den == 0:
         return float(torch.linalg.vector_norm(a - b))
     return float(torch.linalg.vector_norm(a - b) / den)
+
+
+def note(key, value):
+    """Append an observed parity number to gpurun_out/parity_numbers.txt (copied to profiles/ per round):
+    the bounds asserted by the tests say what must hold, this file says what was measured."""
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_numbers.txt"), "a") as f:
+            f.write("%-70s %s\n" % (key, value))
+    except OSError:
+        pass

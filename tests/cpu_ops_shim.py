@@ -92,6 +92,14 @@ def lstm_bidir_forward(table, captions, lens, wt_ih, wt_hh, b_ih, b_hh, max_len)
     return tm.rnn_encoder_forward(sd, captions, lens, int(max_len))
 
 
+def max_pool2d(x, kernel_size, stride):
+    return F.max_pool2d(x, kernel_size, stride)
+
+
+def avg_pool2d(x, kernel_size, stride=None, padding=0):
+    return F.avg_pool2d(x, kernel_size, stride, padding)
+
+
 def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, n=None):
     n = p.numel() if n is None else int(n)
     pn, mn, vn = tr.adam_step(p[:n], g[:n] * grad_scale, m[:n], v[:n], lr, beta1, beta2, eps, step)
@@ -127,7 +135,7 @@ def get_conv_math():
 
 API = ("conv2d", "conv2d_frozen", "linear", "norm_act", "norm_act_eval", "attn_general", "attn_bu", "masked_max",
        "softmax_strided", "roi_align", "avgpool2s1", "bilinear_resize", "lstm_bidir_forward", "adam_step_",
-       "adam_step_gated_", "ema_update_")
+       "adam_step_gated_", "ema_update_", "max_pool2d", "avg_pool2d")
 
 
 def install(monkeypatch):
@@ -137,10 +145,11 @@ def install(monkeypatch):
     import GlobalAttention
     import model
     import trainer
+    import encoders
     from miscc import losses, utils
     shim = types.SimpleNamespace(**{k: globals()[k] for k in API})
     shim.set_conv_math, shim.get_conv_math = set_conv_math, get_conv_math
-    for mod in (model, GlobalAttention, trainer, losses, utils):
+    for mod in (model, GlobalAttention, trainer, losses, utils, encoders):
         if hasattr(mod, "ops"):
             monkeypatch.setattr(mod, "ops", shim)
     for name in ("models.roi_align.modules.roi_align", "models.roi_align.functions.roi_align"):

@@ -19,7 +19,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "obj-gan_amd")]
 
 from oracle import ref_harness as rh          # noqa: E402
 import synth_batch                            # noqa: E402
-import encoders                               # noqa: E402
+from oracle import torch_encoders as encoders  # noqa: E402  (plain-PyTorch Inception-v3)
 
 B = 2
 SEEDS = dict(batch=1234, G=11, pat=21, shp=31, objss=41, objls=42, inception=51, enc_proj=52)

@@ -42,6 +42,10 @@ def _worker(rank, world, port, q):
         pn, mn, vn = torch_ref.adam_step(p[:n], g[:n] * grad_scale, m[:n], v[:n], lr, b1, b2, eps, step)
         p[:n].copy_(pn); m[:n].copy_(mn); v[:n].copy_(vn)
     T.ops.adam_step_ = cpu_adam
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import cpu_ops_shim
+    cpu_ops_shim.adam_step_ = cpu_adam
+    T.ops.adam_step_gated_ = cpu_ops_shim.adam_step_gated_
 
     net = _make_net(0)                                  # identical replicas
     arena = T.ParamArena(net)
@@ -58,10 +62,10 @@ def _worker(rank, world, port, q):
     arena.grad[-1] = 1.0 if rank == 0 else 0.0          # only rank 0 "has boxes of this scale"
     h = dist.all_reduce(arena.grad, op=dist.ReduceOp.SUM, async_op=True)
     h.wait()
-    active = bool(arena.grad[-1].item() > 0)
     grad_avg = arena.grad[:arena.n].clone() / world
-    if active:
-        opt.step(grad_scale=1.0 / world)
+    # the gate is the flag slot itself, read by the optimizer kernel: no host-side decision
+    opt.step(grad_scale=1.0 / world, gated=True)
+    active = opt.steps_taken == 1
     q.put((rank, active, grad_avg, arena.flat.clone()))
     dist.barrier()
     dist.destroy_process_group()

@@ -167,3 +167,21 @@ def test_load_params_invalidates_filter_bank_caches():
     assert not torch.allclose(bank1, ref0) and float(bank1.max()) == 1.0   # 4 taps of 0.25 summed
     load_params(net, backup)
     assert torch.allclose(ops._up_bank(w)[0], ref0)
+
+
+def test_product_inception_wiring_matches_oracle_twin_on_the_cpu_shim(monkeypatch):
+    """encoders.py (kernels only, no CPU path) with its `ops` pointed at the CPU definitions of the
+    kernels: module wiring, BatchNorm folding and pooling geometry against oracle/torch_encoders.py."""
+    import cpu_ops_shim
+    import encoders
+    from oracle import torch_encoders as te
+    cpu_ops_shim.install(monkeypatch)
+    enc = encoders.CNN_ENCODER(256, encoders.seeded_init_(encoders.inception_v3(), 5)).eval()
+    for p in enc.parameters():
+        p.requires_grad_(False)
+    x = torch.tanh(torch.randn(1, 3, 48, 48, generator=torch.Generator().manual_seed(2)))
+    with torch.no_grad():
+        r0, c0 = te.cpu_twin(enc)(x)
+        r1, c1 = enc(x)
+    rel = lambda a, b: float((a - b).norm() / b.norm())   # noqa: E731
+    assert rel(r1, r0) < 1e-5 and rel(c1, c0) < 1e-5

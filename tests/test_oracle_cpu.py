@@ -108,7 +108,7 @@ def test_oracle_generator_matches_reference_golden():
 def test_oracle_losses_match_reference_golden():
     from oracle import torch_model as tm
     import synth_batch
-    import encoders
+    from oracle import torch_encoders as encoders
     from oracle import ref_harness as rh
     g = _golden()
     s = g["seeds"]

@@ -1,16 +1,21 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): [tests,] conv micro-bench, bench line, rocprofv3 kernel stats.
-#   tools/gpu_round.sh TAG [test] [convbench] [bench] [prof] [cpu]
+#   tools/gpu_round.sh TAG [test] [convbench] [bench] [benchfull] [benchddp] [prof] ...
 set -x
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 TAG=${1:-run}; shift
 R=$GRAFT_REPO_ROOT
 for what in "$@"; do case $what in
-test) ( time timeout 900 python -m pytest tests -m gpu -x -q ) > gpurun_out/${TAG}_pytest.log 2>&1; tail -5 gpurun_out/${TAG}_pytest.log ;;
+test) rm -f gpurun_out/parity_numbers.txt
+  ( time timeout 1500 python -m pytest tests -m gpu -x -q ) > gpurun_out/${TAG}_pytest.log 2>&1; tail -5 gpurun_out/${TAG}_pytest.log
+  cp gpurun_out/parity_numbers.txt gpurun_out/${TAG}_parity.txt 2>/dev/null ;;
+testk) ( time timeout 900 python -m pytest tests -m gpu -x -q -k "$OG_K" ) > gpurun_out/${TAG}_pytestk.log 2>&1; tail -15 gpurun_out/${TAG}_pytestk.log ;;
 convbench) ( timeout 300 tools/conv_bench "" 5 ) > gpurun_out/${TAG}_convbench.log 2>&1; cat gpurun_out/${TAG}_convbench.log ;;
-bench) ( time timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ) > gpurun_out/${TAG}_bench.log 2>&1; tail -3 gpurun_out/${TAG}_bench.log ;;
-benchfull) ( time timeout 900 python bench.py ) > gpurun_out/${TAG}_benchfull.log 2>&1; tail -3 gpurun_out/${TAG}_benchfull.log ;;
-prof) cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof -o prof -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_prof.log 2>&1
+bench) ( time timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --shape-table gpurun_out/${TAG}_shapes.txt ) > gpurun_out/${TAG}_bench.log 2>&1; tail -3 gpurun_out/${TAG}_bench.log ;;
+benchfull) ( time timeout 900 python bench.py --steps 20 --warmup 5 ) > gpurun_out/${TAG}_benchfull.log 2>&1; tail -3 gpurun_out/${TAG}_benchfull.log ;;
+benchddp) ( time timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --force-ddp ) > gpurun_out/${TAG}_benchddp.log 2>&1; tail -3 gpurun_out/${TAG}_benchddp.log ;;
+benchbf16) ( time timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --math bf16 ) > gpurun_out/${TAG}_benchbf16.log 2>&1; tail -3 gpurun_out/${TAG}_benchbf16.log ;;
+prof) cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof -o prof -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing > $R/gpurun_out/${TAG}_prof.log 2>&1
   cd $R; find gpurun_out/${TAG}_prof -type f | head; find gpurun_out/${TAG}_prof -type f ! -name '*stats*' -size +1M -delete ;;
 esac; done
