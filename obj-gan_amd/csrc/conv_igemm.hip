@@ -1689,6 +1689,11 @@ static int og_wgrad3_maxtm() {
     if (v < 0) { const char* e = getenv("OG_WGRAD3_MAXTM"); v = e ? atoi(e) : 2; }
     return v;
 }
+static int og_wgrad_oldsplit() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OG_WGRAD_OLDSPLIT"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v;
+}
 static int og_wgrad_nob128() {      // development switch: OG_WGRAD_NOB128=1 restores the dword gathers
     static int v = -1;
     if (v < 0) { const char* e = getenv("OG_WGRAD_NOB128"); v = (e && e[0] == '1') ? 1 : 0; }
@@ -1976,13 +1981,31 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
             if (rows == 0) continue;
             a.m_begin = part == 0 ? 0 : full_rows * TM * 32;
             a.m_end = part == 0 ? (Cout < full_rows * TM * 32 ? Cout : full_rows * TM * 32) : Cout;
-            // split K (pixels) so that this launch fills the resident workgroup slots once
-            // (2 per CU for tall tiles, 3 up to TM = 4) without spilling into a second round
-            const int slots = 256 * (tm == 1 ? 6 : (tm <= 4 ? 3 : 2));   // LDS-free TM = 1: more waves
-            int splits = slots / (rows * tiles_n);
+            // split K (pixels): the launch takes about (workgroups per CU, rounded up) x (K steps per
+            // split + a fixed prologue / atomic-epilogue cost); pick the split count that minimises it
+            // (r02: `slots / workgroups` left the 288-workgroup launches of the 16x16 maps at 1 split --
+            // 32 CUs with two workgroups, 224 with one -- 63 TFLOP/s).  OG_WGRAD_OLDSPLIT=1: previous rule.
+            int splits;
             const int max_splits = og_cdiv(Npix, 512);       // >= 32 K steps per split
-            if (splits > max_splits) splits = max_splits;
-            if (splits < 1) splits = 1;
+            if (og_wgrad_oldsplit()) {
+                const int slots = 256 * (tm == 1 ? 6 : (tm <= 4 ? 3 : 2));   // LDS-free TM = 1: more waves
+                splits = slots / (rows * tiles_n);
+                if (splits > max_splits) splits = max_splits;
+                if (splits < 1) splits = 1;
+            } else {
+                const long wgs = (long)rows * tiles_n;
+                const int nsteps = og_cdiv(Npix, 16);
+                const int resident = tm == 1 ? 6 : (tm <= 4 ? 3 : 2);
+                double best = -1;
+                splits = 1;
+                for (int sp = 1; sp <= max_splits && sp <= 1024; ++sp) {
+                    const long per_cu = og_cdiv(wgs * sp, 256);
+                    // fewer co-resident workgroups than the CU can hold: nothing hides the memory latency
+                    const double lat = per_cu < resident ? 1.0 + 0.15 * (resident - per_cu) : 1.0;
+                    const double cost = (double)per_cu * (og_cdiv(nsteps, sp) + 10.0) * lat;
+                    if (best < 0 || cost < best * 0.985) { best = cost; splits = sp; }
+                }
+            }
             int pps = og_cdiv(Npix, splits);
             pps = (pps + 15) / 16 * 16;
             splits = og_cdiv(Npix, pps);

@@ -8,6 +8,8 @@ over captions (losses.py:87-127).  What remains in PyTorch here is scalar glue o
 most a few hundred kilobytes (BCE on B x 1 x k x k probabilities, cosine / log-sum-exp on
 B x B x L values, index selects).
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -74,7 +76,7 @@ def sent_loss(cnn_code, rnn_code, labels, class_ids, batch_size, eps=1e-8, top1=
 
 
 def words_loss(img_features, words_emb, labels, cap_lens, class_ids, batch_size, top1=True,
-               is_training=True):
+               is_training=True, need_att_maps=True):
     """
         words_emb(query): batch x nef x seq_len
         img_features(context): batch x nef x 17 x 17
@@ -86,7 +88,6 @@ def words_loss(img_features, words_emb, labels, cap_lens, class_ids, batch_size,
     S = ih * iw
     dev = img_features.device
     lens = cap_lens.detach().to(torch.int32)
-    lens_list = lens.cpu().tolist()
     lens_dev = lens.to(dev).clamp(max=L)
 
     # Eq. (7): every region x every word of every caption in one 1x1 convolution
@@ -112,7 +113,10 @@ def words_loss(img_features, words_emb, labels, cap_lens, class_ids, batch_size,
     row_sim = (row_sim * word_ok.to(row_sim.dtype)).sum(2)
     similarities = torch.log(row_sim) * cfg.TRAIN.SMOOTH.GAMMA3              # [image b, caption i]
 
-    att_maps = [a2[i, i, :lens_list[i]].reshape(1, -1, ih, iw).detach() for i in range(B)]
+    att_maps = None
+    if need_att_maps:        # per-caption maps for the visualisations: needs the lengths on the host (a sync)
+        lens_list = lens.cpu().tolist()
+        att_maps = [a2[i, i, :lens_list[i]].reshape(1, -1, ih, iw).detach() for i in range(B)]
     masks = _class_mask(class_ids, B, dev)
     if masks is not None:
         similarities = similarities.masked_fill(masks, -float('inf'))
@@ -226,6 +230,30 @@ def _obj_g_term(netObjD, fake_img, seg, slabels_emb, raw_bt_c_codes, rois, num_r
     return err * cfg.TRAIN.SMOOTH.OBJ_LAMBDA
 
 
+_ENC_OVERLAP = os.environ.get("OBJGAN_NO_ENC_OVERLAP") != "1"
+_SIDE = {}
+
+
+def _damsm_side(image_encoder, img, words_embs, sent_emb, match_labels, cap_lens, class_ids, batch_size):
+    """-> (DAMSM_LAMBDA * (word + sentence ranking losses), side stream) evaluated on a side stream."""
+    dev = img.device
+    side = _SIDE.get(dev)
+    if side is None:
+        side = _SIDE[dev] = torch.cuda.Stream(device=dev)
+    cur = torch.cuda.current_stream()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        region_features, cnn_code = image_encoder(img)
+        w0, w1, _, _ = words_loss(region_features, words_embs, match_labels, cap_lens, class_ids, batch_size,
+                                  top1=False, need_att_maps=False)
+        s0, s1, _ = sent_loss(cnn_code, sent_emb, match_labels, class_ids, batch_size, top1=False)
+        total = (w0 + w1 + s0 + s1) * cfg.TRAIN.SMOOTH.DAMSM_LAMBDA
+    for t in (img, words_embs, sent_emb):
+        t.record_stream(side)              # allocated on the main stream, read on the side stream
+    total.record_stream(cur)               # and the other way round
+    return total, side
+
+
 def G_loss(netsPatD, netsShpD, netObjSSD, netObjLSD, image_encoder, fake_imgs, seg_conditions,
            words_embs, sent_emb, slabels_emb, raw_bt_c_codes, match_labels, cap_lens, class_ids,
            rois, fm_rois, num_rois, quiet=False, use_obj=True):
@@ -237,6 +265,12 @@ def G_loss(netsPatD, netsShpD, netObjSSD, netObjLSD, image_encoder, fake_imgs, s
     logs = ''
     errG_total = 0
     sm = cfg.TRAIN.SMOOTH
+    # The DAMSM branch (frozen Inception-v3 encoder: ~100 convolutions on 35x35 ... 8x8 maps whose grids
+    # cover a fraction of the 256 CUs, then the word / sentence ranking losses) is independent of the
+    # discriminator passes below: on the GPU it runs on a side stream next to them, forward and -- since
+    # autograd replays every node on the stream of its forward -- backward.
+    damsm = _damsm_side(image_encoder, fake_imgs[numDs - 1], words_embs, sent_emb, match_labels, cap_lens,
+                        class_ids, batch_size) if quiet and _ENC_OVERLAP and fake_imgs[0].is_cuda else None
     for i in range(numDs):
         pat = _net(netsPatD[i])
         features = netsPatD[i](fake_imgs[i])
@@ -254,12 +288,16 @@ def G_loss(netsPatD, netsShpD, netObjSSD, netObjLSD, image_encoder, fake_imgs, s
         if not quiet:
             logs += 'shp_g_loss%d: %.2f ' % (i, shp_g_loss.item())
 
-        if i == (numDs - 1):        # DAMSM ranking loss on the full-resolution image
+        if i == (numDs - 1) and damsm is not None:
+            torch.cuda.current_stream().wait_stream(damsm[1])
+            errG_total = errG_total + damsm[0]
+        elif i == (numDs - 1):      # DAMSM ranking loss on the full-resolution image
             region_features, cnn_code = image_encoder(fake_imgs[i])
             w_loss0, w_loss1, _, _ = words_loss(region_features, words_embs, match_labels, cap_lens,
-                                                class_ids, batch_size)
+                                                class_ids, batch_size, top1=not quiet, need_att_maps=not quiet)
             w_loss = (w_loss0 + w_loss1) * sm.DAMSM_LAMBDA
-            s_loss0, s_loss1, _ = sent_loss(cnn_code, sent_emb, match_labels, class_ids, batch_size)
+            s_loss0, s_loss1, _ = sent_loss(cnn_code, sent_emb, match_labels, class_ids, batch_size,
+                                            top1=not quiet)
             s_loss = (s_loss0 + s_loss1) * sm.DAMSM_LAMBDA
             errG_total = errG_total + w_loss + s_loss
             if not quiet:

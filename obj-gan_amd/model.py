@@ -36,13 +36,43 @@ from objgan_hip import ops
 # ---------------------------------------------------------------------------------------------
 # small helpers shared by the blocks
 # ---------------------------------------------------------------------------------------------
+# BatchNorm's `num_batches_tracked` counters (pure bookkeeping: momentum is fixed) cost one 4 us launch per
+# layer and pass -- 111 per training step.  Inside `deferred_bn_counters()` the increments are collected on
+# the host and applied with one multi-tensor add per distinct count when the block exits.
+_NBT_PENDING = None
+
+
+class deferred_bn_counters(object):
+    def __enter__(self):
+        global _NBT_PENDING
+        self.outer = _NBT_PENDING
+        if self.outer is None:
+            _NBT_PENDING = {}
+        return self
+
+    def __exit__(self, *exc):
+        global _NBT_PENDING
+        if self.outer is None:
+            pending, _NBT_PENDING = _NBT_PENDING, None
+            by_count = {}
+            for t, k in pending.values():
+                by_count.setdefault(k, []).append(t)
+            for k, ts in by_count.items():
+                torch._foreach_add_(ts, k)
+        return False
+
+
 def _bn_act(x, bn, mode):
     """BatchNorm fused with GLU / LeakyReLU: batch statistics + running-stat update in train mode,
     running statistics (forward only) in eval mode -- sampling with the EMA generator."""
     if not bn.training:
         return ops.norm_act_eval(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, mode=mode, eps=bn.eps)
     if bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+        if _NBT_PENDING is not None:
+            ent = _NBT_PENDING.get(id(bn))
+            _NBT_PENDING[id(bn)] = (bn.num_batches_tracked, 1 if ent is None else ent[1] + 1)
+        else:
+            bn.num_batches_tracked += 1
     return ops.norm_act(x, bn.weight, bn.bias, None, bn.running_mean, bn.running_var,
                         per_channel=True, mode=mode, eps=bn.eps, momentum=bn.momentum)
 

@@ -342,6 +342,10 @@ class condGANTrainer(object):
         """batch: dict with imgs[3], hmaps[3], rois[3], fm_rois, num_rois, bt_masks[2], fm_bt_masks,
         words_embs, sent_emb, glove_words_embs, mask, clabels_emb, cap_lens, class_ids (see
         synth_batch.py).  Returns a dict of loss tensors (no host sync unless want_logs)."""
+        with M.deferred_bn_counters():
+            return self._train_step(batch, noise, want_logs)
+
+    def _train_step(self, batch, noise, want_logs):
         b = batch
         imgs, hmaps, rois = b["imgs"], b["hmaps"], b["rois"]
         fm_rois, num_rois = b["fm_rois"], b["num_rois"]
