@@ -185,3 +185,36 @@ def test_product_inception_wiring_matches_oracle_twin_on_the_cpu_shim(monkeypatc
         r1, c1 = enc(x)
     rel = lambda a, b: float((a - b).norm() / b.norm())   # noqa: E731
     assert rel(r1, r0) < 1e-5 and rel(c1, c0) < 1e-5
+
+
+def test_main_cli_mirrors_the_reference_arguments(tmp_path):
+    """main.py: the reference's argparse surface (main.py:26-56) and its args -> cfg wiring (:58-88), then
+    dataset / sharded loader / trainer construction on the committed six-image data directory."""
+    import copy
+    import os
+    from conftest import ROOT
+    import main as cli
+    from miscc.config import cfg
+    saved = copy.deepcopy(dict(cfg))
+    try:
+        data_dir = os.path.join(ROOT, "tests", "golden", "data_tiny")
+        args = cli.parse_args(["--gpu", "0", "--FLAG", "--data_dir", data_dir, "--BATCH_SIZE", "2",
+                               "--BRANCH_NUM", "3", "--OBJ_LAMBDA", "0.2", "--MAX_EPOCH", "1",
+                               "--output_dir", str(tmp_path), "--manualSeed", "7"])
+        cli.apply_args(args)
+        assert cfg.TRAIN.FLAG and cfg.TRAIN.BATCH_SIZE == 2 and cfg.GPU_IDS == [0] and cfg.CUDA
+        assert cfg.TRAIN.SMOOTH.OBJ_LAMBDA == 0.2 and cfg.TRAIN.MAX_EPOCH == 1
+        assert cfg.TRAIN.NET_E == data_dir + "/pretrained/text_encoder100.pth"
+        assert cfg.TEST.NET_SHP_G == data_dir + "/pretrained/shape_ckpt/shape_gen.pth"
+        assert cli.seed_everything(args, rank=1) == 7
+        dataset, loader, algo = cli.build_training(args, rank=0, world=1, device=torch.device("cpu"))
+        assert len(dataset) == 4 and len(loader) == 2 and algo.n_words == dataset.n_words      # train split of the tiny set
+        assert os.path.isdir(algo.model_dir) and algo.model_dir.startswith(str(tmp_path))
+        ref_defaults = cli.parse_args([])
+        assert ref_defaults.BATCH_SIZE == 24 and ref_defaults.gpu_ids == '-1' and not ref_defaults.FLAG
+        cli.apply_args(ref_defaults)
+        assert cfg.CUDA is False                      # '--gpu -1' switches CUDA off, like the reference
+    finally:
+        cfg.clear()
+        for k, v in saved.items():
+            cfg[k] = v
