@@ -243,7 +243,7 @@ def main():
     ops.set_conv_math(args.math)
     tr = build_trainer(device, args.batch, seed=1234, with_is_monitor=not args.no_is_monitor)
     # a new minibatch every step, like training: four distinct per-rank batches in rotation (the trainer
-    # drops its layout-lift memo at the start of every step, so nothing is carried from step to step)
+    # carries nothing from step to step)
     nb = max(1, min(4, args.steps + args.warmup))
     batches = [synth_batch.make_batch(args.batch, seed=1234 + rank + 1000 * i, device=device) for i in range(nb)]
     it = [0]

@@ -146,6 +146,20 @@ int objgan_bilinear_backward(const float* dy, float* dx, long planes, int ih, in
                              void* stream);
 int objgan_sum2x2(const float* dy, float* dx, long planes, int h, int w, void* stream);
 int objgan_reflect_fold(const float* dxp, float* dx, long planes, int h, int w, void* stream);
+/* Layout-map stem of the object discriminators without the 512x512 lift (reference
+ * image_generation/model.py:1217-1226: shp_code(F.interpolate(seg, 512, bilinear, align_corners))).  The channel
+ * contraction runs at low resolution (a 1x1 convolution C -> 9*Mo through objgan_conv_igemm); these two entry
+ * points apply the separable per-axis operator "shift by the tap offset o reflect-pad o bilinear lift" to its
+ * result, forward and adjoint.  z [N, 9*Mo, h, w] (channel (dh*3+dw)*Mo + co), y / dy [N, Mo, SH, SW],
+ * scratch N*3*Mo*h*SW floats.  Tables live in device memory and are built by the caller:
+ *   forward  [3][S] per axis: source indices i0, i1 and the weight l1 of i1 (l0 = 1 - l1), per tap offset;
+ *   backward CSR transposes: off [3][len+1], idx, wt. */
+int objgan_lift_taps_forward(const float* z, const float* bias, float* y, float* scratch, int N, int Mo, int h,
+                             int w, int SH, int SW, const int* ci0, const int* ci1, const float* cl1,
+                             const int* ri0, const int* ri1, const float* rl1, void* stream);
+int objgan_lift_taps_backward(const float* dy, float* dz, float* scratch, int N, int Mo, int h, int w, int SH,
+                              int SW, const int* roff, const int* ridx, const float* rwt, const int* coff,
+                              const int* cidx, const float* cwt, void* stream);
 /* Pooling layers of the frozen Inception-v3 encoder (reference image_generation/model.py:203-287:
  * F.max_pool2d(k3, s2), F.avg_pool2d(k3, s1, p1), F.avg_pool2d(k8)); planes = N*C NCHW planes.
  * mode 0 = max (no padding; idx receives the plane-local arg-max of every output for the backward pass,

@@ -781,30 +781,6 @@ def _rois_blob(fm_rois, boxes_num):
     return blob.to(torch.float32).contiguous()
 
 
-# Two-entry memo (least recently used out) of the bilinear lift of a layout map (80 channels,
-# 256^2 -> 512^2: 1.3 GB at B=16).  One step lifts two kinds of map: the batch's own layout
-# (both object discriminators, D and G phase: one lift serves all of them) and the permuted
-# "wrong layout" maps of each discriminator loss (fresh tensors every time) -- with a single entry
-# the latter evict the former between its uses.  An entry holds the source tensor itself, so its
-# address cannot be recycled while cached; an in-place torch edit of the source changes `_version`
-# and misses.
-_LIFT = []
-
-
-def _lift_cached(s_var, img_size):
-    if s_var.requires_grad:
-        return ops.bilinear_resize(s_var, img_size, img_size)
-    for i, (src, ver, size, out) in enumerate(_LIFT):
-        if src is s_var and ver == s_var._version and size == img_size:
-            if i:
-                _LIFT.insert(0, _LIFT.pop(i))
-            return out
-    out = ops.bilinear_resize(s_var, img_size, img_size)
-    _LIFT.insert(0, (s_var, s_var._version, img_size, out))
-    del _LIFT[2:]
-    return out
-
-
 class _ObjD(nn.Module):
     """ROIAlign-based object discriminator (reference model.py:1184-1312)."""
 
@@ -830,11 +806,13 @@ class _ObjD(nn.Module):
         self.COND_DNET = D_GET_LOGITS(ndf // 2, nef, bcondition=True)
 
     def encode_seg(self, s_var, img_size=512):
-        """shp_code(lift(s_var)) (reference model.py:1218-1226): depends on the layout map only, so
-        the real and fake passes of one loss evaluation share it; the parameter-free bilinear lift
-        to img_size is shared further -- by both object discriminators and by every pass of a step
-        that sees the same layout tensor."""
-        return self.shp_code(_lift_cached(s_var, img_size))
+        """shp_code(F.interpolate(s_var, img_size, bilinear, align_corners)) (reference model.py:1217-1226)
+        WITHOUT the lifted map: the 80 -> 12 channel contraction runs at the source resolution, the lift /
+        reflect-pad / tap shifts are applied to its 9 x 12 planes (objgan_hip.ops.lift_stem_conv).  Depends
+        on the layout map only, so the real and fake passes of one loss evaluation share the result."""
+        conv, inorm = self.shp_code[1], self.shp_code[2]
+        y = ops.lift_stem_conv(s_var, conv.weight, conv.bias, img_size)
+        return _in_act(y, inorm, "lrelu")
 
     def forward(self, x_var, s_var, fm_rois, num_rois, img_size=512, s_code=None):
         x_var = ops.bilinear_resize(x_var, img_size, img_size)

@@ -54,6 +54,10 @@ SIGNATURES = {
     "objgan_bilinear_backward": [_ptr, _ptr, _c_long, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_sum2x2": [_ptr, _ptr, _c_long, _c_int, _c_int, _ptr],
     "objgan_reflect_fold": [_ptr, _ptr, _c_long, _c_int, _c_int, _ptr],
+    "objgan_lift_taps_forward": [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                 _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "objgan_lift_taps_backward": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                  _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "objgan_pool2d_forward": [_ptr, _ptr, _ptr, _c_long, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_pool2d_backward": [_ptr, _ptr, _ptr, _c_long, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_adam_step": [_ptr, _ptr, _ptr, _ptr, _c_long, _c_double, _c_double, _c_double, _c_double, _c_int, _c_float, _ptr],

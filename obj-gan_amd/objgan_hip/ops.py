@@ -235,6 +235,14 @@ def _grad_slot(w):
     return g
 
 
+def _notify_ready(w):
+    """A gradient accumulated in place bypasses AccumulateGrad: tell the owner (the optimizer arena's
+    bucketed all-reduce) that this parameter's gradient is final."""
+    cb = getattr(w, "_og_ready", None)
+    if cb is not None:
+        cb()
+
+
 def _conv_wgrad(x, g, Cout, k, stride, pad, refl, upsample, into=None):
     """Gradient w.r.t. the filter bank [Cout, Cin, k, k] of conv(x, w) given g = dL/d(conv output);
     `into`: accumulate into this tensor instead of returning a fresh one."""
@@ -291,6 +299,7 @@ class _Conv2dFn(torch.autograd.Function):
             dw_ = _conv_wgrad(x, g, Cout, k, stride, pad, refl, upsample, into=slot)
             if slot is not None:
                 dw_ = None
+                _notify_ready(w)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(Cout, dtype=_F32, device=x.device)
             _lib.call("objgan_channel_sum", _p(g), _p(db), N, Cout, g.shape[2] * g.shape[3], _stream())
@@ -378,6 +387,7 @@ class _UpConv3x3Fn(torch.autograd.Function):
             if slot is not None:
                 slot.add_(dw_)
                 dw_ = None
+                _notify_ready(w)
         return dx, dw_
 
 
@@ -824,6 +834,101 @@ class _BilinearFn(torch.autograd.Function):
 def bilinear_resize(x, oh, ow):
     """F.interpolate(x, size=(oh, ow), mode='bilinear', align_corners=True)."""
     return _BilinearFn.apply(x, int(oh), int(ow))
+
+
+# ---- layout-map stem of the object discriminators, evaluated below the 512x512 lift -------------------
+# conv3x3(reflect_pad(lift(seg)))[co] = sum_taps (shift_tap o reflect o lift)(conv1x1(seg; W[:, :, tap])[co]):
+# the channel contraction is a 1x1 convolution at the source resolution (MFMA kernel), the pixel operators
+# are separable per axis and table-driven (csrc/lift_stem.hip).
+_LIFT_TABLES = {}
+
+
+def _lift_axis_tables(n_in, n_out, device):
+    """Per-axis operator A_d = shift_d o reflect o bilinear(align_corners) for d = -1, 0, +1: forward tables
+    (i0, i1, l1) [3][n_out] and their CSR transposes (off [3][n_in + 1], idx, wt), in the fp32 arithmetic of
+    bilinear_fwd_kernel (src = scale * dst)."""
+    key = (n_in, n_out, str(device))
+    ent = _LIFT_TABLES.get(key)
+    if ent is not None:
+        return ent
+    import numpy as np
+    scale = np.float32(n_in - 1) / np.float32(n_out - 1) if n_out > 1 else np.float32(0)
+    i0s, i1s, l1s, offs, idxs, wts = [], [], [], [], [], []
+    base = 0
+    for d in (-1, 0, 1):
+        r = np.arange(n_out, dtype=np.int64) + d
+        r = np.where(r < 0, -r, r)
+        r = np.where(r >= n_out, 2 * (n_out - 1) - r, r)
+        src = (scale * r.astype(np.float32)).astype(np.float32)
+        i0 = np.minimum(src.astype(np.int32), n_in - 1)
+        i1 = i0 + (i0 < n_in - 1)
+        l1 = (src - i0.astype(np.float32)).astype(np.float32)
+        l0 = (np.float32(1.0) - l1).astype(np.float32)
+        i0s.append(i0); i1s.append(i1); l1s.append(l1)
+        q = np.concatenate([i0, i1]).astype(np.int64)
+        o = np.concatenate([np.arange(n_out), np.arange(n_out)])
+        wv = np.concatenate([l0, l1])
+        order = np.lexsort((o, q))
+        q, o, wv = q[order], o[order], wv[order]
+        off = np.zeros(n_in + 1, np.int64)
+        np.add.at(off, q + 1, 1)
+        off = np.cumsum(off) + base
+        base = int(off[-1])
+        offs.append(off); idxs.append(o); wts.append(wv)
+    def t(arrays, dt, flat=False):
+        a = np.concatenate(arrays) if flat else np.stack(arrays)
+        return torch.from_numpy(np.ascontiguousarray(a.astype(dt))).to(device)
+    ent = (t(i0s, np.int32), t(i1s, np.int32), t(l1s, np.float32),
+           t(offs, np.int32), t(idxs, np.int32, True), t(wts, np.float32, True))
+    _LIFT_TABLES[key] = ent
+    return ent
+
+
+class _LiftTapsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, bias, SH, SW):
+        _chk(z, bias)
+        z = _c(z)
+        N, C9, h, w = z.shape
+        Mo = C9 // 9
+        rows = _lift_axis_tables(h, SH, z.device)
+        cols = _lift_axis_tables(w, SW, z.device)
+        y = torch.empty((N, Mo, SH, SW), dtype=_F32, device=z.device)
+        scratch = torch.empty(N * 3 * Mo * h * SW, dtype=_F32, device=z.device)
+        _lib.call("objgan_lift_taps_forward", _p(z), _p(bias), _p(y), _p(scratch), N, Mo, h, w, SH, SW,
+                  _p(cols[0]), _p(cols[1]), _p(cols[2]), _p(rows[0]), _p(rows[1]), _p(rows[2]), _stream())
+        ctx.geom = (N, Mo, h, w, SH, SW)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, Mo, h, w, SH, SW = ctx.geom
+        dy = _c(dy)
+        _chk(dy)
+        dz = db = None
+        if ctx.needs_input_grad[0]:
+            rows = _lift_axis_tables(h, SH, dy.device)
+            cols = _lift_axis_tables(w, SW, dy.device)
+            dz = torch.empty((N, 9 * Mo, h, w), dtype=_F32, device=dy.device)
+            scratch = torch.empty(N * 3 * Mo * h * SW, dtype=_F32, device=dy.device)
+            _lib.call("objgan_lift_taps_backward", _p(dy), _p(dz), _p(scratch), N, Mo, h, w, SH, SW,
+                      _p(rows[3]), _p(rows[4]), _p(rows[5]), _p(cols[3]), _p(cols[4]), _p(cols[5]), _stream())
+        if ctx.has_bias and ctx.needs_input_grad[1]:
+            db = torch.empty(Mo, dtype=_F32, device=dy.device)
+            _lib.call("objgan_channel_sum", _p(dy), _p(db), N, Mo, SH * SW, _stream())
+        return dz, db, None, None
+
+
+def lift_stem_conv(seg, w, bias, size):
+    """conv2d(reflect_pad(F.interpolate(seg, (size, size), 'bilinear', align_corners=True)), w, bias) for a 3x3
+    bank w [Mo, C, 3, 3] (reference model.py:1217-1226), without materialising the lifted map."""
+    Mo, C = w.shape[0], w.shape[1]
+    if w.shape[2] != 3 or w.shape[3] != 3:
+        raise _lib.ObjganHipError("lift_stem_conv: 3x3 filter bank expected")
+    w9 = w.permute(2, 3, 0, 1).reshape(9 * Mo, C, 1, 1)          # row (dh*3 + dw)*Mo + co
+    z = conv2d(seg, w9.contiguous())
+    return _LiftTapsFn.apply(z, bias, int(size), int(size))
 
 
 # ----------------------------------------------------------------------------------------------

@@ -80,6 +80,60 @@ class ParamArena(object):
         for p, gv in zip(self.params, self._views):
             p.grad = gv
 
+    # ---- gradient-ready notification, in buckets (data-parallel overlap of the generator's all-reduce) ----
+    def make_buckets(self, k=4):
+        """Split the arena into <= k contiguous ranges of whole parameters (registration order, about equal
+        sizes) and install the per-parameter 'gradient is final' notifications: AccumulateGrad's
+        post-hook for gradients autograd delivers, `p._og_ready()` for those a kernel accumulates in place."""
+        if getattr(self, "buckets", None) is not None:
+            return self.buckets
+        target = max(1, self.n // k)
+        self.buckets, self._bucket_of = [], []
+        start = off = 0
+        members = []
+        for i, p in enumerate(self.params):
+            members.append(i)
+            off += p.numel()
+            if off - start >= target and len(self.buckets) < k - 1:
+                self.buckets.append((start, off, members))
+                start, members = off, []
+        if members:
+            self.buckets.append((start, off, members))
+        self._bucket_of = [0] * len(self.params)
+        for b, (_, _, mem) in enumerate(self.buckets):
+            for i in mem:
+                self._bucket_of[i] = b
+        self._armed = None
+        for i, p in enumerate(self.params):
+            cb = (lambda *_a, i=i: self._mark(i))
+            p._og_ready = cb
+            p.register_post_accumulate_grad_hook(cb)
+        return self.buckets
+
+    def arm(self, on_bucket):
+        """Until disarm(): on_bucket(start, end) is called once per bucket, as soon as every parameter of the
+        bucket has reported its gradient (each parameter of the network is used once per forward)."""
+        self.make_buckets()
+        self._armed = (on_bucket, [set(mem) for (_, _, mem) in self.buckets], set())
+
+    def _mark(self, i):
+        if self._armed is None:
+            return
+        on_bucket, waiting, fired = self._armed
+        b = self._bucket_of[i]
+        waiting[b].discard(i)
+        if not waiting[b] and b not in fired:
+            fired.add(b)
+            on_bucket(self.buckets[b][0], self.buckets[b][1])
+
+    def disarm(self):
+        """-> the (start, end) ranges that never fired (a parameter without a gradient this step)."""
+        if self._armed is None:
+            return []
+        _, _, fired = self._armed
+        self._armed = None
+        return [(s0, e0) for b, (s0, e0, _) in enumerate(self.buckets) if b not in fired]
+
     def sync_grads(self):
         """Make sure every gradient lives in the arena (callers may have used
         module.zero_grad(set_to_none=True) or assigned .grad themselves)."""
@@ -369,7 +423,6 @@ class condGANTrainer(object):
             words_embs, sent_emb = b["words_embs"], b["sent_emb"]
         inv_world = 1.0 / self.world
         out = {}
-        M._LIFT.clear()          # the layout-lift memo never outlives a step (every step brings new tensors)
 
         clabels_feat = form_clabels_feat(clabels_emb, rois[0], num_rois)
         # (2) generate fake images
@@ -437,12 +490,22 @@ class condGANTrainer(object):
                                             bt_last, b, rois, fm_rois, num_rois)
         kl = KL_loss(mu, logvar)
         errG_total = errG_total + kl
+        # data parallel: the generator's gradient arena is all-reduced in buckets AS its backward pass
+        # completes them (stage 3 first), not in one piece after it
+        g_arena, handles = self.optimizerG.arena, []
+        if self.ddp:
+            g_arena.arm(lambda s0, e0: handles.append(
+                dist.all_reduce(g_arena.grad[s0:e0], op=dist.ReduceOp.SUM, async_op=True)))
         errG_total.backward()
         for opt in d_opts:
             opt.arena.set_requires_grad(True)
-        h = self._reduce_async(self.optimizerG)
-        if h is not None:
-            h.wait()
+        if self.ddp:
+            during = len(handles)
+            for s0, e0 in g_arena.disarm():
+                handles.append(dist.all_reduce(g_arena.grad[s0:e0], op=dist.ReduceOp.SUM, async_op=True))
+            self.g_buckets = (during, len(handles) - during)     # issued inside backward / after it
+            for h in handles:
+                h.wait()
         self.optimizerG.step(grad_scale=inv_world)
         ops.ema_update_(self.avg_param_G, self.optimizerG.arena.flat, 0.999)
         out["errG"] = errG_total.detach()

@@ -92,6 +92,12 @@ def lstm_bidir_forward(table, captions, lens, wt_ih, wt_hh, b_ih, b_hh, max_len)
     return tm.rnn_encoder_forward(sd, captions, lens, int(max_len))
 
 
+def lift_stem_conv(seg, w, bias, size):
+    """definition: the reference formulation (model.py:1217-1226)"""
+    up = F.interpolate(seg, size=(size, size), mode="bilinear", align_corners=True)
+    return F.conv2d(F.pad(up, (1, 1, 1, 1), mode="reflect"), w, bias)
+
+
 def max_pool2d(x, kernel_size, stride):
     return F.max_pool2d(x, kernel_size, stride)
 
@@ -135,7 +141,7 @@ def get_conv_math():
 
 API = ("conv2d", "conv2d_frozen", "linear", "norm_act", "norm_act_eval", "attn_general", "attn_bu", "masked_max",
        "softmax_strided", "roi_align", "avgpool2s1", "bilinear_resize", "lstm_bidir_forward", "adam_step_",
-       "adam_step_gated_", "ema_update_", "max_pool2d", "avg_pool2d")
+       "adam_step_gated_", "ema_update_", "max_pool2d", "avg_pool2d", "lift_stem_conv")
 
 
 def install(monkeypatch):
@@ -156,7 +162,6 @@ def install(monkeypatch):
         m = sys.modules.get(name)
         if m is not None and hasattr(m, "ops"):
             monkeypatch.setattr(m, "ops", shim)
-    monkeypatch.setattr(model, "_LIFT", [])
     monkeypatch.setattr(utils, "_HOST", [])
     return shim
 

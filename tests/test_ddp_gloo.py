@@ -193,6 +193,7 @@ def _trainer_worker(rank, world, port, q):
     random.seed(7 + rank)
     out = tr.train_step(b, noise=b["noise"])
     # numpy copies: a tensor put on the queue travels through shared memory owned by this process
+    assert tr.g_buckets[0] >= 3 and tr.g_buckets[1] <= 1, tr.g_buckets   # generator all-reduce overlapped its backward
     q.put((rank, "errObjLSD" in out, tr.optimizerG.arena.flat.numpy().copy(),
            tr.optimizersPatD[1].arena.flat.numpy().copy(), tr.optimizerObjLSD.arena.flat.numpy().copy(),
            init_ls.numpy().copy(), tr.avg_param_G.numpy().copy()))

@@ -489,6 +489,31 @@ def test_inception_loads_a_torchvision_keyed_checkpoint(dev):
     assert set(enc.state_dict().keys()) == want
 
 
+def test_lift_stem_conv_matches_the_reference_formulation(dev):
+    """shp_code's conv over the bilinearly lifted layout map (reference model.py:1217-1226), evaluated below
+    the lift (1x1 channel contraction at the source resolution + separable lift / reflect / shift operator):
+    output, weight / bias gradients and the gradient w.r.t. the map against
+    conv2d(reflect_pad(F.interpolate(seg, S, bilinear, align_corners=True)), w, b) on the CPU."""
+    import torch.nn.functional as F
+    ops = _ops()
+    g = torch.Generator().manual_seed(23)
+    for (N, C, Mo, h, S) in [(2, 80, 12, 32, 64), (1, 7, 5, 9, 25), (2, 80, 12, 64, 128)]:
+        seg = torch.rand(N, C, h, h, generator=g)
+        w = torch.randn(Mo, C, 3, 3, generator=g) / (C * 9) ** 0.5
+        b = torch.randn(Mo, generator=g)
+        sr, wr, br = seg.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+        up = F.interpolate(sr, size=(S, S), mode="bilinear", align_corners=True)
+        yr = F.conv2d(F.pad(up, (1, 1, 1, 1), mode="reflect"), wr, br)
+        gy = torch.randn(yr.shape, generator=g)
+        yr.backward(gy)
+        sd, wd, bd = (t.to(dev).requires_grad_() for t in (seg, w, b))
+        yd = ops.lift_stem_conv(sd, wd, bd, S)
+        yd.backward(gy.to(dev))
+        torch.cuda.synchronize()
+        e = (rel_l2(yd, yr), rel_l2(wd.grad, wr.grad), rel_l2(bd.grad, br.grad), rel_l2(sd.grad, sr.grad))
+        assert max(e) < TOL, ((N, C, Mo, h, S), e)
+
+
 def test_gated_adam_follows_the_device_flag(dev):
     """objgan_adam_step_gated: flag <= 0 leaves parameters, moments and the device step counter untouched;
     flag > 0 reproduces torch.optim.Adam step for step (bias corrections from the device counter)."""
