@@ -67,6 +67,8 @@ struct IgemmArgs {
     int ksplit_steps;    // > 0: split-K -- blockIdx.y owns this many BK steps, epilogue = atomicAdd
     int nphase;          // > 1 (v2 kernel only): blockIdx.z = output phase p with its own tap table
                          // tap[p*8 ..], packed bank wt + p*M*Kpad and output offset (ooh, oow) = (p>>1, p&1)
+    int xr_begin, xr_count;   // XR kernels: rows [xr_begin, xr_begin + xr_count) (<= 4) ride along with block
+                              // row 0 on the fp32 VALU instead of costing a 32-row MFMA group (194 = 6*32 + 2)
     int tap[OG_MAX_TAPS];   // (dw << 16) | (dh & 0xffff): one scalar load per (uniform) tap
 };
 
@@ -560,6 +562,7 @@ struct WgradArgs {
     int ncol;
     int pix_per_split;
     int math;          // 0 fp32, 1 bf16 inputs
+    int xr_begin, xr_count;   // XR kernels: dy rows [xr_begin, xr_begin + xr_count) (<= 4) on the VALU (block row 0)
 };
 
 template <int KS, int WM, int TM>
@@ -715,7 +718,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 // SCALAR (n, oh, ow0 .. ow0+7), the per-lane part is the column's (ci, kh, kw) -- dy rows are read
 // as aligned 16-byte pieces with a constant per-lane offset, x elements as dwords whose validity
 // (zero padding) rides on the buffer range check.
-template <int TM, bool BF = false>
+template <int TM, bool BF = false, int XR = 0>
 __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, const int KS) {
     constexpr int BM = 32 * TM;
     constexpr int BN = 128;
@@ -723,7 +726,9 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
     constexpr int LD = BK + 4;
     constexpr int NA4 = BM * 4;
     constexpr int NA_PER = (NA4 + 255) / 256;
-    constexpr int TILE = (BM + BN) * LD;
+    constexpr int AROWS = BM + XR;                     // dy rows in LDS (XR extra rows, see conv_igemm3_kernel)
+    constexpr int TILE = (AROWS + BN) * LD;
+    static_assert(XR == 0 || !BF, "extra rows: fp32 only");
 
     __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
 
@@ -784,7 +789,12 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
         alds[i] = (NA4 % 256 == 0 || idx < NA4) ? row * LD + q * 4 : -1;
     }
 
+    const bool has_x = XR > 0 && tile_m == 0 && a.xr_count > 0;
+    const bool x_loader = has_x && tid < XR * 4;
+    const unsigned xvoff = (x_loader && (tid >> 2) < a.xr_count)
+        ? ((unsigned)(a.xr_begin + (tid >> 2)) * (unsigned)OHW + (tid & 3) * 4u) * 4u : OG_OOB;
     f32x4 ra[NA_PER];
+    f32x4 rax = {0.f, 0.f, 0.f, 0.f};
     float rb[8];
     // scalar pixel state of the next K step to load: image n, offset rem in the image, and the
     // (row, first column) of this wave's eight pixels; advanced incrementally (no divisions)
@@ -798,6 +808,8 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
 #pragma unroll
         for (int i = 0; i < NA_PER; ++i)
             ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyres, avoff[i], asoff, 0));
+        if (XR > 0 && has_x)
+            rax = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyres, xvoff, asoff, 0));
         rem_ld += BK;
         ow_ld += BK;
         while (ow_ld >= a.OW) { ow_ld -= a.OW; oh_ld += 1; }
@@ -824,10 +836,11 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
     };
     auto store_step = [&](int buf) {
         float* As = lds + buf * TILE;
-        float* Bs = As + BM * LD;
+        float* Bs = As + AROWS * LD;
 #pragma unroll
         for (int i = 0; i < NA_PER; ++i)
             if (NA4 % 256 == 0 || alds[i] >= 0) *reinterpret_cast<f32x4*>(As + alds[i]) = ra[i];
+        if (XR > 0 && x_loader) *reinterpret_cast<f32x4*>(As + (BM + (tid >> 2)) * LD + (tid & 3) * 4) = rax;
         f32x4 v0 = {rb[0], rb[1], rb[2], rb[3]}, v1 = {rb[4], rb[5], rb[6], rb[7]};
         *reinterpret_cast<f32x4*>(Bs + bc * LD + bg * 8) = v0;
         *reinterpret_cast<f32x4*>(Bs + bc * LD + bg * 8 + 4) = v1;
@@ -842,13 +855,16 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
     const int lrow = lane >> 5;
     const int lcol = lane & 31;
     const int a_rd = lcol * LD + lrow * 8;
-    const int b_rd = BM * LD + (wid * 32 + lcol) * LD + lrow * 8;
+    const int b_rd = AROWS * LD + (wid * 32 + lcol) * LD + lrow * 8;
 
     f32x16 acc[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float accx[XR > 0 ? XR : 1];
+#pragma unroll
+    for (int j = 0; j < (XR > 0 ? XR : 1); ++j) accx[j] = 0.f;
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         if ((kt + 1) < nk) store_step(cur ^ 1);      // two-deep register -> LDS pipeline
@@ -884,11 +900,26 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][kk], b1[kk], acc[i], 0, 0, 0);
+            if (XR > 0 && has_x) {
+#pragma unroll
+                for (int j = 0; j < XR; ++j) {
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(Tl + (BM + j) * LD + lrow * 8);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(Tl + (BM + j) * LD + lrow * 8 + 4);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) accx[j] = fmaf(x0[kk], b0[kk], accx[j]);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) accx[j] = fmaf(x1[kk], b1[kk], accx[j]);
+                }
+            }
         }
         __syncthreads();
         cur ^= 1;
     }
 
+    if (XR > 0 && has_x) {
+#pragma unroll
+        for (int j = 0; j < XR; ++j) accx[j] += __shfl_xor(accx[j], 32, 64);
+    }
     const int ocol = c0 + wid * 32 + lcol;
     if (ocol >= a.ncol) return;
 #pragma unroll
@@ -898,6 +929,11 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
             const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
             if (m < a.m_end) atomicAdd(a.dw + (size_t)m * a.ncol + ocol, acc[i][r]);
         }
+    }
+    if (XR > 0 && has_x && lrow == 0) {
+#pragma unroll
+        for (int j = 0; j < XR; ++j)
+            if (j < a.xr_count) atomicAdd(a.dw + (size_t)(a.xr_begin + j) * a.ncol + ocol, accx[j]);
     }
 }
 
@@ -911,7 +947,11 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
 // barriers at all: waves are independent and latency is hidden by occupancy.
 // (A chunk-major K order -- all taps of a 16-channel chunk back to back, hoping for L1 hits between the
 // shifted windows -- was measured in round 2 and lost on every shape: profiles/r02_ab_convbench_variants.txt.)
-template <int TM, bool ADIRECT = false, bool BF = false>
+// XR (0 or 4): up to XR extra output rows are carried by the workgroups of block row 0 on the VALU, which
+// idles under the MFMA stream: the lane's eight k values of its pixel (its MFMA operand) meet the extra rows'
+// filter entries read as LDS broadcasts; the two k halves of a pixel meet in one shuffle in the epilogue.
+// 194 output channels then cost 6 row groups instead of 7, 388 cost 12 instead of 13.
+template <int TM, bool ADIRECT = false, bool BF = false, int XR = 0>
 __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
     constexpr int BM = 32 * TM;
     constexpr int BN = 128;
@@ -919,7 +959,8 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
     constexpr int LD = BK + 4;
     constexpr int NA4 = BM * 4;
     constexpr int NA_PER = (NA4 + 255) / 256;
-    constexpr int TILE = BM * LD;
+    constexpr int TILE = (BM + XR) * LD;
+    static_assert(XR == 0 || (!BF && !(ADIRECT && TM == 1)), "extra rows: fp32 LDS form only");
     constexpr bool ALDS = !(ADIRECT && TM == 1);      // row operand through LDS (shared by 4 waves)
     // BF: bf16 inputs (round-to-nearest-even of the fp32 operands) on v_mfma_f32_32x32x16_bf16, fp32
     // accumulation.  One loop iteration then covers 32 k (two 16-channel gathers, two MFMAs per row
@@ -1023,17 +1064,26 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
     }
     const unsigned adir = (m0 + lcol) < a.m_end
         ? (unsigned)(m0 + lcol) * (unsigned)a.Krow * (unsigned)ESZ + lrow * (BF ? 16u : 32u) : OG_OOB;
+    // extra rows (block row 0 only): 4 float4 per row and K step, fetched by the first XR*4 threads
+    const bool has_x = XR > 0 && tile_m == 0 && a.xr_count > 0;
+    const bool x_loader = has_x && tid < XR * 4;
+    const unsigned xvoff = (x_loader && (tid >> 2) < a.xr_count)
+        ? (unsigned)(a.xr_begin + (tid >> 2)) * (unsigned)a.Krow * 4u + (tid & 3) * 16u : OG_OOB;
     f32x4 ra[NA_PER];
+    f32x4 rax = {0.f, 0.f, 0.f, 0.f};
     auto load_a = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < NA_PER; ++i)
             ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, avoff[i], kt * (BK * 4), 0));
+        if (XR > 0 && has_x)
+            rax = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, xvoff, kt * (BK * 4), 0));
     };
     auto store_a = [&](int buf) {
         float* As = lds + buf * TILE;
 #pragma unroll
         for (int i = 0; i < NA_PER; ++i)
             if (NA4 % 256 == 0 || alds[i] >= 0) *reinterpret_cast<f32x4*>(As + alds[i]) = ra[i];
+        if (XR > 0 && x_loader) *reinterpret_cast<f32x4*>(As + (BM + (tid >> 2)) * LD + (tid & 3) * 4) = rax;
     };
 
     const int nk_all = BF ? a.Krow / 32 : a.Kpad / BK;
@@ -1053,6 +1103,9 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     const int a_rd = lcol * LD + lrow * 8;
+    float accx[XR > 0 ? XR : 1];
+#pragma unroll
+    for (int j = 0; j < (XR > 0 ? XR : 1); ++j) accx[j] = 0.f;
     float rb0[NB], rb1[NB];
     f32x4 ad0[2], ad1[2];                              // TM == 1: direct row fragments (ping-pong)
     auto load_adir = [&](f32x4 (&ad)[2], int kt) {
@@ -1103,6 +1156,19 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][kk], rb[4 + kk], acc[i], 0, 0, 0);
+            if (XR > 0 && has_x) {
+                // extra rows on the VALU: filter entries as LDS broadcasts (all lanes of a k half read the
+                // same address), the pixel operand is the MFMA fragment already in registers
+#pragma unroll
+                for (int j = 0; j < XR; ++j) {
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(T + (BM + j) * LD + lrow * 8);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(T + (BM + j) * LD + lrow * 8 + 4);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) accx[j] = fmaf(x0[kk], rb[kk], accx[j]);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) accx[j] = fmaf(x1[kk], rb[4 + kk], accx[j]);
+                }
+            }
         } else {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
@@ -1171,6 +1237,10 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
     if (kt < nk) mma(rb0, ad0, cur);                   // odd step count: last step
 
     // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+    if (XR > 0 && has_x) {
+#pragma unroll
+        for (int j = 0; j < XR; ++j) accx[j] += __shfl_xor(accx[j], 32, 64);      // the two k halves of a pixel
+    }
     if (!pix_ok) return;
     const int ppi = a.PH * a.PW;
     const int n = pix / ppi;
@@ -1200,6 +1270,22 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
             }
         }
     }
+    if (XR > 0 && has_x && lrow == 0) {
+#pragma unroll
+        for (int j = 0; j < XR; ++j) {
+            if (j < a.xr_count) {
+                const int m = a.xr_begin + j;
+                float v = accx[j];
+                if (split) {
+                    atomicAdd(&yb[(size_t)m * plane], v);
+                } else {
+                    if (a.bias) v += a.bias[m];
+                    v = lrelu ? (v > 0.f ? v : 0.2f * v) : (relu ? fmaxf(v, 0.f) : v);
+                    yb[(size_t)m * plane] = v;
+                }
+            }
+        }
+    }
 }
 
 // Weight gradient on the v3 scheme: the gathered-x fragment goes straight to registers (lane =
@@ -1208,7 +1294,7 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
 // B128: on the stride-1 interior fast path the eight consecutive pixels of a lane are fetched as two
 // 16-byte loads (4-byte aligned) instead of eight dwords -- the lanes of a wave sit on different
 // (channel, tap) planes, so every gather instruction touches ~20 cache lines.
-template <int TM, bool BF = false, bool B128 = false>
+template <int TM, bool BF = false, bool B128 = false, int XR = 0>
 __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, const int KS) {
     constexpr int BM = 32 * TM;
     constexpr int BN = 128;
@@ -1216,8 +1302,9 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, con
     constexpr int LD = BK + 4;
     constexpr int NA4 = BM * 4;
     constexpr int NA_PER = (NA4 + 255) / 256;
-    constexpr int TILE = BM * LD;
+    constexpr int TILE = (BM + XR) * LD;
     constexpr bool ALDS = TM > 1;
+    static_assert(XR == 0 || (!BF && TM > 1), "extra rows: fp32 LDS form only");
 
     __shared__ __attribute__((aligned(16))) float lds[ALDS ? 2 * TILE : 4];
 
@@ -1342,18 +1429,26 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, con
         if (rem_ld >= OHW) { rem_ld = 0; n_ld += 1; }
         return so;
     };
+    const bool has_x = XR > 0 && tile_m == 0 && a.xr_count > 0;
+    const bool x_loader = has_x && tid < XR * 4;
+    const unsigned xvoff = (x_loader && (tid >> 2) < a.xr_count)
+        ? ((unsigned)(a.xr_begin + (tid >> 2)) * (unsigned)OHW + (tid & 3) * 4u) * 4u : OG_OOB;
     f32x4 ra[NA_PER];
+    f32x4 rax = {0.f, 0.f, 0.f, 0.f};
     auto load_a = [&]() {
         const int so = a_soff();
 #pragma unroll
         for (int i = 0; i < NA_PER; ++i)
             ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyres, avoff[i], so, 0));
+        if (XR > 0 && has_x)
+            rax = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyres, xvoff, so, 0));
     };
     auto store_a = [&](int buf) {
         float* As = lds + buf * TILE;
 #pragma unroll
         for (int i = 0; i < NA_PER; ++i)
             if (NA4 % 256 == 0 || alds[i] >= 0) *reinterpret_cast<f32x4*>(As + alds[i]) = ra[i];
+        if (XR > 0 && x_loader) *reinterpret_cast<f32x4*>(As + (BM + (tid >> 2)) * LD + (tid & 3) * 4) = rax;
     };
     auto load_adir = [&](f32x4 (&ad)[2]) {
         const int so = a_soff();
@@ -1367,6 +1462,9 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, con
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     const int a_rd = lcol * LD + lrow * 8;
+    float accx[XR > 0 ? XR : 1];
+#pragma unroll
+    for (int j = 0; j < (XR > 0 ? XR : 1); ++j) accx[j] = 0.f;
     float rb0[8], rb1[8];
     f32x4 ad0[2], ad1[2];
     auto mma = [&](const float (&rb)[8], const f32x4 (&ad)[2], int cur) {
@@ -1409,6 +1507,17 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, con
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][kk], rb[4 + kk], acc[i], 0, 0, 0);
+            if (XR > 0 && has_x) {
+#pragma unroll
+                for (int j = 0; j < XR; ++j) {
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(Tl + (BM + j) * LD + lrow * 8);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(Tl + (BM + j) * LD + lrow * 8 + 4);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) accx[j] = fmaf(x0[kk], rb[kk], accx[j]);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) accx[j] = fmaf(x1[kk], rb[4 + kk], accx[j]);
+                }
+            }
         } else {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
@@ -1449,6 +1558,10 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, con
     }
     if (kt < nk) mma(rb0, ad0, cur);
 
+    if (XR > 0 && has_x) {
+#pragma unroll
+        for (int j = 0; j < XR; ++j) accx[j] += __shfl_xor(accx[j], 32, 64);
+    }
     if (!col_ok) return;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -1457,6 +1570,11 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, con
             const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
             if (m < a.m_end) atomicAdd(a.dw + (size_t)m * a.ncol + col, acc[i][r]);
         }
+    }
+    if (XR > 0 && has_x && lrow == 0) {
+#pragma unroll
+        for (int j = 0; j < XR; ++j)
+            if (j < a.xr_count) atomicAdd(a.dw + (size_t)(a.xr_begin + j) * a.ncol + col, accx[j]);
     }
 }
 
@@ -1723,6 +1841,17 @@ static int launch_igemm2(const IgemmArgs& a, int TM, dim3 grid, hipStream_t s) {
         }
         return og_launch_status();
     }
+    if (a.xr_count > 0) {       // extra VALU rows ride with block row 0 (fp32, TM >= 2: see run_igemm2)
+        switch (TM) {
+            case 2: hipLaunchKernelGGL((conv_igemm3_kernel<2, false, false, 4>), grid, dim3(256), 0, s, a); break;
+            case 3: hipLaunchKernelGGL((conv_igemm3_kernel<3, false, false, 4>), grid, dim3(256), 0, s, a); break;
+            case 4: hipLaunchKernelGGL((conv_igemm3_kernel<4, false, false, 4>), grid, dim3(256), 0, s, a); break;
+            case 5: hipLaunchKernelGGL((conv_igemm3_kernel<5, false, false, 4>), grid, dim3(256), 0, s, a); break;
+            case 6: hipLaunchKernelGGL((conv_igemm3_kernel<6, false, false, 4>), grid, dim3(256), 0, s, a); break;
+            default: hipLaunchKernelGGL((conv_igemm3_kernel<7, false, false, 4>), grid, dim3(256), 0, s, a); break;
+        }
+        return og_launch_status();
+    }
     switch (TM) {
         // TM = 1: the LDS-free form reads the filter rows directly, which only pays while the bank is tiny
         case 1: if (a.M <= 32) hipLaunchKernelGGL((conv_igemm3_kernel<1, true>), grid, dim3(256), 0, s, a);
@@ -1741,13 +1870,30 @@ static int launch_igemm2(const IgemmArgs& a, int TM, dim3 grid, hipStream_t s) {
 // Rows are covered by block rows of TM 32-row groups: `brows - 1` (or all) full-height block rows
 // in one launch, plus one launch with a smaller TM for the remaining groups (388 rows = 13 groups
 // -> 7 + 6; 194 -> 7; 768 -> 3 x 8), so that no block computes an empty row group.
+static int og_no_xrows() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OG_NO_XROWS"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v;
+}
+
 static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed) {
-    const int groups = og_cdiv(a.M, 32);
+    int groups = og_cdiv(a.M, 32);
     const int Npix = a.N * a.PH * a.PW;
     const int tiles_n = og_cdiv(Npix, 128);
     const int nph = a.nphase > 1 ? a.nphase : 1;
     int TM, full_rows, rest;                             // block rows of height TM + one of height rest
+    // 1..4 rows beyond a multiple of 32 (194, 388 channels): carried on the VALU by block row 0 instead
+    // of a mostly empty MFMA row group
+    const int tail_rows = a.M & 31;
+    bool xrows = !og_no_xrows() && a.math == 0 && tail_rows >= 1 && tail_rows <= 4 && a.M >= 64;
+    if (xrows) {
+        int tm2, fr2, rs2;
+        og_row_plan(groups - 1, tiles_n * nph, 0, &tm2, &fr2, &rs2);
+        if (tm2 >= 2 && fr2 >= 1) groups -= 1; else xrows = false;
+    }
     og_row_plan(groups, tiles_n * nph, 0, &TM, &full_rows, &rest);
+    a.xr_begin = groups * 32;
+    a.xr_count = 0;
     const int tiles = (full_rows + (rest ? 1 : 0)) * tiles_n;
     const int nk = a.math == 1 ? a.Krow / 32 : a.Kpad / 16;      // loop iterations of the kernel
     const bool full_cover = (a.osh == 1 && a.osw == 1 && a.PH == a.OHf && a.PW == a.OWf);
@@ -1777,15 +1923,17 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed) {
     int rc = OG_OK;
     if (full_rows > 0) {
         a.m_begin = 0; a.m_end = min(a.M, full_rows * TM * 32);
+        a.xr_count = xrows ? tail_rows : 0;
         ProfRec* pr = prof_begin(OG_CAT_IGEMM2(TM),
-                                 2.0 * (a.m_end - a.m_begin) * (double)a.K * (double)Npix * nph, s);
-        prof_meta(pr, 0, TM, a.m_end - a.m_begin, a.C, a.T, a.N, a.PH * nph, a.PW, a.stride * (a.osh > 1 ? -1 : 1), splits);
+                                 2.0 * (a.m_end - a.m_begin + a.xr_count) * (double)a.K * (double)Npix * nph, s);
+        prof_meta(pr, 0, TM, a.m_end - a.m_begin + a.xr_count, a.C, a.T, a.N, a.PH * nph, a.PW, a.stride * (a.osh > 1 ? -1 : 1), splits);
         rc = launch_igemm2(a, TM, dim3(full_rows * tiles_n, splits, nph), s);
         prof_end(pr, s);
         if (rc != OG_OK) return rc;
     }
     if (rest > 0) {
-        a.m_begin = full_rows * TM * 32; a.m_end = a.M;
+        a.m_begin = full_rows * TM * 32; a.m_end = xrows ? groups * 32 : a.M;
+        a.xr_count = 0;
         ProfRec* pr = prof_begin(OG_CAT_IGEMM2(rest),
                                  2.0 * (a.m_end - a.m_begin) * (double)a.K * (double)Npix * nph, s);
         prof_meta(pr, 0, rest, a.m_end - a.m_begin, a.C, a.T, a.N, a.PH * nph, a.PW, a.stride * (a.osh > 1 ? -1 : 1), splits);
@@ -1963,6 +2111,7 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
     a.Cout = Cout; a.OH = OH; a.OW = OW;
     a.stride = stride; a.pad = pad; a.pad_mode = pad_mode; a.upsample = upsample;
     a.ncol = Cin * ksize * ksize;
+    a.xr_begin = 0; a.xr_count = 0;
     const int Npix = N * OH * OW;
 
     const int OHW = OH * OW;
@@ -1971,16 +2120,26 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
     a.math = math;
     if (v2) {
         const bool bf = math == 1;
-        const int groups = og_cdiv(Cout, 32);
+        int groups = og_cdiv(Cout, 32);
         const int tiles_n = og_cdiv(a.ncol, 128);
+        // 1..4 output channels beyond a multiple of 32: on the VALU of block row 0 (see conv_igemm3_kernel)
+        const int tail_rows = Cout & 31;
+        bool xrows = !og_no_xrows() && !bf && tail_rows >= 1 && tail_rows <= 4 && Cout >= 64;
         int TM, full_rows, rest;
+        if (xrows) {
+            og_row_plan(groups - 1, tiles_n, 1, &TM, &full_rows, &rest);
+            if (TM >= 2 && full_rows >= 1) groups -= 1; else xrows = false;
+        }
         og_row_plan(groups, tiles_n, 1, &TM, &full_rows, &rest);
+        a.xr_begin = groups * 32;
         for (int part = 0; part < 2; ++part) {
             const int tm = part == 0 ? TM : rest;
             const int rows = part == 0 ? full_rows : (rest ? 1 : 0);
             if (rows == 0) continue;
+            const int m_cap = xrows ? groups * 32 : Cout;
             a.m_begin = part == 0 ? 0 : full_rows * TM * 32;
-            a.m_end = part == 0 ? (Cout < full_rows * TM * 32 ? Cout : full_rows * TM * 32) : Cout;
+            a.m_end = part == 0 ? (m_cap < full_rows * TM * 32 ? m_cap : full_rows * TM * 32) : m_cap;
+            a.xr_count = (part == 0 && xrows) ? tail_rows : 0;
             // split K (pixels): the launch takes about (workgroups per CU, rounded up) x (K steps per
             // split + a fixed prologue / atomic-epilogue cost); pick the split count that minimises it
             // (r02: `slots / workgroups` left the 288-workgroup launches of the 16x16 maps at 1 split --
@@ -2018,8 +2177,8 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
             const bool b128 = wide_s1 && !og_wgrad_nob128() && !bf;
             const bool use3 = bf ? tm <= 2 : (tm <= og_wgrad3_maxtm() || b128);
             ProfRec* pr = prof_begin(use3 ? OG_CAT_WGRAD3(tm) : OG_CAT_WGRAD2(tm),
-                                     2.0 * (a.m_end - a.m_begin) * (double)a.ncol * (double)Npix, s);
-            prof_meta(pr, 1, tm, a.m_end - a.m_begin, Cin, ksize * ksize, N, OH, OW,
+                                     2.0 * (a.m_end - a.m_begin + a.xr_count) * (double)a.ncol * (double)Npix, s);
+            prof_meta(pr, 1, tm, a.m_end - a.m_begin + a.xr_count, Cin, ksize * ksize, N, OH, OW,
                       stride * (upsample ? 10 : 1) * (pad_mode ? -1 : 1), splits);
             // LDS-free register-fragment form for short tiles, LDS-staged form for tall ones
             // register-fragment form for short tiles, LDS-staged form for tall ones (measured equal or
@@ -2028,11 +2187,24 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
             // maps without upsampling (r02 A/B: res1_128 100 -> 107 TF, shp_512 33 -> 37), the LDS-staged
             // kernel (wgrad2) elsewhere: narrow maps spend half of their spans on the border path, the
             // up-sampling gather keeps its per-element address math.
+#define OG_WG2X(TMv) if (use3 && b128) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, false, true, 4>), grid, dim3(256), 0, s, a, ksize); \
+                     else if (use3) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, false, false, 4>), grid, dim3(256), 0, s, a, ksize); \
+                     else hipLaunchKernelGGL((conv_wgrad2_kernel<TMv, false, 4>), grid, dim3(256), 0, s, a, ksize);
 #define OG_WG2(TMv) if (bf && TMv <= 2) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, true>), grid, dim3(256), 0, s, a, ksize); \
                     else if (bf) hipLaunchKernelGGL((conv_wgrad2_kernel<TMv, true>), grid, dim3(256), 0, s, a, ksize); \
                     else if (use3 && b128) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, false, true>), grid, dim3(256), 0, s, a, ksize); \
                     else if (use3) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv>), grid, dim3(256), 0, s, a, ksize); \
                     else hipLaunchKernelGGL((conv_wgrad2_kernel<TMv>), grid, dim3(256), 0, s, a, ksize);
+            if (a.xr_count > 0) {
+                switch (tm) {
+                    case 2: OG_WG2X(2) break;
+                    case 3: OG_WG2X(3) break;
+                    case 4: OG_WG2X(4) break;
+                    case 5: OG_WG2X(5) break;
+                    case 6: OG_WG2X(6) break;
+                    default: OG_WG2X(7) break;
+                }
+            } else {
             switch (tm) {
                 case 1: OG_WG2(1) break;
                 case 2: OG_WG2(2) break;
@@ -2042,7 +2214,9 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
                 case 6: OG_WG2(6) break;
                 default: OG_WG2(7) break;
             }
+            }
 #undef OG_WG2
+#undef OG_WG2X
             prof_end(pr, s);
             int rc = og_launch_status();
             if (rc != OG_OK) return rc;
