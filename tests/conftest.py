@@ -14,6 +14,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _bounded_cpu_threads():
+    """The CPU oracle runs on the host cores of whatever box executes the tests (8 here, 256 on the GPU
+    box).  Hundreds of threads make the many small fp64 GEMMs of an Inception pass crawl (fork-join cost per
+    call), so every test starts from a moderate pool; the full-batch oracle step raises it for itself."""
+    import torch
+    n = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(n)
+    yield
+    torch.set_num_threads(n)
+
+
 @pytest.fixture(scope="session")
 def dev():
     import torch

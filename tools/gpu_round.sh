@@ -8,9 +8,9 @@ TAG=${1:-run}; shift
 R=$GRAFT_REPO_ROOT
 for what in "$@"; do case $what in
 test) rm -f gpurun_out/parity_numbers.txt
-  ( time timeout 1500 python -m pytest tests -m gpu -x -q --durations=40 ) > gpurun_out/${TAG}_pytest.log 2>&1; tail -5 gpurun_out/${TAG}_pytest.log
+  ( time timeout 1500 python -m pytest tests -m gpu -x -v --timeout=420 --durations=40 ) > gpurun_out/${TAG}_pytest.log 2>&1; tail -5 gpurun_out/${TAG}_pytest.log
   cp gpurun_out/parity_numbers.txt gpurun_out/${TAG}_parity.txt 2>/dev/null ;;
-testk) ( time timeout 900 python -m pytest tests -m gpu -x -q --durations=10 -k "$OG_K" ) > gpurun_out/${TAG}_pytestk.log 2>&1; tail -15 gpurun_out/${TAG}_pytestk.log ;;
+testk) ( time timeout 900 python -m pytest tests -m gpu -x -v --timeout=240 --durations=10 -k "$OG_K" ) > gpurun_out/${TAG}_pytestk.log 2>&1; tail -15 gpurun_out/${TAG}_pytestk.log ;;
 convbench) ( timeout 300 tools/conv_bench "" 5 ) > gpurun_out/${TAG}_convbench.log 2>&1; cat gpurun_out/${TAG}_convbench.log ;;
 bench) ( time timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --shape-table gpurun_out/${TAG}_shapes.txt ) > gpurun_out/${TAG}_bench.log 2>&1; tail -3 gpurun_out/${TAG}_bench.log ;;
 benchfull) ( time timeout 900 python bench.py --steps 20 --warmup 5 ) > gpurun_out/${TAG}_benchfull.log 2>&1; tail -3 gpurun_out/${TAG}_benchfull.log ;;
