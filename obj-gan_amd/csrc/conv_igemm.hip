@@ -67,8 +67,6 @@ struct IgemmArgs {
     int ksplit_steps;    // > 0: split-K -- blockIdx.y owns this many BK steps, epilogue = atomicAdd
     int nphase;          // > 1 (v2 kernel only): blockIdx.z = output phase p with its own tap table
                          // tap[p*8 ..], packed bank wt + p*M*Kpad and output offset (ooh, oow) = (p>>1, p&1)
-    int xr_begin, xr_count;   // XR kernels: rows [xr_begin, xr_begin + xr_count) (<= 4) ride along with block
-                              // row 0 on the fp32 VALU instead of costing a 32-row MFMA group (194 = 6*32 + 2)
     int tap[OG_MAX_TAPS];   // (dw << 16) | (dh & 0xffff): one scalar load per (uniform) tap
 };
 
@@ -562,7 +560,11 @@ struct WgradArgs {
     int ncol;
     int pix_per_split;
     int math;          // 0 fp32, 1 bf16 inputs
-    int xr_begin, xr_count;   // XR kernels: dy rows [xr_begin, xr_begin + xr_count) (<= 4) on the VALU (block row 0)
+    int xr_begin, xr_count;   // XR kernels: dy rows [xr_begin, xr_begin + xr_count) (<= 4) are carried by block row 0 on
+                              // the fp32 VALU instead of costing a 32-row MFMA group (194 = 6*32 + 2, 388 = 12*32 + 4):
+                              // the lane's eight gathered values (its MFMA operand) meet the extra rows' dy values read
+                              // as LDS broadcasts; the two pixel halves of a column meet in one shuffle in the epilogue.
+                              // r02: -8 % on the 194 / 388-channel weight gradients at 128^2, -20 % at 32^2.
 };
 
 template <int KS, int WM, int TM>
@@ -726,7 +728,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
     constexpr int LD = BK + 4;
     constexpr int NA4 = BM * 4;
     constexpr int NA_PER = (NA4 + 255) / 256;
-    constexpr int AROWS = BM + XR;                     // dy rows in LDS (XR extra rows, see conv_igemm3_kernel)
+    constexpr int AROWS = BM + XR;                     // dy rows in LDS (XR extra rows, see WgradArgs)
     constexpr int TILE = (AROWS + BN) * LD;
     static_assert(XR == 0 || !BF, "extra rows: fp32 only");
 
@@ -947,11 +949,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
 // barriers at all: waves are independent and latency is hidden by occupancy.
 // (A chunk-major K order -- all taps of a 16-channel chunk back to back, hoping for L1 hits between the
 // shifted windows -- was measured in round 2 and lost on every shape: profiles/r02_ab_convbench_variants.txt.)
-// XR (0 or 4): up to XR extra output rows are carried by the workgroups of block row 0 on the VALU, which
-// idles under the MFMA stream: the lane's eight k values of its pixel (its MFMA operand) meet the extra rows'
-// filter entries read as LDS broadcasts; the two k halves of a pixel meet in one shuffle in the epilogue.
-// 194 output channels then cost 6 row groups instead of 7, 388 cost 12 instead of 13.
-template <int TM, bool ADIRECT = false, bool BF = false, int XR = 0>
+template <int TM, bool ADIRECT = false, bool BF = false>
 __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
     constexpr int BM = 32 * TM;
     constexpr int BN = 128;
@@ -959,8 +957,7 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
     constexpr int LD = BK + 4;
     constexpr int NA4 = BM * 4;
     constexpr int NA_PER = (NA4 + 255) / 256;
-    constexpr int TILE = (BM + XR) * LD;
-    static_assert(XR == 0 || (!BF && !(ADIRECT && TM == 1)), "extra rows: fp32 LDS form only");
+    constexpr int TILE = BM * LD;
     constexpr bool ALDS = !(ADIRECT && TM == 1);      // row operand through LDS (shared by 4 waves)
     // BF: bf16 inputs (round-to-nearest-even of the fp32 operands) on v_mfma_f32_32x32x16_bf16, fp32
     // accumulation.  One loop iteration then covers 32 k (two 16-channel gathers, two MFMAs per row
@@ -1064,26 +1061,17 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
     }
     const unsigned adir = (m0 + lcol) < a.m_end
         ? (unsigned)(m0 + lcol) * (unsigned)a.Krow * (unsigned)ESZ + lrow * (BF ? 16u : 32u) : OG_OOB;
-    // extra rows (block row 0 only): 4 float4 per row and K step, fetched by the first XR*4 threads
-    const bool has_x = XR > 0 && tile_m == 0 && a.xr_count > 0;
-    const bool x_loader = has_x && tid < XR * 4;
-    const unsigned xvoff = (x_loader && (tid >> 2) < a.xr_count)
-        ? (unsigned)(a.xr_begin + (tid >> 2)) * (unsigned)a.Krow * 4u + (tid & 3) * 16u : OG_OOB;
     f32x4 ra[NA_PER];
-    f32x4 rax = {0.f, 0.f, 0.f, 0.f};
     auto load_a = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < NA_PER; ++i)
             ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, avoff[i], kt * (BK * 4), 0));
-        if (XR > 0 && has_x)
-            rax = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, xvoff, kt * (BK * 4), 0));
     };
     auto store_a = [&](int buf) {
         float* As = lds + buf * TILE;
 #pragma unroll
         for (int i = 0; i < NA_PER; ++i)
             if (NA4 % 256 == 0 || alds[i] >= 0) *reinterpret_cast<f32x4*>(As + alds[i]) = ra[i];
-        if (XR > 0 && x_loader) *reinterpret_cast<f32x4*>(As + (BM + (tid >> 2)) * LD + (tid & 3) * 4) = rax;
     };
 
     const int nk_all = BF ? a.Krow / 32 : a.Kpad / BK;
@@ -1103,9 +1091,6 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     const int a_rd = lcol * LD + lrow * 8;
-    float accx[XR > 0 ? XR : 1];
-#pragma unroll
-    for (int j = 0; j < (XR > 0 ? XR : 1); ++j) accx[j] = 0.f;
     float rb0[NB], rb1[NB];
     f32x4 ad0[2], ad1[2];                              // TM == 1: direct row fragments (ping-pong)
     auto load_adir = [&](f32x4 (&ad)[2], int kt) {
@@ -1156,19 +1141,6 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][kk], rb[4 + kk], acc[i], 0, 0, 0);
-            if (XR > 0 && has_x) {
-                // extra rows on the VALU: filter entries as LDS broadcasts (all lanes of a k half read the
-                // same address), the pixel operand is the MFMA fragment already in registers
-#pragma unroll
-                for (int j = 0; j < XR; ++j) {
-                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(T + (BM + j) * LD + lrow * 8);
-                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(T + (BM + j) * LD + lrow * 8 + 4);
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) accx[j] = fmaf(x0[kk], rb[kk], accx[j]);
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) accx[j] = fmaf(x1[kk], rb[4 + kk], accx[j]);
-                }
-            }
         } else {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
@@ -1237,10 +1209,6 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
     if (kt < nk) mma(rb0, ad0, cur);                   // odd step count: last step
 
     // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
-    if (XR > 0 && has_x) {
-#pragma unroll
-        for (int j = 0; j < XR; ++j) accx[j] += __shfl_xor(accx[j], 32, 64);      // the two k halves of a pixel
-    }
     if (!pix_ok) return;
     const int ppi = a.PH * a.PW;
     const int n = pix / ppi;
@@ -1260,22 +1228,6 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
             const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
             if (m < a.m_end) {
                 float v = acc[i][r];
-                if (split) {
-                    atomicAdd(&yb[(size_t)m * plane], v);
-                } else {
-                    if (a.bias) v += a.bias[m];
-                    v = lrelu ? (v > 0.f ? v : 0.2f * v) : (relu ? fmaxf(v, 0.f) : v);
-                    yb[(size_t)m * plane] = v;
-                }
-            }
-        }
-    }
-    if (XR > 0 && has_x && lrow == 0) {
-#pragma unroll
-        for (int j = 0; j < XR; ++j) {
-            if (j < a.xr_count) {
-                const int m = a.xr_begin + j;
-                float v = accx[j];
                 if (split) {
                     atomicAdd(&yb[(size_t)m * plane], v);
                 } else {
@@ -1841,17 +1793,6 @@ static int launch_igemm2(const IgemmArgs& a, int TM, dim3 grid, hipStream_t s) {
         }
         return og_launch_status();
     }
-    if (a.xr_count > 0) {       // extra VALU rows ride with block row 0 (fp32, TM >= 2: see run_igemm2)
-        switch (TM) {
-            case 2: hipLaunchKernelGGL((conv_igemm3_kernel<2, false, false, 4>), grid, dim3(256), 0, s, a); break;
-            case 3: hipLaunchKernelGGL((conv_igemm3_kernel<3, false, false, 4>), grid, dim3(256), 0, s, a); break;
-            case 4: hipLaunchKernelGGL((conv_igemm3_kernel<4, false, false, 4>), grid, dim3(256), 0, s, a); break;
-            case 5: hipLaunchKernelGGL((conv_igemm3_kernel<5, false, false, 4>), grid, dim3(256), 0, s, a); break;
-            case 6: hipLaunchKernelGGL((conv_igemm3_kernel<6, false, false, 4>), grid, dim3(256), 0, s, a); break;
-            default: hipLaunchKernelGGL((conv_igemm3_kernel<7, false, false, 4>), grid, dim3(256), 0, s, a); break;
-        }
-        return og_launch_status();
-    }
     switch (TM) {
         // TM = 1: the LDS-free form reads the filter rows directly, which only pays while the bank is tiny
         case 1: if (a.M <= 32) hipLaunchKernelGGL((conv_igemm3_kernel<1, true>), grid, dim3(256), 0, s, a);
@@ -1877,23 +1818,15 @@ static int og_no_xrows() {
 }
 
 static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed) {
-    int groups = og_cdiv(a.M, 32);
+    const int groups = og_cdiv(a.M, 32);
     const int Npix = a.N * a.PH * a.PW;
     const int tiles_n = og_cdiv(Npix, 128);
     const int nph = a.nphase > 1 ? a.nphase : 1;
     int TM, full_rows, rest;                             // block rows of height TM + one of height rest
-    // 1..4 rows beyond a multiple of 32 (194, 388 channels): carried on the VALU by block row 0 instead
-    // of a mostly empty MFMA row group
-    const int tail_rows = a.M & 31;
-    bool xrows = !og_no_xrows() && a.math == 0 && tail_rows >= 1 && tail_rows <= 4 && a.M >= 64;
-    if (xrows) {
-        int tm2, fr2, rs2;
-        og_row_plan(groups - 1, tiles_n * nph, 0, &tm2, &fr2, &rs2);
-        if (tm2 >= 2 && fr2 >= 1) groups -= 1; else xrows = false;
-    }
+    // (Carrying the 2 / 4 rows that 194 / 388 channels have beyond a multiple of 32 on the VALU next to the
+    // MFMA stream -- as the weight-gradient kernels do -- was measured here in round 2 and bought nothing:
+    // 106.0 vs 107.8 TFLOP/s on res1_128; interleaving the FMAs with the MFMAs cost 20 %.)
     og_row_plan(groups, tiles_n * nph, 0, &TM, &full_rows, &rest);
-    a.xr_begin = groups * 32;
-    a.xr_count = 0;
     const int tiles = (full_rows + (rest ? 1 : 0)) * tiles_n;
     const int nk = a.math == 1 ? a.Krow / 32 : a.Kpad / 16;      // loop iterations of the kernel
     const bool full_cover = (a.osh == 1 && a.osw == 1 && a.PH == a.OHf && a.PW == a.OWf);
@@ -1923,17 +1856,15 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed) {
     int rc = OG_OK;
     if (full_rows > 0) {
         a.m_begin = 0; a.m_end = min(a.M, full_rows * TM * 32);
-        a.xr_count = xrows ? tail_rows : 0;
         ProfRec* pr = prof_begin(OG_CAT_IGEMM2(TM),
-                                 2.0 * (a.m_end - a.m_begin + a.xr_count) * (double)a.K * (double)Npix * nph, s);
-        prof_meta(pr, 0, TM, a.m_end - a.m_begin + a.xr_count, a.C, a.T, a.N, a.PH * nph, a.PW, a.stride * (a.osh > 1 ? -1 : 1), splits);
+                                 2.0 * (a.m_end - a.m_begin) * (double)a.K * (double)Npix * nph, s);
+        prof_meta(pr, 0, TM, a.m_end - a.m_begin, a.C, a.T, a.N, a.PH * nph, a.PW, a.stride * (a.osh > 1 ? -1 : 1), splits);
         rc = launch_igemm2(a, TM, dim3(full_rows * tiles_n, splits, nph), s);
         prof_end(pr, s);
         if (rc != OG_OK) return rc;
     }
     if (rest > 0) {
-        a.m_begin = full_rows * TM * 32; a.m_end = xrows ? groups * 32 : a.M;
-        a.xr_count = 0;
+        a.m_begin = full_rows * TM * 32; a.m_end = a.M;
         ProfRec* pr = prof_begin(OG_CAT_IGEMM2(rest),
                                  2.0 * (a.m_end - a.m_begin) * (double)a.K * (double)Npix * nph, s);
         prof_meta(pr, 0, rest, a.m_end - a.m_begin, a.C, a.T, a.N, a.PH * nph, a.PW, a.stride * (a.osh > 1 ? -1 : 1), splits);
@@ -2122,7 +2053,7 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
         const bool bf = math == 1;
         int groups = og_cdiv(Cout, 32);
         const int tiles_n = og_cdiv(a.ncol, 128);
-        // 1..4 output channels beyond a multiple of 32: on the VALU of block row 0 (see conv_igemm3_kernel)
+        // 1..4 output channels beyond a multiple of 32: on the VALU of block row 0 (see WgradArgs)
         const int tail_rows = Cout & 31;
         bool xrows = !og_no_xrows() && !bf && tail_rows >= 1 && tail_rows <= 4 && Cout >= 64;
         int TM, full_rows, rest;
