@@ -146,6 +146,29 @@ int objgan_bilinear_backward(const float* dy, float* dx, long planes, int ih, in
                              void* stream);
 int objgan_sum2x2(const float* dy, float* dx, long planes, int h, int w, void* stream);
 int objgan_reflect_fold(const float* dxp, float* dx, long planes, int h, int w, void* stream);
+/* Data gradient of the discriminators' first layer (Conv2d(3 + ngf, ndf, 4, 2, 1), reference
+ * image_generation/model.py:989-1003) down to its <= 16 input channels: dX [N, Cin, 2*OH, 2*OW] from
+ * dY [N, Cout, OH, OW], all four output-parity phases in one pass over dY.  wt: (Cout + 1) * 256 floats. */
+int objgan_conv_dgrad_s2k4_thin(const float* dy, const float* w, float* dx, float* wt, int N, int Cout, int OH,
+                                int OW, int Cin, int wt_packed, void* stream);
+/* Batched re-packing of cached filter banks.  A job is an opaque blob (objgan_conv_pack_job_bytes() bytes) that
+ * says "pack w into wt exactly as objgan_conv_igemm -- or phase `phase` of objgan_conv_dgrad_s2_phases --
+ * does for these arguments"; a caller that keeps packed banks (wt_packed = 1) stores the blobs of a network
+ * back to back in device memory and refreshes all of them with ONE launch after an optimizer step (the
+ * per-use re-pack was 499 launches per training step).  Replaces nothing in the reference: cuDNN transforms
+ * filters internally. */
+int objgan_conv_pack_job_bytes();
+int objgan_conv_pack_job(void* job, const float* w, float* wt, int N, int C, int H, int W, int Cout, int Cin,
+                         int Torig, int transpose, int Tg, const int* src_tap, int PH, int PW, int act, int math);
+int objgan_conv_pack_job_phase(void* job, const float* w, float* wt, int Cout, int Cin, int Torig, int Tg,
+                               const int* src_tap_phase, int phase, int math);
+int objgan_conv_pack_jobs_run(const void* jobs_dev, int njobs, void* stream);
+/* Batched small matrix product C[b] = A[b] . B[b] with arbitrary element strides (transposes are free): the
+ * per-image region-context products of the DAMSM word loss (reference GlobalAttention.py:62-68 inside the
+ * caption loop of losses.py:87-127: B torch.bmm calls) in one launch, likewise both of its gradients. */
+int objgan_bmm_strided(const float* A, const float* B, float* C, int batch, int M, int N, int K,
+                       long sab, long sam, long sak, long sbb, long sbk, long sbn,
+                       long scb, long scm, long scn, void* stream);
 /* Layout-map stem of the object discriminators without the 512x512 lift (reference
  * image_generation/model.py:1217-1226: shp_code(F.interpolate(seg, 512, bilinear, align_corners))).  The channel
  * contraction runs at low resolution (a 1x1 convolution C -> 9*Mo through objgan_conv_igemm); these two entry

@@ -380,6 +380,72 @@ __global__ __launch_bounds__(256) void softmax_strided_bwd_kernel(
     }
 }
 
+// ---- small batched matrix product with arbitrary strides ---------------------------------------------
+//   C[b][m][n] = sum_k A[b][m][k] * B[b][k][n]
+// The DAMSM word loss forms, per image b, the region-context of every word of every caption:
+// weightedContext[b] = context[b] (nef x 289) . attn[b]^T (289 x B*L) (reference GlobalAttention.py:62-68,
+// losses.py:108-112) -- B tiny products that the reference issues as B bmm calls inside a python loop.  One
+// launch serves the whole batch and, through the strides, both gradients (dA = dC B^T, dB = A^T dC).
+// fp32 VALU, 64 x 64 tile, 16-deep K chunks through LDS; the products total < 1 GFLOP per step.
+struct BmmArgs {
+    const float* A; const float* B; float* C;
+    int M, N, K;
+    long sab, sam, sak;     // strides of A: batch, m, k
+    long sbb, sbk, sbn;     // strides of B: batch, k, n
+    long scb, scm, scn;     // strides of C
+};
+
+__global__ __launch_bounds__(256) void bmm_strided_kernel(const BmmArgs a) {
+    __shared__ float As[16][64 + 1];
+    __shared__ float Bs[16][64 + 1];
+    const int b = blockIdx.z;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    const int tm = (tid >> 4) * 4, tn = (tid & 15) * 4;      // this thread's 4 x 4 outputs
+    const float* Ab = a.A + (long)b * a.sab;
+    const float* Bb = a.B + (long)b * a.sbb;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int k0 = 0; k0 < a.K; k0 += 16) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = tid + 256 * r;                      // 1024 elements per operand tile
+            // A tile: consecutive threads along whichever of (m, k) is contiguous in memory
+            int mm, kk;
+            if (a.sak <= a.sam) { kk = e & 15; mm = e >> 4; } else { mm = e & 63; kk = e >> 6; }
+            const int gm = m0 + mm, gk = k0 + kk;
+            As[kk][mm] = (gm < a.M && gk < a.K) ? Ab[(long)gm * a.sam + (long)gk * a.sak] : 0.f;
+            int nn, k2;
+            if (a.sbn <= a.sbk) { nn = e & 63; k2 = e >> 6; } else { k2 = e & 15; nn = e >> 4; }
+            const int gn = n0 + nn, gk2 = k0 + k2;
+            Bs[k2][nn] = (gn < a.N && gk2 < a.K) ? Bb[(long)gk2 * a.sbk + (long)gn * a.sbn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { av[i] = As[kk][tm + i]; bv[i] = Bs[kk][tn + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    float* Cb = a.C + (long)b * a.scb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gm = m0 + tm + i, gn = n0 + tn + j;
+            if (gm < a.M && gn < a.N) Cb[(long)gm * a.scm + (long)gn * a.scn] = acc[i][j];
+        }
+}
+
 extern "C" {
 
 int objgan_attn_general_forward(const float* x, const float* src, const unsigned char* mask,
@@ -488,6 +554,19 @@ int objgan_softmax_strided_backward(const float* y, const float* dy, float* dx, 
     if (total <= 0 || dim <= 0) return OG_OK;
     hipLaunchKernelGGL(softmax_strided_bwd_kernel, dim3(og_stream_grid(total, 256)), dim3(256), 0,
                        (hipStream_t)stream, y, dy, dx, outer, dim, inner, scale);
+    return og_launch_status();
+}
+
+// C[b] = A[b] . B[b] for `batch` small matrices with arbitrary (element) strides; C is overwritten.
+int objgan_bmm_strided(const float* A, const float* B, float* C, int batch, int M, int N, int K,
+                       long sab, long sam, long sak, long sbb, long sbk, long sbn,
+                       long scb, long scm, long scn, void* stream) {
+    OG_ENTRY();
+    if (batch <= 0 || M <= 0 || N <= 0) return OG_OK;
+    if (K < 0 || batch > 65535) return OG_BAD_ARGS;
+    BmmArgs a = {A, B, C, M, N, K, sab, sam, sak, sbb, sbk, sbn, scb, scm, scn};
+    dim3 grid(og_cdiv(N, 64), og_cdiv(M, 64), batch);
+    hipLaunchKernelGGL(bmm_strided_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     return og_launch_status();
 }
 

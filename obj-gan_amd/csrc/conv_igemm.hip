@@ -33,6 +33,7 @@
 #include "common.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -482,6 +483,93 @@ __global__ __launch_bounds__(256) void conv_thin3x3_kernel(const IgemmArgs a) {
     }
 }
 
+
+// Data gradient of the discriminators' FIRST layer (4x4, stride 2, pad 1, reference model.py:989-1003) down
+// to its 3 / 15-channel input (image [+ 12-channel layout code]): all four output-parity phases in one
+// pass.  dx[2a+pa][2b+pb] reads the 2x2 of the 3x3 window dy[a-1..a+1][b-1..b+1] that parity (pa, pb)
+// selects: one thread = one (a, b), the window of a channel is loaded ONCE (9 coalesced dwords) and feeds the
+// 4 x 4 x MT FMAs of all phases -- the four per-phase launches of the generic thin kernel read dy four times
+// (1.6 GB per call at 256^2: HBM-bound at 65 TFLOP/s) and ran at half the FMA-per-load ratio.  Bank:
+// wt[co][kh*4 + kw][MT] (the thin layout with 16 taps), through the scalar cache.
+template <int MT>
+__global__ __launch_bounds__(256) void conv_thin_dgrad_s2k4_kernel(const float* __restrict__ dy,
+                                                                   const float* __restrict__ wt,
+                                                                   float* __restrict__ dx, int N, int C, int OH,
+                                                                   int OW, int M) {
+    const int OHW = OH * OW;
+    const long total = (long)N * OHW;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool t_ok = gid < total;
+    const long g = t_ok ? gid : 0;
+    const int n = (int)(g / OHW);
+    const int rem = (int)(g - (long)n * OHW);
+    const int pa_ = rem / OW, pb_ = rem - pa_ * OW;       // (a, b)
+    __amdgpu_buffer_rsrc_t res = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)dy, 0, (int)((unsigned)N * C * OHW * 4u), OG_BUF_FLAGS);
+    const unsigned img_off = (unsigned)n * (unsigned)C * (unsigned)OHW;
+    unsigned voff[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int oh = pa_ + r - 1, ow = pb_ + c - 1;
+            const bool ok = t_ok && (unsigned)oh < (unsigned)OH && (unsigned)ow < (unsigned)OW;
+            voff[r][c] = ok ? (img_off + (unsigned)(oh * OW + ow)) * 4u : OG_OOB;
+        }
+    float acc[4][MT];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[p][m] = 0.f;
+    auto load_win = [&](float (&xv)[3][3], int co) {
+        const int so = min(co, C - 1) * OHW * 4;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                xv[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(res, voff[r][c], so, 0));
+    };
+    // parity 0 pairs (tap k, window index): (1, 1), (3, 0); parity 1: (0, 2), (2, 1)
+    auto fma_win = [&](const float (&xv)[3][3], int co) {
+        const float* __restrict__ wc = wt + (size_t)co * (16 * MT);
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int kh = pa ? 2 * i : 1 + 2 * i, r = pa ? 2 - i : 1 - i;
+                        const int kw = pb ? 2 * j : 1 + 2 * j, c = pb ? 2 - j : 1 - j;
+                        const float v = xv[r][c];
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            acc[pa * 2 + pb][m] = fmaf(wc[(kh * 4 + kw) * MT + m], v, acc[pa * 2 + pb][m]);
+                    }
+    };
+    float xa[3][3], xb[3][3];
+    load_win(xa, 0);
+    for (int co = 0; co < C; co += 2) {           // the bank carries one zero channel: odd C needs no branch
+        load_win(xb, co + 1);
+        fma_win(xa, co);
+        load_win(xa, co + 2);
+        fma_win(xb, co + 1);
+    }
+    if (!t_ok) return;
+    const int LW = 2 * OW;
+    const size_t plane = (size_t)4 * OHW;
+    float* base = dx + (size_t)n * M * plane + (size_t)(2 * pa_) * LW + 2 * pb_;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (m < M) {
+            float* o = base + (size_t)m * plane;
+            *reinterpret_cast<float2*>(o) = make_float2(acc[0][m], acc[1][m]);
+            *reinterpret_cast<float2*>(o + LW) = make_float2(acc[2][m], acc[3][m]);
+        }
+    }
+}
+
 // ---- weight packing ------------------------------------------------------------------
 // wt[(t*Cp + ck) * Mpad + cm] = src_tap[t] >= 0 ? w[...] : 0, zero padded to [T*Cp][Mpad].
 // w is the PyTorch conv weight [Cout][Cin][Torig].  transpose = 0: cm = cout, ck = cin
@@ -505,6 +593,45 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
                                       : (a.m_major ? (long)a.M * Krow : (long)Kpad * a.Mpad);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long)gridDim.x * blockDim.x) {
+        int m, t, ck;
+        bool pad = false;
+        if (a.m_major == 2) {
+            m = (int)(i % a.Mpad);
+            const int r = (int)(i / a.Mpad);
+            t = r % a.Tg;
+            ck = r / a.Tg;
+        } else {
+            m = a.m_major ? (int)(i / Krow) : (int)(i % a.Mpad);
+            const int k = a.m_major ? (int)(i % Krow) : (int)(i / a.Mpad);
+            pad = k >= Kpad;
+            t = pad ? 0 : k / a.Cp;
+            ck = k - t * a.Cp;
+        }
+        float v = 0.f;
+        if (!pad && m < a.M && ck < a.Ck) {
+            const int st = a.src_tap[t];
+            if (st >= 0) {
+                const int co = a.transpose ? ck : m;
+                const int ci = a.transpose ? m : ck;
+                v = a.w[((size_t)co * a.Cin + ci) * a.Torig + st];
+            }
+        }
+        if (a.m_major == 3) reinterpret_cast<__bf16*>(a.wt)[i] = (__bf16)v;
+        else a.wt[i] = v;
+    }
+}
+
+// Many banks in one launch: blockIdx.y = job.  After an optimizer step every cached bank of the updated
+// network is stale at once -- ~60 banks per network, 499 7-us launches per training step when each is
+// re-packed at its next use; the host keeps the jobs of a network in a device table instead and refreshes
+// them right behind the Adam kernel (objgan_conv_pack_jobs_run).
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackArgs* __restrict__ jobs) {
+    const PackArgs a = jobs[blockIdx.y];
+    const int Kpad = a.Tg * a.Cp;
+    const int Krow = a.m_major == 3 ? (Kpad + 31) / 32 * 32 : Kpad;
+    const long total = a.m_major == 2 ? (long)(a.Ck + 1) * a.Tg * a.Mpad
+                                      : (a.m_major ? (long)a.M * Krow : (long)Kpad * a.Mpad);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int m, t, ck;
         bool pad = false;
         if (a.m_major == 2) {
@@ -1898,7 +2025,75 @@ static int og_bank_layout(int N, int C, int H, int W, int M, int Tg, int PH, int
     return math == 1 ? 3 : 1;
 }
 
+// The PackArgs of objgan_conv_igemm for these arguments (single source of truth for the call itself and for
+// objgan_conv_pack_job); returns the bank layout class, MT_out as og_bank_layout.
+static int og_fill_pack(PackArgs& p, const float* w, float* wt, int N, int C, int H, int W, int Cout, int Cin,
+                        int Torig, int transpose, int Tg, const int* src_tap, int PH, int PW, int act, int math,
+                        int* MT_out) {
+    const int M = transpose ? Cin : Cout;
+    p.w = w; p.wt = wt; p.Cout = Cout; p.Cin = Cin; p.Torig = Torig; p.Tg = Tg;
+    p.M = M; p.Mpad = (M + 127) / 128 * 128; p.Ck = C; p.Cp = (C + 15) / 16 * 16;
+    p.transpose = transpose;
+    int MT = 32;
+    p.m_major = og_bank_layout(N, C, H, W, M, Tg, PH, PW, act, math, &MT);
+    if (p.m_major == 2) p.Mpad = MT;
+    for (int t = 0; t < OG_MAX_TAPS; ++t) p.src_tap[t] = (signed char)(t < Tg ? src_tap[t] : -1);
+    if (MT_out) *MT_out = MT;
+    return p.m_major;
+}
+
+static void og_fill_pack_phase(PackArgs& p, const float* w, float* wt, int Cout, int Cin, int Torig, int Tg,
+                               const int* src_tap_phase, int phase, int math) {
+    const int M = Cin, C = Cout;
+    const int Cp = (C + 15) / 16 * 16;
+    const int Kpad = Tg * Cp;
+    const int Krow = math == 1 ? (Kpad + 31) / 32 * 32 : Kpad;
+    const long bank = math == 1 ? (long)M * Krow / 2 : (long)M * Krow;
+    p.w = w; p.wt = wt + phase * bank; p.Cout = Cout; p.Cin = Cin; p.Torig = Torig; p.Tg = Tg;
+    p.M = M; p.Mpad = (M + 127) / 128 * 128; p.Ck = C; p.Cp = Cp;
+    p.transpose = 1; p.m_major = math == 1 ? 3 : 1;
+    for (int t = 0; t < OG_MAX_TAPS; ++t) p.src_tap[t] = (signed char)(t < Tg ? src_tap_phase[t] : -1);
+}
+
 extern "C" {
+
+// ---- batched re-packing of cached filter banks ---------------------------------------------------
+// A job is an opaque blob of objgan_conv_pack_job_bytes() bytes describing "pack w into wt exactly as
+// objgan_conv_igemm (or phase `phase` of objgan_conv_dgrad_s2_phases) would for these arguments".  The
+// caller keeps the blobs of all banks it caches for a network back to back in DEVICE memory and refreshes
+// them with one launch after the network's weights changed.
+int objgan_conv_pack_job_bytes() { return (int)sizeof(PackArgs); }
+
+int objgan_conv_pack_job(void* job, const float* w, float* wt, int N, int C, int H, int W, int Cout, int Cin,
+                         int Torig, int transpose, int Tg, const int* src_tap, int PH, int PW, int act, int math) {
+    if (!job || Tg < 1 || Tg > OG_MAX_TAPS || Torig < 1 || Torig > 127) return OG_BAD_ARGS;
+    if ((transpose ? Cout : Cin) != C) return OG_BAD_ARGS;
+    PackArgs p;
+    memset(&p, 0, sizeof(p));
+    og_fill_pack(p, w, wt, N, C, H, W, Cout, Cin, Torig, transpose, Tg, src_tap, PH, PW, act, math, nullptr);
+    memcpy(job, &p, sizeof(p));
+    return OG_OK;
+}
+
+int objgan_conv_pack_job_phase(void* job, const float* w, float* wt, int Cout, int Cin, int Torig, int Tg,
+                               const int* src_tap_phase, int phase, int math) {
+    if (!job || Tg < 1 || Tg > 8 || phase < 0 || phase > 3 || Torig < 1 || Torig > 127) return OG_BAD_ARGS;
+    PackArgs p;
+    memset(&p, 0, sizeof(p));
+    og_fill_pack_phase(p, w, wt, Cout, Cin, Torig, Tg, src_tap_phase, phase, math);
+    memcpy(job, &p, sizeof(p));
+    return OG_OK;
+}
+
+// jobs_dev: njobs blobs in device memory.
+int objgan_conv_pack_jobs_run(const void* jobs_dev, int njobs, void* stream) {
+    OG_ENTRY();
+    if (njobs <= 0) return OG_OK;
+    if (!jobs_dev || njobs > 65535) return OG_BAD_ARGS;
+    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(128, njobs), dim3(256), 0, (hipStream_t)stream,
+                       (const PackArgs*)jobs_dev);
+    return og_launch_status();
+}
 
 // Layout class of the packed bank objgan_conv_igemm would write / expect for these arguments (0..3).
 // A caller that keeps packed banks (wt_packed = 1) must key them on this value as well: the same
@@ -1936,14 +2131,9 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
     if (N <= 0 || PH <= 0 || PW <= 0 || M <= 0) return OG_OK;
     hipStream_t s = (hipStream_t)stream;
     PackArgs p;
-    p.w = w; p.wt = wt; p.Cout = Cout; p.Cin = Cin; p.Torig = Torig; p.Tg = Tg;
-    p.M = M; p.Mpad = (M + 127) / 128 * 128; p.Ck = C; p.Cp = (C + 15) / 16 * 16;
-    p.transpose = transpose;
     int MT = 32;
-    p.m_major = og_bank_layout(N, C, H, W, M, Tg, PH, PW, act, math, &MT);
+    og_fill_pack(p, w, wt, N, C, H, W, Cout, Cin, Torig, transpose, Tg, src_tap, PH, PW, act, math, &MT);
     const bool v2 = p.m_major != 0, thin = p.m_major == 2, bf = p.m_major == 3;
-    if (thin) p.Mpad = MT;
-    for (int t = 0; t < OG_MAX_TAPS; ++t) p.src_tap[t] = (signed char)(t < Tg ? src_tap[t] : -1);
     if (!wt_packed) {       // wt_packed: the caller kept wt from an earlier call with the same
         const long ptotal = (long)Tg * p.Cp * p.Mpad;   // filter bank, taps, math and geometry class
         hipLaunchKernelGGL(pack_weights_kernel, dim3(og_stream_grid(ptotal, 256)), dim3(256), 0, s, p);
@@ -1998,10 +2188,7 @@ int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float*
     if (!wt_packed) {
         for (int ph = 0; ph < 4; ++ph) {
             PackArgs p;
-            p.w = w; p.wt = wt + ph * bank; p.Cout = Cout; p.Cin = Cin; p.Torig = Torig; p.Tg = Tg;
-            p.M = M; p.Mpad = (M + 127) / 128 * 128; p.Ck = C; p.Cp = Cp;
-            p.transpose = 1; p.m_major = math == 1 ? 3 : 1;
-            for (int t = 0; t < OG_MAX_TAPS; ++t) p.src_tap[t] = (signed char)(t < Tg ? src_tap[ph * Tg + t] : -1);
+            og_fill_pack_phase(p, w, wt, Cout, Cin, Torig, Tg, src_tap + ph * Tg, ph, math);
             hipLaunchKernelGGL(pack_weights_kernel, dim3(og_stream_grid((long)M * Krow, 256)), dim3(256), 0, s, p);
             int rc = og_launch_status();
             if (rc != OG_OK) return rc;
@@ -2023,6 +2210,43 @@ int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float*
         for (int t = 0; t < Tg; ++t)
             a.tap[ph * 8 + t] = (int)(((unsigned)dw[ph * Tg + t] << 16) | ((unsigned)dh[ph * Tg + t] & 0xffffu));
     return run_igemm2(a, s, 0);
+}
+
+// dX [N, Cin, 2*OH, 2*OW] of a 4x4 / stride 2 / pad 1 convolution with Cin <= 16 input channels, from
+// dY [N, Cout, OH, OW]: all four parity phases in one launch (conv_thin_dgrad_s2k4_kernel).  w: the PyTorch
+// weight [Cout][Cin][4][4]; wt: scratch of (Cout + 1) * 16 * 16 floats (thin bank, kept by the caller when
+// wt_packed).  Every element of dX is written.
+int objgan_conv_dgrad_s2k4_thin(const float* dy, const float* w, float* dx, float* wt, int N, int Cout, int OH,
+                                int OW, int Cin, int wt_packed, void* stream) {
+    OG_ENTRY();
+    if (Cin < 1 || Cin > 16) return OG_BAD_ARGS;
+    if (N <= 0 || Cout <= 0 || OH <= 0 || OW <= 0) return OG_OK;
+    if ((double)N * Cout * OH * OW * 4.0 >= 4.0e9) return OG_BAD_ARGS;
+    hipStream_t s = (hipStream_t)stream;
+    const int MT = Cin <= 4 ? 4 : 16;
+    if (!wt_packed) {
+        PackArgs p;
+        memset(&p, 0, sizeof(p));
+        p.w = w; p.wt = wt; p.Cout = Cout; p.Cin = Cin; p.Torig = 16; p.Tg = 16;
+        p.M = Cin; p.Mpad = MT; p.Ck = Cout; p.Cp = (Cout + 15) / 16 * 16;
+        p.transpose = 1; p.m_major = 2;
+        for (int t = 0; t < OG_MAX_TAPS; ++t) p.src_tap[t] = (signed char)(t < 16 ? t : -1);
+        const long ptotal = (long)(Cout + 1) * 16 * MT;
+        hipLaunchKernelGGL(pack_weights_kernel, dim3(og_stream_grid(ptotal, 256)), dim3(256), 0, s, p);
+        int rc = og_launch_status();
+        if (rc != OG_OK) return rc;
+    }
+    const long total = (long)N * OH * OW;
+    ProfRec* pr = prof_begin(OG_CAT_THIN, 2.0 * Cin * (double)Cout * 4.0 * (double)total * 4.0, s);
+    prof_meta(pr, 2, MT, Cin, Cout, 16, N, OH, OW, -2, 1);
+    if (MT == 4)
+        hipLaunchKernelGGL((conv_thin_dgrad_s2k4_kernel<4>), dim3(og_cdiv(total, 256)), dim3(256), 0, s, dy,
+                           (const float*)wt, dx, N, Cout, OH, OW, Cin);
+    else
+        hipLaunchKernelGGL((conv_thin_dgrad_s2k4_kernel<16>), dim3(og_cdiv(total, 256)), dim3(256), 0, s, dy,
+                           (const float*)wt, dx, N, Cout, OH, OW, Cin);
+    prof_end(pr, s);
+    return og_launch_status();
 }
 
 // dw must be zero-initialised by the caller (or hold a gradient to accumulate into).

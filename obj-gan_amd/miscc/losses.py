@@ -100,12 +100,8 @@ def words_loss(img_features, words_emb, labels, cap_lens, class_ids, batch_size,
     word_ok = (torch.arange(L, device=dev).view(1, 1, L) < lens_dev.view(1, B, 1)).expand(B, B, L)
     a2 = ops.softmax_strided(a1, 3, float(cfg.TRAIN.SMOOTH.GAMMA1),
                              rowvalid=word_ok.reshape(-1).to(torch.uint8).contiguous())
-    # weightedContext[b, :, i, l] = sum_s context[b, :, s] * a2[b, i, l, s]
-    wcs = []
-    for b in range(B):
-        regions = a2[b].reshape(B * L, S).t().reshape(1, S, B * L, 1)
-        wcs.append(ops.conv2d(regions, img_features[b].reshape(nef, S, 1, 1)).reshape(1, nef, B, L))
-    wc = torch.cat(wcs, 0)                                                   # B x nef x B x L
+    # weightedContext[b, :, i, l] = sum_s context[b, :, s] * a2[b, i, l, s]: B small products, one launch
+    wc = ops.bmm(img_features.reshape(B, nef, S), a2.reshape(B, B * L, S).transpose(1, 2)).reshape(B, nef, B, L)
     word = words_emb.permute(1, 0, 2).unsqueeze(0)                           # 1 x nef x B x L
     w12 = (word * wc).sum(1)
     denom = (torch.norm(word, 2, 1) * torch.norm(wc, 2, 1)).clamp(min=1e-8)

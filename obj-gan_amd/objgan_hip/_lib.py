@@ -54,6 +54,13 @@ SIGNATURES = {
     "objgan_bilinear_backward": [_ptr, _ptr, _c_long, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_sum2x2": [_ptr, _ptr, _c_long, _c_int, _c_int, _ptr],
     "objgan_reflect_fold": [_ptr, _ptr, _c_long, _c_int, _c_int, _ptr],
+    "objgan_conv_dgrad_s2k4_thin": [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr],
+    "objgan_conv_pack_job_bytes": [],
+    "objgan_conv_pack_job": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                             _c_int, _ptr, _c_int, _c_int, _c_int, _c_int],
+    "objgan_conv_pack_job_phase": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _c_int, _c_int],
+    "objgan_conv_pack_jobs_run": [_ptr, _c_int, _ptr],
+    "objgan_bmm_strided": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int] + [_c_long] * 9 + [_ptr],
     "objgan_lift_taps_forward": [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                  _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "objgan_lift_taps_backward": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,

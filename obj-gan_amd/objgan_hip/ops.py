@@ -70,31 +70,89 @@ def get_conv_math():
 
 
 
-def _packed_scratch(M, C, T, device):
-    n = _lib.load().objgan_conv_packed_floats(int(M), int(C), int(T))
-    return torch.empty(n, dtype=_F32, device=device)
-
-
 # Packed filter banks are kept while their weights are unchanged.  A weight tensor is eligible
 # when something vouches for its contents: either it carries `_og_epoch` (a one-element list owned
 # by its optimizer arena, bumped by every ArenaAdam.step -- the fused Adam kernel writes through a
 # raw pointer, invisible to torch's version counter), or it is frozen (requires_grad False, e.g.
 # the Inception encoder); torch-side in-place edits are caught by `_version`.  The C library stays
 # stateless: the cache is host-side memory ownership, exactly like any other scratch buffer.
+#
+# One entry per (weight, direction, taps, bank layout, math): the entry records the version / epoch its
+# bank was packed for; a stale bank is re-packed IN PLACE (no new buffer), either by the conv call that
+# finds it stale or -- for the banks of an optimizer arena -- all at once by repack_arena() right behind
+# the Adam kernel, from a device table of pack jobs (one launch instead of ~60 per network and step).
+class _Bank(object):
+    __slots__ = ("w", "wt", "version", "epoch", "jobs")
+
+    def __init__(self, w, wt):
+        self.w, self.wt, self.version, self.epoch, self.jobs = w, wt, None, None, None
+
+
 _PACK_CACHE = {}
 _PACK_CACHE_MAX = 4096
+_ARENA_BANKS = {}       # id(epoch cell) -> {"cell": cell, "banks": [...], "table": device bytes or None, "n": jobs}
 
 
 def invalidate_packed():
     _PACK_CACHE.clear()
+    _ARENA_BANKS.clear()
 
 
 def _pack_key(w, transpose, src_tap, big):
     ep = getattr(w, "_og_epoch", None)
     if ep is None and w.requires_grad:
         return None
-    return (w.data_ptr(), w._version, ep[0] if ep is not None else -1, tuple(w.shape), int(transpose),
-            tuple(src_tap), big, _MATH["mode"])
+    return (w.data_ptr(), tuple(w.shape), int(transpose), tuple(src_tap), big, _MATH["mode"])
+
+
+def _epoch_of(w):
+    ep = getattr(w, "_og_epoch", None)
+    return ep[0] if ep is not None else -1
+
+
+def _bank_lookup(key, w, nfloats, device, batched=True):
+    """-> (_Bank, fresh): the cached bank of this key (created on first use) and whether its contents
+    match the weight's current version / epoch.  batched=False: the bank is not part of its network's
+    repack table (it is refreshed by the call that finds it stale)."""
+    ent = _PACK_CACHE.get(key)
+    if ent is None or ent.w is not w:
+        if len(_PACK_CACHE) >= _PACK_CACHE_MAX:
+            invalidate_packed()
+        ent = _Bank(w, torch.empty(nfloats, dtype=_F32, device=device))   # holding w keeps its address from being reused
+        _PACK_CACHE[key] = ent
+        cell = getattr(w, "_og_epoch", None)
+        if cell is not None and batched:
+            grp = _ARENA_BANKS.setdefault(id(cell), {"cell": cell, "banks": [], "table": None, "n": 0})
+            grp["banks"].append(ent)
+            grp["table"] = None
+        return ent, False
+    return ent, (ent.version == w._version and ent.epoch == _epoch_of(w))
+
+
+def _bank_mark(ent):
+    ent.version, ent.epoch = ent.w._version, _epoch_of(ent.w)
+
+
+def repack_arena(epoch_cell):
+    """Refresh every cached bank of the network that owns `epoch_cell` (call right after its optimizer
+    step, on the same stream): one launch over the device table of pack jobs."""
+    grp = _ARENA_BANKS.get(id(epoch_cell))
+    if grp is None or not grp["banks"]:
+        return 0
+    if grp["table"] is None:
+        blob = b"".join(j for ent in grp["banks"] for j in ent.jobs)
+        nbytes = _lib.load().objgan_conv_pack_job_bytes()
+        grp["n"] = len(blob) // nbytes
+        dev = grp["banks"][0].wt.device
+        grp["table"] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    _lib.call("objgan_conv_pack_jobs_run", _p(grp["table"]), grp["n"], _stream())
+    for ent in grp["banks"]:
+        _bank_mark(ent)
+    return grp["n"]
+
+
+def _job_blob():
+    return ctypes.create_string_buffer(_lib.load().objgan_conv_pack_job_bytes())
 
 
 def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, transpose,
@@ -104,15 +162,18 @@ def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, tran
     # the library picks the kernel -- hence the bank layout -- from sizes, taps and math: ask it
     layout = _lib.load().objgan_conv_bank_layout(N, C, H, W, M, Tg, PH, PW, act, _MATH["mode"])
     key = _pack_key(w, transpose, src_tap, layout)
-    ent = _PACK_CACHE.get(key) if key is not None else None
-    if ent is not None and ent[0] is w:
-        wt, packed = ent[1], 1
+    nfl = _lib.load().objgan_conv_packed_floats(int(M), int(C), int(Tg))
+    if key is not None:
+        ent, fresh = _bank_lookup(key, w, nfl, x.device)
+        wt, packed = ent.wt, int(fresh)
+        if ent.jobs is None:
+            job = _job_blob()
+            _lib.call("objgan_conv_pack_job", job, _p(w), _p(wt), N, C, H, W, Cout, Cin, Torig, int(transpose),
+                      Tg, _iarr(src_tap), PH, PW, act, _MATH["mode"])
+            ent.jobs = [job.raw]
+        _bank_mark(ent)
     else:
-        wt, packed = _packed_scratch(M, C, Tg, x.device), 0
-        if key is not None:
-            if len(_PACK_CACHE) >= _PACK_CACHE_MAX:
-                _PACK_CACHE.clear()
-            _PACK_CACHE[key] = (w, wt)          # holding w keeps its address from being reused
+        wt, packed = torch.empty(nfl, dtype=_F32, device=x.device), 0
     _lib.call("objgan_conv_igemm", _p(x), _p(w), _p(bias), _p(y), _p(wt),
               N, C, H, W, int(upsample), int(pad_mode), Cout, Cin, Torig, int(transpose),
               Tg, _iarr(dh), _iarr(dw), _iarr(src_tap), PH, PW, stride,
@@ -141,15 +202,19 @@ def _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad_h, pad_w, LH, LW, cachea
     dx = torch.empty((N, Cin, LH, LW), dtype=_F32, device=g.device)
     n = 4 * Cin * Tg * ((Cout + 15) // 16 * 16)
     key = _pack_key(w, 2, st, False) if cacheable else None
-    ent = _PACK_CACHE.get(key) if key is not None else None
-    if ent is not None and ent[0] is w:
-        wt, packed = ent[1], 1
+    if key is not None:
+        ent, fresh = _bank_lookup(key, w, n, g.device)
+        wt, packed = ent.wt, int(fresh)
+        if ent.jobs is None:
+            ent.jobs = []
+            for ph in range(4):
+                job = _job_blob()
+                _lib.call("objgan_conv_pack_job_phase", job, _p(w), _p(wt), Cout, Cin, KH * KW, Tg,
+                          _iarr(st[ph * Tg:(ph + 1) * Tg]), ph, _MATH["mode"])
+                ent.jobs.append(job.raw)
+        _bank_mark(ent)
     else:
         wt, packed = torch.empty(n, dtype=_F32, device=g.device), 0
-        if key is not None:
-            if len(_PACK_CACHE) >= _PACK_CACHE_MAX:
-                _PACK_CACHE.clear()
-            _PACK_CACHE[key] = (w, wt)
     _lib.call("objgan_conv_dgrad_s2_phases", _p(g), _p(w), _p(dx), _p(wt), N, Cout, OH, OW, Cin, KH * KW,
               Tg, _iarr(dh), _iarr(dw), _iarr(st), LH // 2, LW // 2, packed, _MATH["mode"], _stream())
     return dx
@@ -195,6 +260,21 @@ def _conv_dgrad(g, w, N, Cin, H, W, stride, pad, refl, upsample, cacheable=True)
     elif stride == 2:
         if refl:
             raise _lib.ObjganHipError("stride-2 reflect conv is not on the hot path")
+        if k == 4 and pad == 1 and Cin <= 16 and LH == 2 * OH and LW == 2 * OW and not upsample \
+                and _MATH["mode"] == 0 and float(N) * Cout * OH * OW * 4.0 < 4.0e9:
+            # first discriminator layer: all four parity phases in one pass over dY (thin VALU kernel)
+            dxl = torch.empty((N, Cin, LH, LW), dtype=_F32, device=g.device)
+            nfl = (Cout + 1) * 256
+            key = _pack_key(w, 3, (16,), False) if cacheable else None
+            if key is not None:
+                ent, fresh = _bank_lookup(key, w, nfl, g.device, batched=False)
+                wt, packed = ent.wt, int(fresh)
+                _bank_mark(ent)
+            else:
+                wt, packed = torch.empty(nfl, dtype=_F32, device=g.device), 0
+            _lib.call("objgan_conv_dgrad_s2k4_thin", _p(g), _p(w), _p(dxl), _p(wt), N, Cout, OH, OW, Cin,
+                      packed, _stream())
+            return dxl
         dxl = _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad, pad, LH, LW, cacheable)
         phases = range(2) if dxl is None else ()
         if dxl is None:
@@ -676,6 +756,40 @@ class _MaskedMaxFn(torch.autograd.Function):
 
 def masked_max(f, m, ih, iw):
     return _MaskedMaxFn.apply(f, m, ih, iw)
+
+
+def _bmm_raw(A, B):
+    """C[b] = A[b] @ B[b] for 3-D fp32 tensors with arbitrary strides (no copies)."""
+    Bt, M, K = A.shape
+    N = B.shape[2]
+    C = torch.empty((Bt, M, N), dtype=_F32, device=A.device)
+    _lib.call("objgan_bmm_strided", _p(A), _p(B), _p(C), Bt, M, N, K,
+              A.stride(0), A.stride(1), A.stride(2), B.stride(0), B.stride(1), B.stride(2),
+              C.stride(0), C.stride(1), C.stride(2), _stream())
+    return C
+
+
+class _BmmFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A, B):
+        _chk(A, B)
+        if A.dim() != 3 or B.dim() != 3 or A.shape[0] != B.shape[0] or A.shape[2] != B.shape[1]:
+            raise _lib.ObjganHipError("bmm: shapes %s x %s" % (tuple(A.shape), tuple(B.shape)))
+        ctx.save_for_backward(A, B)
+        return _bmm_raw(A, B)
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, B = ctx.saved_tensors
+        _chk(dC)
+        dA = _bmm_raw(dC, B.transpose(1, 2)) if ctx.needs_input_grad[0] else None
+        dB = _bmm_raw(A.transpose(1, 2), dC) if ctx.needs_input_grad[1] else None
+        return dA, dB
+
+
+def bmm(A, B):
+    """torch.bmm for small fp32 batches on one launch (any strides)."""
+    return _BmmFn.apply(A, B)
 
 
 class _SoftmaxStridedFn(torch.autograd.Function):

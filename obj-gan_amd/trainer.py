@@ -179,6 +179,7 @@ class ArenaAdam(object):
             ops.adam_step_gated_(a.flat, a.grad, a.exp_avg, a.exp_avg_sq, lr, self.betas[0], self.betas[1],
                                  self.eps, a.gate_state, a.grad[a.n:], a.gate_coef, grad_scale=grad_scale,
                                  n=a.n)
+            ops.repack_arena(a.epoch)
             return
         if a.gate_state is not None:        # leave gated mode: one read of the device counter
             a.step_count = int(a.gate_state[0].item())
@@ -187,6 +188,7 @@ class ArenaAdam(object):
         ops.adam_step_(a.flat, a.grad, a.exp_avg, a.exp_avg_sq, lr,
                        self.betas[0], self.betas[1], self.eps, a.step_count, grad_scale=grad_scale,
                        n=a.n)
+        ops.repack_arena(a.epoch)       # every cached filter bank of this network, one launch
 
     @property
     def steps_taken(self):

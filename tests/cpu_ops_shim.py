@@ -98,6 +98,14 @@ def lift_stem_conv(seg, w, bias, size):
     return F.conv2d(F.pad(up, (1, 1, 1, 1), mode="reflect"), w, bias)
 
 
+def bmm(A, B):
+    return torch.bmm(A, B)
+
+
+def repack_arena(epoch_cell):
+    return 0
+
+
 def max_pool2d(x, kernel_size, stride):
     return F.max_pool2d(x, kernel_size, stride)
 
@@ -141,7 +149,7 @@ def get_conv_math():
 
 API = ("conv2d", "conv2d_frozen", "linear", "norm_act", "norm_act_eval", "attn_general", "attn_bu", "masked_max",
        "softmax_strided", "roi_align", "avgpool2s1", "bilinear_resize", "lstm_bidir_forward", "adam_step_",
-       "adam_step_gated_", "ema_update_", "max_pool2d", "avg_pool2d", "lift_stem_conv")
+       "adam_step_gated_", "ema_update_", "max_pool2d", "avg_pool2d", "lift_stem_conv", "bmm", "repack_arena")
 
 
 def install(monkeypatch):

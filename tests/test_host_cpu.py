@@ -157,12 +157,12 @@ def test_load_params_invalidates_filter_bank_caches():
     net = torch.nn.Conv2d(40, 64, 3, bias=False)
     w = net.weight
     w._og_epoch = [0]                                     # as if owned by an optimizer arena
-    key0 = ops._pack_key(w, 0, (0,), 1)
+    stamp0 = (w._version, ops._epoch_of(w))               # what a cached bank is checked against
     bank0, _ = ops._up_bank(w)
     ref0 = bank0.clone()
     backup = copy_G_params(net)
     load_params(net, [torch.full_like(w, 0.25)])
-    assert ops._pack_key(w, 0, (0,), 1) != key0
+    assert (w._version, ops._epoch_of(w)) != stamp0
     bank1, _ = ops._up_bank(w)
     assert not torch.allclose(bank1, ref0) and float(bank1.max()) == 1.0   # 4 taps of 0.25 summed
     load_params(net, backup)

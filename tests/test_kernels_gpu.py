@@ -49,6 +49,8 @@ CONV_CASES = [
     (2, 6, 190, 194, 3, 3, 1, 1, "zeros", False, False, "tanh"),        # ... to-RGB, ragged strips
     (1, 5, 136, 128, 20, 3, 1, 1, "zeros", True, False, "lrelu"),       # generic thin kernel (upsample)
     (2, 15, 384, 384, 40, 4, 2, 1, "zeros", False, False, "lrelu"),     # dgrad phases with M = 15: thin T=4
+    (2, 3, 40, 24, 96, 4, 2, 1, "zeros", False, False, "lrelu"),        # first D layer, image only: fused 4-phase thin dgrad (MT 4)
+    (1, 12, 16, 16, 33, 4, 2, 1, "zeros", False, False, None),          # ... odd Cout (bank's zero channel)
     # one-launch four-phase data gradient (Cin > 32, even sizes)
     (2, 48, 24, 40, 64, 4, 2, 1, "zeros", False, False, None),
     # upBlock convs on the four-phase 2x2 form (pre-summed taps): ragged channel counts, odd height
@@ -512,6 +514,25 @@ def test_lift_stem_conv_matches_the_reference_formulation(dev):
         torch.cuda.synchronize()
         e = (rel_l2(yd, yr), rel_l2(wd.grad, wr.grad), rel_l2(bd.grad, br.grad), rel_l2(sd.grad, sr.grad))
         assert max(e) < TOL, ((N, C, Mo, h, S), e)
+
+
+def test_bmm_strided_matches_torch(dev):
+    """One-launch batched product of small strided matrices (DAMSM region-context products) and both
+    gradients against torch.bmm on the CPU; operands are non-contiguous views on purpose."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    for (Bt, M, N, K) in [(16, 256, 192, 289), (3, 70, 5, 33), (2, 1, 130, 17)]:
+        A = torch.randn(Bt, M, K, generator=g)
+        Bm = torch.randn(Bt, N, K, generator=g)               # used transposed: a strided view
+        Ar, Br = A.clone().requires_grad_(), Bm.clone().requires_grad_()
+        Cr = torch.bmm(Ar, Br.transpose(1, 2))
+        gC = torch.randn(Cr.shape, generator=g)
+        Cr.backward(gC)
+        Ad, Bd = A.to(dev).requires_grad_(), Bm.to(dev).requires_grad_()
+        Cd = ops.bmm(Ad, Bd.transpose(1, 2))
+        Cd.backward(gC.to(dev))
+        torch.cuda.synchronize()
+        assert rel_l2(Cd, Cr) < 1e-5 and rel_l2(Ad.grad, Ar.grad) < 1e-5 and rel_l2(Bd.grad, Br.grad) < 1e-5
 
 
 def test_gated_adam_follows_the_device_flag(dev):

@@ -30,6 +30,7 @@ static const Shape SHAPES[] = {
     {"up_256   194->96 3x3 up", 16, 194, 128, 128, 96, 3, 1, 1, 0, 1},
     {"hmap_256 80->24 3x3 refl", 16, 80, 256, 256, 24, 3, 1, 1, 1, 0},
     {"shp_512  80->12 3x3 refl", 16, 80, 512, 512, 12, 3, 1, 1, 1, 0},
+    {"patd_l1  3->96 4x4 s2 @256", 16, 3, 256, 256, 96, 4, 2, 1, 0, 0},
     {"objd_l1  15->96 4x4 s2 @512", 16, 15, 512, 512, 96, 4, 2, 1, 0, 0},
     {"objd_l2  96->192 4x4 s2 @256", 16, 96, 256, 256, 192, 4, 2, 1, 0, 0},
     {"objd_l3  192->384 4x4 s2 @128", 16, 192, 128, 128, 384, 4, 2, 1, 0, 0},
@@ -70,7 +71,8 @@ int main(int argc, char** argv) {
         float *dx, *dw, *dy, *dg, *dgx, *dgw, *wt;
         const int TH = sh.refl ? LH + 2 : LH, TW = sh.refl ? LW + 2 : LW;   // dgrad target (padded when reflect)
         const size_t ngx = (size_t)sh.N * sh.Cin * TH * TW;
-        const long nwt = objgan_conv_packed_floats(sh.Cout > sh.Cin ? sh.Cout : sh.Cin, sh.Cout > sh.Cin ? sh.Cout : sh.Cin, T);
+        long nwt = objgan_conv_packed_floats(sh.Cout > sh.Cin ? sh.Cout : sh.Cin, sh.Cout > sh.Cin ? sh.Cout : sh.Cin, T);
+        if (nwt < (long)(sh.Cout + 1) * 256) nwt = (long)(sh.Cout + 1) * 256;
         CK(hipMalloc(&dx, nx * 4)); CK(hipMalloc(&dw, nw * 4)); CK(hipMalloc(&dy, ny * 4)); CK(hipMalloc(&dg, ny * 4));
         CK(hipMalloc(&dgx, ngx * 4)); CK(hipMalloc(&dgw, nw * 4)); CK(hipMalloc(&wt, nwt * 4));
         CK(hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice));
@@ -95,6 +97,9 @@ int main(int argc, char** argv) {
                 int rc = objgan_conv_igemm(dg, dw, nullptr, dgx, wt, sh.N, sh.Cout, OH, OW, 0, 0, sh.Cout, sh.Cin, T, 1,
                                            T, h2.data(), w2.data(), stp.data(), TH, TW, 1, TH, TW, 1, 1, 0, 0, 0, 0, 0, g_math, st);
                 if (rc != 1) { fprintf(stderr, "dgrad rc=%d\n", rc); exit(1); }
+            } else if (sh.k == 4 && sh.s == 2 && sh.p == 1 && sh.Cin <= 16 && LH == 2 * OH && LW == 2 * OW && !getenv("OG_BENCH_OLD_THIN")) {
+                int rc = objgan_conv_dgrad_s2k4_thin(dg, dw, dgx, wt, sh.N, sh.Cout, OH, OW, sh.Cin, 0, st);
+                if (rc != 1) { fprintf(stderr, "dgrad s2k4 rc=%d\n", rc); exit(1); }
             } else if (sh.k % 2 == 0 && LH % 2 == 0 && sh.Cin > 32) {
                 std::vector<int> h2, w2, s2;
                 for (int ph = 0; ph < 2; ++ph) for (int pw = 0; pw < 2; ++pw)
