@@ -146,11 +146,6 @@ int objgan_bilinear_backward(const float* dy, float* dx, long planes, int ih, in
                              void* stream);
 int objgan_sum2x2(const float* dy, float* dx, long planes, int h, int w, void* stream);
 int objgan_reflect_fold(const float* dxp, float* dx, long planes, int h, int w, void* stream);
-/* Data gradient of the discriminators' first layer (Conv2d(3 + ngf, ndf, 4, 2, 1), reference
- * image_generation/model.py:989-1003) down to its <= 16 input channels: dX [N, Cin, 2*OH, 2*OW] from
- * dY [N, Cout, OH, OW], all four output-parity phases in one pass over dY.  wt: (Cout + 1) * 256 floats. */
-int objgan_conv_dgrad_s2k4_thin(const float* dy, const float* w, float* dx, float* wt, int N, int Cout, int OH,
-                                int OW, int Cin, int wt_packed, void* stream);
 /* Batched re-packing of cached filter banks.  A job is an opaque blob (objgan_conv_pack_job_bytes() bytes) that
  * says "pack w into wt exactly as objgan_conv_igemm -- or phase `phase` of objgan_conv_dgrad_s2_phases --
  * does for these arguments"; a caller that keeps packed banks (wt_packed = 1) stores the blobs of a network

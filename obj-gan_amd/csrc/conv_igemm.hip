@@ -483,93 +483,6 @@ __global__ __launch_bounds__(256) void conv_thin3x3_kernel(const IgemmArgs a) {
     }
 }
 
-
-// Data gradient of the discriminators' FIRST layer (4x4, stride 2, pad 1, reference model.py:989-1003) down
-// to its 3 / 15-channel input (image [+ 12-channel layout code]): all four output-parity phases in one
-// pass.  dx[2a+pa][2b+pb] reads the 2x2 of the 3x3 window dy[a-1..a+1][b-1..b+1] that parity (pa, pb)
-// selects: one thread = one (a, b), the window of a channel is loaded ONCE (9 coalesced dwords) and feeds the
-// 4 x 4 x MT FMAs of all phases -- the four per-phase launches of the generic thin kernel read dy four times
-// (1.6 GB per call at 256^2: HBM-bound at 65 TFLOP/s) and ran at half the FMA-per-load ratio.  Bank:
-// wt[co][kh*4 + kw][MT] (the thin layout with 16 taps), through the scalar cache.
-template <int MT>
-__global__ __launch_bounds__(256) void conv_thin_dgrad_s2k4_kernel(const float* __restrict__ dy,
-                                                                   const float* __restrict__ wt,
-                                                                   float* __restrict__ dx, int N, int C, int OH,
-                                                                   int OW, int M) {
-    const int OHW = OH * OW;
-    const long total = (long)N * OHW;
-    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    const bool t_ok = gid < total;
-    const long g = t_ok ? gid : 0;
-    const int n = (int)(g / OHW);
-    const int rem = (int)(g - (long)n * OHW);
-    const int pa_ = rem / OW, pb_ = rem - pa_ * OW;       // (a, b)
-    __amdgpu_buffer_rsrc_t res = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)dy, 0, (int)((unsigned)N * C * OHW * 4u), OG_BUF_FLAGS);
-    const unsigned img_off = (unsigned)n * (unsigned)C * (unsigned)OHW;
-    unsigned voff[3][3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int oh = pa_ + r - 1, ow = pb_ + c - 1;
-            const bool ok = t_ok && (unsigned)oh < (unsigned)OH && (unsigned)ow < (unsigned)OW;
-            voff[r][c] = ok ? (img_off + (unsigned)(oh * OW + ow)) * 4u : OG_OOB;
-        }
-    float acc[4][MT];
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[p][m] = 0.f;
-    auto load_win = [&](float (&xv)[3][3], int co) {
-        const int so = min(co, C - 1) * OHW * 4;
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                xv[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(res, voff[r][c], so, 0));
-    };
-    // parity 0 pairs (tap k, window index): (1, 1), (3, 0); parity 1: (0, 2), (2, 1)
-    auto fma_win = [&](const float (&xv)[3][3], int co) {
-        const float* __restrict__ wc = wt + (size_t)co * (16 * MT);
-#pragma unroll
-        for (int pa = 0; pa < 2; ++pa)
-#pragma unroll
-            for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int kh = pa ? 2 * i : 1 + 2 * i, r = pa ? 2 - i : 1 - i;
-                        const int kw = pb ? 2 * j : 1 + 2 * j, c = pb ? 2 - j : 1 - j;
-                        const float v = xv[r][c];
-#pragma unroll
-                        for (int m = 0; m < MT; ++m)
-                            acc[pa * 2 + pb][m] = fmaf(wc[(kh * 4 + kw) * MT + m], v, acc[pa * 2 + pb][m]);
-                    }
-    };
-    float xa[3][3], xb[3][3];
-    load_win(xa, 0);
-    for (int co = 0; co < C; co += 2) {           // the bank carries one zero channel: odd C needs no branch
-        load_win(xb, co + 1);
-        fma_win(xa, co);
-        load_win(xa, co + 2);
-        fma_win(xb, co + 1);
-    }
-    if (!t_ok) return;
-    const int LW = 2 * OW;
-    const size_t plane = (size_t)4 * OHW;
-    float* base = dx + (size_t)n * M * plane + (size_t)(2 * pa_) * LW + 2 * pb_;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        if (m < M) {
-            float* o = base + (size_t)m * plane;
-            *reinterpret_cast<float2*>(o) = make_float2(acc[0][m], acc[1][m]);
-            *reinterpret_cast<float2*>(o + LW) = make_float2(acc[2][m], acc[3][m]);
-        }
-    }
-}
-
 // ---- weight packing ------------------------------------------------------------------
 // wt[(t*Cp + ck) * Mpad + cm] = src_tap[t] >= 0 ? w[...] : 0, zero padded to [T*Cp][Mpad].
 // w is the PyTorch conv weight [Cout][Cin][Torig].  transpose = 0: cm = cout, ck = cin
@@ -2210,43 +2123,6 @@ int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float*
         for (int t = 0; t < Tg; ++t)
             a.tap[ph * 8 + t] = (int)(((unsigned)dw[ph * Tg + t] << 16) | ((unsigned)dh[ph * Tg + t] & 0xffffu));
     return run_igemm2(a, s, 0);
-}
-
-// dX [N, Cin, 2*OH, 2*OW] of a 4x4 / stride 2 / pad 1 convolution with Cin <= 16 input channels, from
-// dY [N, Cout, OH, OW]: all four parity phases in one launch (conv_thin_dgrad_s2k4_kernel).  w: the PyTorch
-// weight [Cout][Cin][4][4]; wt: scratch of (Cout + 1) * 16 * 16 floats (thin bank, kept by the caller when
-// wt_packed).  Every element of dX is written.
-int objgan_conv_dgrad_s2k4_thin(const float* dy, const float* w, float* dx, float* wt, int N, int Cout, int OH,
-                                int OW, int Cin, int wt_packed, void* stream) {
-    OG_ENTRY();
-    if (Cin < 1 || Cin > 16) return OG_BAD_ARGS;
-    if (N <= 0 || Cout <= 0 || OH <= 0 || OW <= 0) return OG_OK;
-    if ((double)N * Cout * OH * OW * 4.0 >= 4.0e9) return OG_BAD_ARGS;
-    hipStream_t s = (hipStream_t)stream;
-    const int MT = Cin <= 4 ? 4 : 16;
-    if (!wt_packed) {
-        PackArgs p;
-        memset(&p, 0, sizeof(p));
-        p.w = w; p.wt = wt; p.Cout = Cout; p.Cin = Cin; p.Torig = 16; p.Tg = 16;
-        p.M = Cin; p.Mpad = MT; p.Ck = Cout; p.Cp = (Cout + 15) / 16 * 16;
-        p.transpose = 1; p.m_major = 2;
-        for (int t = 0; t < OG_MAX_TAPS; ++t) p.src_tap[t] = (signed char)(t < 16 ? t : -1);
-        const long ptotal = (long)(Cout + 1) * 16 * MT;
-        hipLaunchKernelGGL(pack_weights_kernel, dim3(og_stream_grid(ptotal, 256)), dim3(256), 0, s, p);
-        int rc = og_launch_status();
-        if (rc != OG_OK) return rc;
-    }
-    const long total = (long)N * OH * OW;
-    ProfRec* pr = prof_begin(OG_CAT_THIN, 2.0 * Cin * (double)Cout * 4.0 * (double)total * 4.0, s);
-    prof_meta(pr, 2, MT, Cin, Cout, 16, N, OH, OW, -2, 1);
-    if (MT == 4)
-        hipLaunchKernelGGL((conv_thin_dgrad_s2k4_kernel<4>), dim3(og_cdiv(total, 256)), dim3(256), 0, s, dy,
-                           (const float*)wt, dx, N, Cout, OH, OW, Cin);
-    else
-        hipLaunchKernelGGL((conv_thin_dgrad_s2k4_kernel<16>), dim3(og_cdiv(total, 256)), dim3(256), 0, s, dy,
-                           (const float*)wt, dx, N, Cout, OH, OW, Cin);
-    prof_end(pr, s);
-    return og_launch_status();
 }
 
 // dw must be zero-initialised by the caller (or hold a gradient to accumulate into).

@@ -23,24 +23,36 @@
 struct AxisFwd { const int* i0; const int* i1; const float* l1; };      // each [3][S]
 struct AxisBwd { const int* off; const int* idx; const float* wt; };    // off [3][h + 1]
 
+// One thread = one pixel position; its table entries are read ONCE and serve all planes of the image (the
+// first version had one thread per output element and re-read the tables for each: 15-18 loads per output,
+// 1 ms per call for the column adjoint).
+#define LIFT_MAXE 8      // a source index is touched by at most 2 * ceil(S / h) + 2 lifted positions (6 for x2)
+
 // F[n][dh*Mo + co][qh][ow] = sum_dw A_dw(z[n][(dh*3 + dw)*Mo + co][qh][:])[ow]
 __global__ __launch_bounds__(256) void lift_cols_fwd_kernel(const float* __restrict__ z, float* __restrict__ F,
                                                             long total, int Mo, int h, int w, int SW, AxisFwd t) {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int ow = (int)(e % SW);
         long r = e / SW;
-        const int qh = (int)(r % h); r /= h;
-        const int c3 = (int)(r % (3 * Mo));
-        const long n = r / (3 * Mo);
-        const int dh = c3 / Mo, co = c3 - dh * Mo;
-        float acc = 0.f;
+        const int qh = (int)(r % h);
+        const long n = r / h;
+        int i0[3], i1[3];
+        float l1[3];
 #pragma unroll
-        for (int dw = 0; dw < 3; ++dw) {
-            const float* zp = z + ((n * 9 + dh * 3 + dw) * Mo + co) * (long)h * w + (long)qh * w;
-            const float l1 = t.l1[dw * SW + ow];
-            acc += (1.0f - l1) * zp[t.i0[dw * SW + ow]] + l1 * zp[t.i1[dw * SW + ow]];
-        }
-        F[e] = acc;
+        for (int dw = 0; dw < 3; ++dw) { i0[dw] = t.i0[dw * SW + ow]; i1[dw] = t.i1[dw * SW + ow]; l1[dw] = t.l1[dw * SW + ow]; }
+        const long hw = (long)h * w;
+        const float* zn = z + n * 9 * Mo * hw + (long)qh * w;
+        float* Fn = F + (n * 3 * Mo * h + qh) * (long)SW + ow;
+        for (int dh = 0; dh < 3; ++dh)
+            for (int co = 0; co < Mo; ++co) {
+                float acc = 0.f;
+#pragma unroll
+                for (int dw = 0; dw < 3; ++dw) {
+                    const float* zp = zn + ((dh * 3 + dw) * Mo + co) * hw;
+                    acc += (1.0f - l1[dw]) * zp[i0[dw]] + l1[dw] * zp[i1[dw]];
+                }
+                Fn[(long)(dh * Mo + co) * h * SW] = acc;
+            }
     }
 }
 
@@ -51,17 +63,26 @@ __global__ __launch_bounds__(256) void lift_rows_fwd_kernel(const float* __restr
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int ow = (int)(e % SW);
         long r = e / SW;
-        const int oh = (int)(r % SH); r /= SH;
-        const int co = (int)(r % Mo);
-        const long n = r / Mo;
-        float acc = bias ? bias[co] : 0.f;
+        const int oh = (int)(r % SH);
+        const long n = r / SH;
+        long o0[3], o1[3];
+        float l1[3];
 #pragma unroll
         for (int dh = 0; dh < 3; ++dh) {
-            const float* fp = F + ((n * 3 + dh) * Mo + co) * (long)h * SW + ow;
-            const float l1 = t.l1[dh * SH + oh];
-            acc += (1.0f - l1) * fp[(long)t.i0[dh * SH + oh] * SW] + l1 * fp[(long)t.i1[dh * SH + oh] * SW];
+            o0[dh] = (long)t.i0[dh * SH + oh] * SW; o1[dh] = (long)t.i1[dh * SH + oh] * SW; l1[dh] = t.l1[dh * SH + oh];
         }
-        y[e] = acc;
+        const long plane = (long)h * SW;
+        const float* Fn = F + n * 3 * Mo * plane + ow;
+        float* yn = y + (n * Mo * SH + oh) * (long)SW + ow;
+        for (int co = 0; co < Mo; ++co) {
+            float acc = bias ? bias[co] : 0.f;
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh) {
+                const float* fp = Fn + (dh * Mo + co) * plane;
+                acc += (1.0f - l1[dh]) * fp[o0[dh]] + l1[dh] * fp[o1[dh]];
+            }
+            yn[(long)co * SH * SW] = acc;
+        }
     }
 }
 
@@ -71,15 +92,29 @@ __global__ __launch_bounds__(256) void lift_rows_bwd_kernel(const float* __restr
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int ow = (int)(e % SW);
         long r = e / SW;
-        const int qh = (int)(r % h); r /= h;
-        const int c3 = (int)(r % (3 * Mo));
-        const long n = r / (3 * Mo);
-        const int dh = c3 / Mo, co = c3 - dh * Mo;
-        const float* gp = dy + (n * Mo + co) * (long)SH * SW + ow;
-        const int b = t.off[dh * (h + 1) + qh], en = t.off[dh * (h + 1) + qh + 1];
-        float acc = 0.f;
-        for (int k = b; k < en; ++k) acc += t.wt[k] * gp[(long)t.idx[k] * SW];
-        dF[e] = acc;
+        const int qh = (int)(r % h);
+        const long n = r / h;
+        const float* gn = dy + n * Mo * (long)SH * SW + ow;
+        float* dn = dF + (n * 3 * Mo * h + qh) * (long)SW + ow;
+        for (int dh = 0; dh < 3; ++dh) {
+            const int b = t.off[dh * (h + 1) + qh];
+            const int cnt = min(t.off[dh * (h + 1) + qh + 1] - b, LIFT_MAXE);
+            long of[LIFT_MAXE];
+            float wv[LIFT_MAXE];
+#pragma unroll
+            for (int k = 0; k < LIFT_MAXE; ++k) {
+                const bool on = k < cnt;
+                of[k] = on ? (long)t.idx[b + k] * SW : 0;
+                wv[k] = on ? t.wt[b + k] : 0.f;
+            }
+            for (int co = 0; co < Mo; ++co) {
+                const float* gp = gn + (long)co * SH * SW;
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < LIFT_MAXE; ++k) acc += wv[k] * gp[of[k]];
+                dn[(long)(dh * Mo + co) * h * SW] = acc;
+            }
+        }
     }
 }
 
@@ -89,16 +124,31 @@ __global__ __launch_bounds__(256) void lift_cols_bwd_kernel(const float* __restr
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int qw = (int)(e % w);
         long r = e / w;
-        const int qh = (int)(r % h); r /= h;
-        const int c9 = (int)(r % (9 * Mo));
-        const long n = r / (9 * Mo);
-        const int tt = c9 / Mo, co = c9 - tt * Mo;
-        const int dh = tt / 3, dw = tt - dh * 3;
-        const float* fp = dF + (((n * 3 + dh) * Mo + co) * (long)h + qh) * SW;
-        const int b = t.off[dw * (w + 1) + qw], en = t.off[dw * (w + 1) + qw + 1];
-        float acc = 0.f;
-        for (int k = b; k < en; ++k) acc += t.wt[k] * fp[t.idx[k]];
-        dz[e] = acc;
+        const int qh = (int)(r % h);
+        const long n = r / h;
+        const long hw = (long)h * w;
+        const float* fn = dF + (n * 3 * Mo * h + qh) * (long)SW;
+        float* zn = dz + n * 9 * Mo * hw + (long)qh * w + qw;
+        for (int dw = 0; dw < 3; ++dw) {
+            const int b = t.off[dw * (w + 1) + qw];
+            const int cnt = min(t.off[dw * (w + 1) + qw + 1] - b, LIFT_MAXE);
+            int of[LIFT_MAXE];
+            float wv[LIFT_MAXE];
+#pragma unroll
+            for (int k = 0; k < LIFT_MAXE; ++k) {
+                const bool on = k < cnt;
+                of[k] = on ? t.idx[b + k] : 0;
+                wv[k] = on ? t.wt[b + k] : 0.f;
+            }
+            for (int dh = 0; dh < 3; ++dh)
+                for (int co = 0; co < Mo; ++co) {
+                    const float* fp = fn + (long)(dh * Mo + co) * h * SW;
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < LIFT_MAXE; ++k) acc += wv[k] * fp[of[k]];
+                    zn[((dh * 3 + dw) * Mo + co) * hw] = acc;
+                }
+        }
     }
 }
 
@@ -113,7 +163,7 @@ int objgan_lift_taps_forward(const float* z, const float* bias, float* y, float*
     OG_ENTRY();
     if (N <= 0 || Mo <= 0) return OG_OK;
     if (h < 1 || w < 1 || SH < 2 || SW < 2 || !scratch) return OG_BAD_ARGS;
-    const long t1 = (long)N * 3 * Mo * h * SW, t2 = (long)N * Mo * SH * SW;
+    const long t1 = (long)N * h * SW, t2 = (long)N * SH * SW;           // one thread per pixel position
     AxisFwd tc = {ci0, ci1, cl1}, trw = {ri0, ri1, rl1};
     hipLaunchKernelGGL(lift_cols_fwd_kernel, dim3(og_stream_grid(t1, 256)), dim3(256), 0, (hipStream_t)stream,
                        z, scratch, t1, Mo, h, w, SW, tc);
@@ -130,7 +180,7 @@ int objgan_lift_taps_backward(const float* dy, float* dz, float* scratch, int N,
     OG_ENTRY();
     if (N <= 0 || Mo <= 0) return OG_OK;
     if (h < 1 || w < 1 || SH < 2 || SW < 2 || !scratch) return OG_BAD_ARGS;
-    const long t1 = (long)N * 3 * Mo * h * SW, t2 = (long)N * 9 * Mo * h * w;
+    const long t1 = (long)N * h * SW, t2 = (long)N * h * w;
     AxisBwd trw = {roff, ridx, rwt}, tc = {coff, cidx, cwt};
     hipLaunchKernelGGL(lift_rows_bwd_kernel, dim3(og_stream_grid(t1, 256)), dim3(256), 0, (hipStream_t)stream,
                        dy, scratch, t1, Mo, h, SH, SW, trw);

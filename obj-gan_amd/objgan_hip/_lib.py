@@ -54,7 +54,6 @@ SIGNATURES = {
     "objgan_bilinear_backward": [_ptr, _ptr, _c_long, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_sum2x2": [_ptr, _ptr, _c_long, _c_int, _c_int, _ptr],
     "objgan_reflect_fold": [_ptr, _ptr, _c_long, _c_int, _c_int, _ptr],
-    "objgan_conv_dgrad_s2k4_thin": [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_conv_pack_job_bytes": [],
     "objgan_conv_pack_job": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                              _c_int, _ptr, _c_int, _c_int, _c_int, _c_int],

@@ -110,10 +110,9 @@ def _epoch_of(w):
     return ep[0] if ep is not None else -1
 
 
-def _bank_lookup(key, w, nfloats, device, batched=True):
+def _bank_lookup(key, w, nfloats, device):
     """-> (_Bank, fresh): the cached bank of this key (created on first use) and whether its contents
-    match the weight's current version / epoch.  batched=False: the bank is not part of its network's
-    repack table (it is refreshed by the call that finds it stale)."""
+    match the weight's current version / epoch."""
     ent = _PACK_CACHE.get(key)
     if ent is None or ent.w is not w:
         if len(_PACK_CACHE) >= _PACK_CACHE_MAX:
@@ -121,7 +120,7 @@ def _bank_lookup(key, w, nfloats, device, batched=True):
         ent = _Bank(w, torch.empty(nfloats, dtype=_F32, device=device))   # holding w keeps its address from being reused
         _PACK_CACHE[key] = ent
         cell = getattr(w, "_og_epoch", None)
-        if cell is not None and batched:
+        if cell is not None:
             grp = _ARENA_BANKS.setdefault(id(cell), {"cell": cell, "banks": [], "table": None, "n": 0})
             grp["banks"].append(ent)
             grp["table"] = None
@@ -260,21 +259,6 @@ def _conv_dgrad(g, w, N, Cin, H, W, stride, pad, refl, upsample, cacheable=True)
     elif stride == 2:
         if refl:
             raise _lib.ObjganHipError("stride-2 reflect conv is not on the hot path")
-        if k == 4 and pad == 1 and Cin <= 16 and LH == 2 * OH and LW == 2 * OW and not upsample \
-                and _MATH["mode"] == 0 and float(N) * Cout * OH * OW * 4.0 < 4.0e9:
-            # first discriminator layer: all four parity phases in one pass over dY (thin VALU kernel)
-            dxl = torch.empty((N, Cin, LH, LW), dtype=_F32, device=g.device)
-            nfl = (Cout + 1) * 256
-            key = _pack_key(w, 3, (16,), False) if cacheable else None
-            if key is not None:
-                ent, fresh = _bank_lookup(key, w, nfl, g.device, batched=False)
-                wt, packed = ent.wt, int(fresh)
-                _bank_mark(ent)
-            else:
-                wt, packed = torch.empty(nfl, dtype=_F32, device=g.device), 0
-            _lib.call("objgan_conv_dgrad_s2k4_thin", _p(g), _p(w), _p(dxl), _p(wt), N, Cout, OH, OW, Cin,
-                      packed, _stream())
-            return dxl
         dxl = _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad, pad, LH, LW, cacheable)
         phases = range(2) if dxl is None else ()
         if dxl is None:
@@ -992,6 +976,9 @@ def _lift_axis_tables(n_in, n_out, device):
     def t(arrays, dt, flat=False):
         a = np.concatenate(arrays) if flat else np.stack(arrays)
         return torch.from_numpy(np.ascontiguousarray(a.astype(dt))).to(device)
+    longest = max(int((o[1:] - o[:-1]).max()) for o in offs)
+    if longest > 8:      # LIFT_MAXE of csrc/lift_stem.hip: entries a kernel thread keeps in registers
+        raise _lib.ObjganHipError("lift_stem_conv: lift factor %d -> %d too large for the adjoint kernel" % (n_in, n_out))
     ent = (t(i0s, np.int32), t(i1s, np.int32), t(l1s, np.float32),
            t(offs, np.int32), t(idxs, np.int32, True), t(wts, np.float32, True))
     _LIFT_TABLES[key] = ent

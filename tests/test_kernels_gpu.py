@@ -49,8 +49,8 @@ CONV_CASES = [
     (2, 6, 190, 194, 3, 3, 1, 1, "zeros", False, False, "tanh"),        # ... to-RGB, ragged strips
     (1, 5, 136, 128, 20, 3, 1, 1, "zeros", True, False, "lrelu"),       # generic thin kernel (upsample)
     (2, 15, 384, 384, 40, 4, 2, 1, "zeros", False, False, "lrelu"),     # dgrad phases with M = 15: thin T=4
-    (2, 3, 40, 24, 96, 4, 2, 1, "zeros", False, False, "lrelu"),        # first D layer, image only: fused 4-phase thin dgrad (MT 4)
-    (1, 12, 16, 16, 33, 4, 2, 1, "zeros", False, False, None),          # ... odd Cout (bank's zero channel)
+    (2, 3, 40, 24, 96, 4, 2, 1, "zeros", False, False, "lrelu"),        # first D layer, image only: thin dgrad phases, MT 4
+    (1, 12, 16, 16, 33, 4, 2, 1, "zeros", False, False, None),          # ... odd channel count (bank's zero channel)
     # one-launch four-phase data gradient (Cin > 32, even sizes)
     (2, 48, 24, 40, 64, 4, 2, 1, "zeros", False, False, None),
     # upBlock convs on the four-phase 2x2 form (pre-summed taps): ragged channel counts, odd height

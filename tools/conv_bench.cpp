@@ -97,9 +97,6 @@ int main(int argc, char** argv) {
                 int rc = objgan_conv_igemm(dg, dw, nullptr, dgx, wt, sh.N, sh.Cout, OH, OW, 0, 0, sh.Cout, sh.Cin, T, 1,
                                            T, h2.data(), w2.data(), stp.data(), TH, TW, 1, TH, TW, 1, 1, 0, 0, 0, 0, 0, g_math, st);
                 if (rc != 1) { fprintf(stderr, "dgrad rc=%d\n", rc); exit(1); }
-            } else if (sh.k == 4 && sh.s == 2 && sh.p == 1 && sh.Cin <= 16 && LH == 2 * OH && LW == 2 * OW && !getenv("OG_BENCH_OLD_THIN")) {
-                int rc = objgan_conv_dgrad_s2k4_thin(dg, dw, dgx, wt, sh.N, sh.Cout, OH, OW, sh.Cin, 0, st);
-                if (rc != 1) { fprintf(stderr, "dgrad s2k4 rc=%d\n", rc); exit(1); }
             } else if (sh.k % 2 == 0 && LH % 2 == 0 && sh.Cin > 32) {
                 std::vector<int> h2, w2, s2;
                 for (int ph = 0; ph < 2; ++ph) for (int pw = 0; pw < 2; ++pw)

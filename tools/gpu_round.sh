@@ -18,6 +18,8 @@ benchddp) ( time timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-basel
 benchbf16) ( time timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --math bf16 ) > gpurun_out/${TAG}_benchbf16.log 2>&1; tail -3 gpurun_out/${TAG}_benchbf16.log ;;
 opsrc) ( timeout 600 python tools/op_sources.py ) > gpurun_out/${TAG}_opsrc.txt 2> gpurun_out/${TAG}_opsrc.err; head -40 gpurun_out/${TAG}_opsrc.txt ;;
 benchenv) ( time env $OG_ENV timeout 600 python bench.py --steps 8 --warmup 2 --no-cpu-baseline ) > gpurun_out/${TAG}_benchenv.log 2>&1; tail -3 gpurun_out/${TAG}_benchenv.log | cut -c1-400 ;;
+profenv) cd /tmp && env $OG_ENV timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_profenv -o prof -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing > $R/gpurun_out/${TAG}_profenv.log 2>&1
+  cd $R; find gpurun_out/${TAG}_profenv -type f ! -name '*stats*' -size +1M -delete ;;
 prof) cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof -o prof -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing > $R/gpurun_out/${TAG}_prof.log 2>&1
   cd $R; find gpurun_out/${TAG}_prof -type f | head; find gpurun_out/${TAG}_prof -type f ! -name '*stats*' -size +1M -delete ;;
 esac; done
