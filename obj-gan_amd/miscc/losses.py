@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from miscc.config import cfg
-from miscc.utils import permute_seg, feat_select
+from miscc.utils import permute_seg, feat_select, take_rows
 from GlobalAttention import func_attention  # noqa: F401  (API parity)
 from objgan_hip import ops
 
@@ -185,9 +185,10 @@ def objD_loss(netObjD, real_imgs, fake_imgs, seg_conditions, raw_conditions, raw
     fake_seg, valid = permute_seg(seg_conditions, fm_rois, num_rois)
     classes2 = []
     if len(valid) > 0:
-        pooled2 = netObjD(real_imgs[valid], fake_seg[valid], fm_rois[valid], num_rois[valid])
-        fake_features2, classes2, bt_c_codes2 = feat_select(pooled2, raw_bt_c_codes, fm_rois[valid],
-                                                            num_rois[valid],
+        rois_v, num_v = take_rows(fm_rois, valid), take_rows(num_rois, valid)      # host copies stay attached
+        pooled2 = netObjD(real_imgs[valid], fake_seg[valid], rois_v, num_v)
+        fake_features2, classes2, bt_c_codes2 = feat_select(pooled2, raw_bt_c_codes, rois_v,
+                                                            num_v,
                                                             is_large_scale=is_large_scale)
     K = len(classes)
     if K == 0:

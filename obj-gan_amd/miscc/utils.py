@@ -22,11 +22,32 @@ from objgan_hip import ops
 _HOST = []          # [(tensor, version, numpy)], most recent first, at most 8 entries
 
 
+def attach_host(t_dev, t_cpu):
+    """Remember the host copy a device tensor was made from (box tables, box counts: a few hundred bytes
+    that the host-side helpers below index).  A `.cpu()` of them in the middle of a step is a full
+    host-device sync: the host stops enqueueing until the GPU has drained."""
+    if torch.is_tensor(t_dev) and t_dev.is_cuda and torch.is_tensor(t_cpu) and not t_cpu.is_cuda:
+        t_dev._og_host = t_cpu.detach().numpy()
+    return t_dev
+
+
+def take_rows(t, rows):
+    """t[rows] (rows: python list of sample indices) that keeps the host copy attached."""
+    out = t[rows]
+    h = getattr(t, "_og_host", None)
+    if h is not None and torch.is_tensor(out) and out.is_cuda:
+        out._og_host = h[rows]
+    return out
+
+
 def _host(t):
     if not isinstance(t, torch.Tensor):
         return np.asarray(t)
     if not t.is_cuda:
         return t.detach().numpy()
+    h = getattr(t, "_og_host", None)
+    if h is not None:
+        return h
     for i, (ref, ver, arr) in enumerate(_HOST):
         if ref is t and ver == t._version:
             if i:

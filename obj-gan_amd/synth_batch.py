@@ -101,14 +101,20 @@ def make_batch(batch_size=16, seed=1234, num_classes=80, words_num=12, boxes_num
     return batch
 
 
+_HOST_KEYS = ("rois", "fm_rois", "num_rois", "cap_lens")       # small tables the host-side helpers index
+
+
 def to_device(batch, device):
-    def mv(v):
+    from miscc.utils import attach_host
+
+    def mv(v, keep):
         if torch.is_tensor(v):
-            return v.to(device)
+            d = v.to(device)
+            return attach_host(d, v) if keep else d
         if isinstance(v, (list, tuple)):
-            return [mv(x) for x in v]
+            return [mv(x, keep) for x in v]
         return v
-    return {k: mv(v) for k, v in batch.items()}
+    return {k: mv(v, k in _HOST_KEYS) for k, v in batch.items()}
 
 
 def make_shape_inputs(seed=71, B_=2, R=3, nbf=8, S=64, fm=16):

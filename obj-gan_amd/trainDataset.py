@@ -10,6 +10,7 @@ import torch
 import torch.utils.data as data
 
 from miscc.config import cfg
+from miscc.utils import attach_host, _host
 from miscc.load import (load_filenames, load_text_data, load_glove_emb, load_cat_label, load_class_id,
                         load_cats, load_imgs_data, load_anns_data, get_imgs, get_caption, get_hmaps_rois)
 
@@ -89,9 +90,13 @@ def prepare_data(data, device=None, num_classes=None):
 
     def take(t):
         return put(t[order])
+
+    def take_small(t):      # box tables / counts: the host copy stays attached (miscc.utils._host)
+        h = t[order]
+        return h if device is None else attach_host(h.to(device, non_blocking=True), h)
     branches = range(len(imgs))
     out_imgs = [take(imgs[b]) for b in branches]
-    out_rois = [take(rois[b]) for b in branches]
+    out_rois = [take_small(rois[b]) for b in branches]
     out_masks, out_hmaps = [], []
     for b in branches:
         masks = take(bt_masks[b])
@@ -103,8 +108,9 @@ def prepare_data(data, device=None, num_classes=None):
             out_hmaps.append(take(hmaps[b].float()))
         out_masks.append(masks.float())
     order_list = order.tolist()
-    return [out_imgs, take(captions).squeeze(), take(glove_captions).squeeze(), put(lens_sorted), out_hmaps,
-            out_rois, take(fm_rois), take(num_rois), out_masks, take(fm_bt_masks).float(),
+    lens_out = lens_sorted if device is None else attach_host(put(lens_sorted), lens_sorted)
+    return [out_imgs, take(captions).squeeze(), take(glove_captions).squeeze(), lens_out, out_hmaps,
+            out_rois, take_small(fm_rois), take_small(num_rois), out_masks, take(fm_bt_masks).float(),
             class_ids[order].numpy(), [keys[i] for i in order_list]]
 
 
@@ -114,7 +120,7 @@ def batch_dict(prepared, clabels_emb):
     imgs, captions, glove_captions, cap_lens, hmaps, rois, fm_rois, num_rois, bt_masks, \
         fm_bt_masks, class_ids, keys = prepared
     return {"imgs": imgs, "captions": captions, "glove_captions": glove_captions, "cap_lens": cap_lens,
-            "max_len": int(torch.max(cap_lens)), "hmaps": hmaps, "rois": rois, "fm_rois": fm_rois,
+            "max_len": int(_host(cap_lens).max()), "hmaps": hmaps, "rois": rois, "fm_rois": fm_rois,
             "num_rois": num_rois, "bt_masks": bt_masks, "fm_bt_masks": fm_bt_masks,
             "class_ids": class_ids, "keys": keys, "clabels_emb": clabels_emb}
 
