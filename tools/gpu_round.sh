@@ -15,7 +15,9 @@ convbench) ( timeout 300 tools/conv_bench "" 5 ) > gpurun_out/${TAG}_convbench.l
 bench) ( time timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --shape-table gpurun_out/${TAG}_shapes.txt ) > gpurun_out/${TAG}_bench.log 2>&1; tail -3 gpurun_out/${TAG}_bench.log ;;
 benchfull) ( time timeout 900 python bench.py --steps 20 --warmup 5 ) > gpurun_out/${TAG}_benchfull.log 2>&1; tail -3 gpurun_out/${TAG}_benchfull.log ;;
 benchddp) ( time timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --force-ddp ) > gpurun_out/${TAG}_benchddp.log 2>&1; tail -3 gpurun_out/${TAG}_benchddp.log ;;
-benchbf16) ( time timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --math bf16 ) > gpurun_out/${TAG}_benchbf16.log 2>&1; tail -3 gpurun_out/${TAG}_benchbf16.log ;;
+benchbf16) ( time timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --math bf16 --batch 32 ) > gpurun_out/${TAG}_benchbf16.log 2>&1; tail -3 gpurun_out/${TAG}_benchbf16.log | cut -c1-600 ;;
+bench8) ( time timeout 600 python bench.py --steps 8 --warmup 2 --no-cpu-baseline ) > gpurun_out/${TAG}_bench8.log 2>&1; tail -3 gpurun_out/${TAG}_bench8.log | cut -c1-400 ;;
+pmc) bash tools/pmc_bench.sh ${TAG} > gpurun_out/${TAG}_pmc.log 2>&1; tail -20 gpurun_out/${TAG}_pmc_traffic.log ;;
 opsrc) ( timeout 600 python tools/op_sources.py ) > gpurun_out/${TAG}_opsrc.txt 2> gpurun_out/${TAG}_opsrc.err; head -40 gpurun_out/${TAG}_opsrc.txt ;;
 benchenv) ( time env $OG_ENV timeout 600 python bench.py --steps 8 --warmup 2 --no-cpu-baseline ) > gpurun_out/${TAG}_benchenv.log 2>&1; tail -3 gpurun_out/${TAG}_benchenv.log | cut -c1-400 ;;
 profenv) cd /tmp && env $OG_ENV timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_profenv -o prof -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing > $R/gpurun_out/${TAG}_profenv.log 2>&1
