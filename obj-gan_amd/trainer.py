@@ -83,8 +83,7 @@ class ParamArena(object):
     # ---- gradient-ready notification, in buckets (data-parallel overlap of the generator's all-reduce) ----
     def make_buckets(self, k=4):
         """Split the arena into <= k contiguous ranges of whole parameters (registration order, about equal
-        sizes) and install the per-parameter 'gradient is final' notifications: AccumulateGrad's
-        post-hook for gradients autograd delivers, `p._og_ready()` for those a kernel accumulates in place."""
+        sizes) and install the per-parameter 'gradient is final' notification (AccumulateGrad's post-hook)."""
         if getattr(self, "buckets", None) is not None:
             return self.buckets
         target = max(1, self.n // k)
@@ -105,9 +104,7 @@ class ParamArena(object):
                 self._bucket_of[i] = b
         self._armed = None
         for i, p in enumerate(self.params):
-            cb = (lambda *_a, i=i: self._mark(i))
-            p._og_ready = cb
-            p.register_post_accumulate_grad_hook(cb)
+            p.register_post_accumulate_grad_hook(lambda *_a, i=i: self._mark(i))
         return self.buckets
 
     def arm(self, on_bucket):
