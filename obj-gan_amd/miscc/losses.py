@@ -8,8 +8,6 @@ over captions (losses.py:87-127).  What remains in PyTorch here is scalar glue o
 most a few hundred kilobytes (BCE on B x 1 x k x k probabilities, cosine / log-sum-exp on
 B x B x L values, index selects).
 """
-import os
-
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -227,34 +225,13 @@ def _obj_g_term(netObjD, fake_img, seg, slabels_emb, raw_bt_c_codes, rois, num_r
     return err * cfg.TRAIN.SMOOTH.OBJ_LAMBDA
 
 
-_ENC_OVERLAP = os.environ.get("OBJGAN_NO_ENC_OVERLAP") != "1"
-_SIDE = {}
-
-
-def _damsm_side(image_encoder, img, words_embs, sent_emb, match_labels, cap_lens, class_ids, batch_size):
-    """-> (DAMSM_LAMBDA * (word + sentence ranking losses), side stream) evaluated on a side stream."""
-    dev = img.device
-    side = _SIDE.get(dev)
-    if side is None:
-        side = _SIDE[dev] = torch.cuda.Stream(device=dev)
-    cur = torch.cuda.current_stream()
-    side.wait_stream(cur)
-    with torch.cuda.stream(side):
-        region_features, cnn_code = image_encoder(img)
-        w0, w1, _, _ = words_loss(region_features, words_embs, match_labels, cap_lens, class_ids, batch_size,
-                                  top1=False, need_att_maps=False)
-        s0, s1, _ = sent_loss(cnn_code, sent_emb, match_labels, class_ids, batch_size, top1=False)
-        total = (w0 + w1 + s0 + s1) * cfg.TRAIN.SMOOTH.DAMSM_LAMBDA
-    for t in (img, words_embs, sent_emb):
-        t.record_stream(side)              # allocated on the main stream, read on the side stream
-    total.record_stream(cur)               # and the other way round
-    return total, side
-
-
 def G_loss(netsPatD, netsShpD, netObjSSD, netObjLSD, image_encoder, fake_imgs, seg_conditions,
            words_embs, sent_emb, slabels_emb, raw_bt_c_codes, match_labels, cap_lens, class_ids,
            rois, fm_rois, num_rois, quiet=False, use_obj=True):
-    """quiet=True skips the log string (every `.item()` in it is a device->host sync);
+    """quiet=True skips the log string, the DAMSM accuracies and attention maps (every `.item()` / `.cpu()` in
+    them is a device->host sync).  (Running the DAMSM branch or the eight discriminator updates on side
+    streams was measured in round 2: 275.3 ms without vs 276.6 with -- the step is MFMA-bound, concurrency
+    buys nothing -- so everything stays on one stream.)
     use_obj=False leaves the two object-discriminator terms out (BASELINE.json configs 1-3: the
     reference has no such switch, its stage-1 / no-ObjD runs are harness compositions)."""
     numDs = len(netsPatD)
@@ -262,12 +239,6 @@ def G_loss(netsPatD, netsShpD, netObjSSD, netObjLSD, image_encoder, fake_imgs, s
     logs = ''
     errG_total = 0
     sm = cfg.TRAIN.SMOOTH
-    # The DAMSM branch (frozen Inception-v3 encoder: ~100 convolutions on 35x35 ... 8x8 maps whose grids
-    # cover a fraction of the 256 CUs, then the word / sentence ranking losses) is independent of the
-    # discriminator passes below: on the GPU it runs on a side stream next to them, forward and -- since
-    # autograd replays every node on the stream of its forward -- backward.
-    damsm = _damsm_side(image_encoder, fake_imgs[numDs - 1], words_embs, sent_emb, match_labels, cap_lens,
-                        class_ids, batch_size) if quiet and _ENC_OVERLAP and fake_imgs[0].is_cuda else None
     for i in range(numDs):
         pat = _net(netsPatD[i])
         features = netsPatD[i](fake_imgs[i])
@@ -285,10 +256,7 @@ def G_loss(netsPatD, netsShpD, netObjSSD, netObjLSD, image_encoder, fake_imgs, s
         if not quiet:
             logs += 'shp_g_loss%d: %.2f ' % (i, shp_g_loss.item())
 
-        if i == (numDs - 1) and damsm is not None:
-            torch.cuda.current_stream().wait_stream(damsm[1])
-            errG_total = errG_total + damsm[0]
-        elif i == (numDs - 1):      # DAMSM ranking loss on the full-resolution image
+        if i == (numDs - 1):        # DAMSM ranking loss on the full-resolution image
             region_features, cnn_code = image_encoder(fake_imgs[i])
             w_loss0, w_loss1, _, _ = words_loss(region_features, words_embs, match_labels, cap_lens,
                                                 class_ids, batch_size, top1=not quiet, need_att_maps=not quiet)
