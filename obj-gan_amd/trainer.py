@@ -214,17 +214,6 @@ def category_embeddings(glove_weight, cat_labels, cat_label_lens, sorted_cat_lab
     return out[sorted_cat_label_indices.to(w.device)]
 
 
-_D_STREAMS = int(os.environ.get("OBJGAN_D_STREAMS", "1"))
-
-
-class _NullCtx(object):
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
-        return False
-
-
 def _dist_on():
     """A process group exists: the data-parallel path is taken, at any world size (a one-rank group runs
     the same collectives -- that is how the RCCL path is exercised on a single-GPU box)."""
@@ -389,13 +378,6 @@ class condGANTrainer(object):
         self.gen_iterations = 0
         return self
 
-    def _d_side_streams(self):
-        if _D_STREAMS <= 1 or self.device.type != "cuda":
-            return []
-        if getattr(self, "_d_streams", None) is None:
-            self._d_streams = [torch.cuda.Stream(device=self.device) for _ in range(_D_STREAMS)]
-        return self._d_streams
-
     def _d_optimizers(self):
         return self.optimizersPatD + self.optimizersShpD + [self.optimizerObjSSD, self.optimizerObjLSD]
 
@@ -473,28 +455,15 @@ class condGANTrainer(object):
                                                                      clabels_emb, bt_c_codes[-1], r, num_rois,
                                                                      is_large_scale=large)))
         pending = []
-        # The eight updates are independent; on the GPU they are dealt round-robin onto `_D_STREAMS` HIP
-        # streams (forward and -- autograd replays a node on its forward stream -- backward), so that the
-        # small-grid launches of one discriminator (heads on 4x4 .. 16x16 maps, norm passes, ROI pooling)
-        # fill the CUs another one leaves idle.  The host must not block inside a job for that to work:
-        # the box tables carry their host copies (miscc.utils.attach_host).
-        side = self._d_side_streams()
-        cur = torch.cuda.current_stream() if side else None
-        for st in side:
-            st.wait_stream(cur)
-        for j, (name, opt, loss_fn) in enumerate(jobs):
-            ctx = torch.cuda.stream(side[j % len(side)]) if side else _NullCtx()
-            with ctx:
-                opt.zero_grad()
-                err = loss_fn()
-                active = torch.is_tensor(err)
-                if active:
-                    err.backward()
-                    opt.arena.grad[-1] = 1.0             # "this rank has a gradient" flag
-                    out[name] = err.detach()
-                pending.append((opt, self._reduce_async(opt), active))
-        for st in side:
-            cur.wait_stream(st)
+        for name, opt, loss_fn in jobs:
+            opt.zero_grad()
+            err = loss_fn()
+            active = torch.is_tensor(err)
+            if active:
+                err.backward()
+                opt.arena.grad[-1] = 1.0             # "this rank has a gradient" flag
+                out[name] = err.detach()
+            pending.append((opt, self._reduce_async(opt), active))
 
         # discriminator Adam steps (after their reductions; they overlapped the later Ds).  Under data
         # parallelism a rank cannot know on the host whether ANOTHER rank had boxes of the wanted scale:
