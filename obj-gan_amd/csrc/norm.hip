@@ -389,6 +389,148 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_plane_kernel(
     }
 }
 
+
+// ---- InstanceNorm, one kernel per direction -------------------------------------------------------------
+// The statistics of an InstanceNorm group are those of ONE plane, so a workgroup can own its plane(s) from
+// the first read to the last write: pass 1 accumulates the shifted sums (block reduction, no atomics, no
+// zeroed workspace), pass 2 re-reads the plane -- 4 .. 64 KB that the workgroup itself has just pulled
+// through L2 / the Infinity Cache -- and applies.  Against the three-kernel path (memset + statistics +
+// finalize + apply) this is one launch instead of four and one HBM read of x instead of two.
+// grid = N*Co workgroups (GLU: the value and the gate plane of an output channel together).
+__device__ __forceinline__ void og_block_sum2(float& a, float& b, float* red) {
+    a = og_wave_sum(a);
+    b = og_wave_sum(b);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) { red[wid] = a; red[4 + wid] = b; }
+    __syncthreads();
+    a = red[0] + red[1] + red[2] + red[3];
+    b = red[4] + red[5] + red[6] + red[7];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void in_fwd_fused_kernel(
+    const float* __restrict__ x, const float* __restrict__ residual, float* __restrict__ y,
+    float* __restrict__ mean, float* __restrict__ rstd, NormGeom gm, float eps) {
+    __shared__ float red[8];
+    const int Co = MODE == OG_NORM_GLU ? gm.C / 2 : gm.C;
+    const int plane = blockIdx.x;                       // n*Co + c
+    const int n = plane / Co;
+    const int c = plane - n * Co;
+    const int ga = n * gm.C + c, gb = ga + Co;
+    const float4* xa = reinterpret_cast<const float4*>(x + (size_t)ga * gm.HW);
+    const float4* xb = reinterpret_cast<const float4*>(x + (size_t)gb * gm.HW);
+    const int n4 = gm.HW / 4;
+    const float inv = 1.0f / (float)gm.HW;
+    const float Ka = x[(size_t)ga * gm.HW];
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 v = xa[i];
+        const float a = v.x - Ka, b = v.y - Ka, cc = v.z - Ka, d = v.w - Ka;
+        s1 += (a + b) + (cc + d);
+        s2 += (a * a + b * b) + (cc * cc + d * d);
+    }
+    og_block_sum2(s1, s2, red);
+    float m1 = s1 * inv;
+    float var = fmaxf(s2 * inv - m1 * m1, 0.f);
+    const float mua = Ka + m1, ra = 1.0f / sqrtf(var + eps);
+    float mub = 0.f, rb = 0.f;
+    if (MODE == OG_NORM_GLU) {
+        const float Kb = x[(size_t)gb * gm.HW];
+        s1 = 0.f; s2 = 0.f;
+        for (int i = threadIdx.x; i < n4; i += 256) {
+            const float4 v = xb[i];
+            const float a = v.x - Kb, b = v.y - Kb, cc = v.z - Kb, d = v.w - Kb;
+            s1 += (a + b) + (cc + d);
+            s2 += (a * a + b * b) + (cc * cc + d * d);
+        }
+        og_block_sum2(s1, s2, red);
+        m1 = s1 * inv;
+        var = fmaxf(s2 * inv - m1 * m1, 0.f);
+        mub = Kb + m1; rb = 1.0f / sqrtf(var + eps);
+    }
+    if (threadIdx.x == 0) {
+        mean[ga] = mua; rstd[ga] = ra;
+        if (MODE == OG_NORM_GLU) { mean[gb] = mub; rstd[gb] = rb; }
+    }
+    const float sa = ra, ta = -mua * ra, sb = rb, tb = -mub * rb;      // z = x*s + t
+    const float4* rp = residual ? reinterpret_cast<const float4*>(residual + (size_t)plane * gm.HW) : nullptr;
+    float4* yp = reinterpret_cast<float4*>(y + (size_t)plane * gm.HW);
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 a = xa[i];
+        const float z[4] = {a.x * sa + ta, a.y * sa + ta, a.z * sa + ta, a.w * sa + ta};
+        float v[4];
+        if (MODE == OG_NORM_GLU) {
+            const float4 b = xb[i];
+            const float zb[4] = {b.x * sb + tb, b.y * sb + tb, b.z * sb + tb, b.w * sb + tb};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = z[j] * og_sigmoid(zb[j]);
+        } else if (MODE == OG_NORM_LRELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = z[j] > 0.f ? z[j] : 0.2f * z[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = z[j];
+        }
+        if (rp) { const float4 r = rp[i]; v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+        yp[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void in_bwd_fused_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+    const float* __restrict__ rstd, float* __restrict__ dx, NormGeom gm) {
+    __shared__ float red[8];
+    const int Co = MODE == OG_NORM_GLU ? gm.C / 2 : gm.C;
+    const int plane = blockIdx.x;
+    const int n = plane / Co;
+    const int c = plane - n * Co;
+    const int ga = n * gm.C + c, gb = ga + Co;
+    const float inv_cnt = 1.0f / (float)gm.HW;
+    const float ma = mean[ga], ra = rstd[ga];
+    const float mb = MODE == OG_NORM_GLU ? mean[gb] : 0.f, rb = MODE == OG_NORM_GLU ? rstd[gb] : 0.f;
+    const float4* xa = reinterpret_cast<const float4*>(x + (size_t)ga * gm.HW);
+    const float4* xb = reinterpret_cast<const float4*>(x + (size_t)gb * gm.HW);
+    const float4* dp = reinterpret_cast<const float4*>(dy + (size_t)plane * gm.HW);
+    float4* oa = reinterpret_cast<float4*>(dx + (size_t)ga * gm.HW);
+    float4* ob = reinterpret_cast<float4*>(dx + (size_t)gb * gm.HW);
+    const int n4 = gm.HW / 4;
+    float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 va = xa[i];
+        const float4 vb = MODE == OG_NORM_GLU ? xb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 vd = dp[i];
+        const float xs[4] = {va.x, va.y, va.z, va.w}, ys[4] = {vb.x, vb.y, vb.z, vb.w}, ds[4] = {vd.x, vd.y, vd.z, vd.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float dza, xha, dzb, xhb;
+            norm_dz_pair<MODE>(xs[j], ys[j], ds[j], ma, ra, mb, rb, 1.f, 0.f, 1.f, 0.f, false, dza, xha, dzb, xhb);
+            a1 += dza; a2 += dza * xha;
+            if (MODE == OG_NORM_GLU) { b1 += dzb; b2 += dzb * xhb; }
+        }
+    }
+    og_block_sum2(a1, a2, red);
+    if (MODE == OG_NORM_GLU) og_block_sum2(b1, b2, red);
+    const float ka1 = a1 * inv_cnt, ka2 = a2 * inv_cnt, kb1 = b1 * inv_cnt, kb2 = b2 * inv_cnt;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 va = xa[i];
+        const float4 vb = MODE == OG_NORM_GLU ? xb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 vd = dp[i];
+        const float xs[4] = {va.x, va.y, va.z, va.w}, ys[4] = {vb.x, vb.y, vb.z, vb.w}, ds[4] = {vd.x, vd.y, vd.z, vd.w};
+        float ra4[4], rb4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float dza, xha, dzb, xhb;
+            norm_dz_pair<MODE>(xs[j], ys[j], ds[j], ma, ra, mb, rb, 1.f, 0.f, 1.f, 0.f, false, dza, xha, dzb, xhb);
+            ra4[j] = ra * (dza - ka1 - xha * ka2);
+            rb4[j] = rb * (dzb - kb1 - xhb * kb2);
+        }
+        oa[i] = make_float4(ra4[0], ra4[1], ra4[2], ra4[3]);
+        if (MODE == OG_NORM_GLU) ob[i] = make_float4(rb4[0], rb4[1], rb4[2], rb4[3]);
+    }
+}
+
 // dgamma[c] = bsums[2c+1], dbeta[c] = bsums[2c]   (BatchNorm only)
 __global__ void norm_affine_grad_kernel(const float* __restrict__ bsums, float* __restrict__ dgamma,
                                         float* __restrict__ dbeta, int C) {
@@ -432,6 +574,14 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
     if (threadIdx.x == 0 && e0 < e1) atomicAdd(&out[c], s);
 }
 
+#define OG_IN_FUSED_MAX 65536        // largest plane (elements) the one-kernel InstanceNorm takes: 256 KB, two passes
+#include <stdlib.h>
+static int og_norm_nofuse() {       // OG_NORM_NOFUSE=1: the three-kernel path everywhere (A/B, debugging)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OG_NORM_NOFUSE"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v;
+}
+
 static inline int norm_splits(int G, long per_group) {
     // aim for >= 4 workgroups per CU overall, >= 1024 elements per workgroup
     long want = (256L * 4 + G - 1) / G;
@@ -460,10 +610,21 @@ int objgan_norm_forward(const float* x, float* y, const float* residual,
     NormGeom gm{N, C, HW, per_channel};
     const int G = per_channel ? C : N * C;
     const long per_group = per_channel ? (long)N * HW : HW;
-    hipMemsetAsync(sums, 0, sizeof(float) * 2 * G, s);
     const bool planes = (HW % 4 == 0) && HW >= 256 && (long)N * C < 2000000;
     const int chunks = og_cdiv(HW, OG_NORM_CHUNK);
     const int Co = mode == OG_NORM_GLU ? C / 2 : C;
+    if (planes && !per_channel && !gamma && HW <= OG_IN_FUSED_MAX && !og_norm_nofuse()) {
+        // InstanceNorm (no affine parameters on this path): one workgroup owns its plane(s) end to end
+        dim3 grid(N * Co);
+        if (mode == OG_NORM_GLU)
+            hipLaunchKernelGGL((in_fwd_fused_kernel<OG_NORM_GLU>), grid, dim3(256), 0, s, x, residual, y, mean, rstd, gm, eps);
+        else if (mode == OG_NORM_LRELU)
+            hipLaunchKernelGGL((in_fwd_fused_kernel<OG_NORM_LRELU>), grid, dim3(256), 0, s, x, residual, y, mean, rstd, gm, eps);
+        else
+            hipLaunchKernelGGL((in_fwd_fused_kernel<OG_NORM_NONE>), grid, dim3(256), 0, s, x, residual, y, mean, rstd, gm, eps);
+        return og_launch_status();
+    }
+    hipMemsetAsync(sums, 0, sizeof(float) * 2 * G, s);
     if (planes) {
         hipLaunchKernelGGL(norm_stats_plane_kernel, dim3(N * C, chunks), dim3(256), 0, s, x, sums, gm);
     } else {
@@ -528,8 +689,19 @@ int objgan_norm_backward(const float* x, const float* dy, const float* mean, con
     NormGeom gm{N, C, HW, per_channel};
     const int G = per_channel ? C : N * C;
     const long per_group = per_channel ? (long)N * HW : HW;
-    hipMemsetAsync(bsums, 0, sizeof(float) * 2 * G, s);
     const bool planes = (HW % 4 == 0) && HW >= 256 && (long)N * C < 2000000;
+    if (planes && !per_channel && !gamma && HW <= OG_IN_FUSED_MAX && !og_norm_nofuse()) {
+        const int Co = mode == OG_NORM_GLU ? C / 2 : C;
+        dim3 grid(N * Co);
+        if (mode == OG_NORM_GLU)
+            hipLaunchKernelGGL((in_bwd_fused_kernel<OG_NORM_GLU>), grid, dim3(256), 0, s, x, dy, mean, rstd, dx, gm);
+        else if (mode == OG_NORM_LRELU)
+            hipLaunchKernelGGL((in_bwd_fused_kernel<OG_NORM_LRELU>), grid, dim3(256), 0, s, x, dy, mean, rstd, dx, gm);
+        else
+            hipLaunchKernelGGL((in_bwd_fused_kernel<OG_NORM_NONE>), grid, dim3(256), 0, s, x, dy, mean, rstd, dx, gm);
+        return og_launch_status();
+    }
+    hipMemsetAsync(bsums, 0, sizeof(float) * 2 * G, s);
     if (planes) {
         const int Co = mode == OG_NORM_GLU ? C / 2 : C;
         dim3 grid(N * Co, og_cdiv(HW, OG_NORM_CHUNK));
