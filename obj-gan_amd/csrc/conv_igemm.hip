@@ -909,34 +909,46 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
     for (int j = 0; j < (XR > 0 ? XR : 1); ++j) accx[j] = 0.f;
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if ((kt + 1) < nk) store_step(cur ^ 1);      // two-deep register -> LDS pipeline
-        if ((kt + 2) < nk) load_step();
         const float* Tl = lds + cur * TILE;
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(Tl + b_rd);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(Tl + b_rd + 4);
-        f32x4 a0[TM], a1[TM];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            a0[i] = *reinterpret_cast<const f32x4*>(Tl + a_rd + i * 32 * LD);
-            a1[i] = *reinterpret_cast<const f32x4*>(Tl + a_rd + i * 32 * LD + 4);
-        }
         if (BF) {           // bf16 inputs (RNE of the fp32 tiles), one 32x32x16 MFMA per row group and K step
+            if ((kt + 1) < nk) store_step(cur ^ 1);      // two-deep register -> LDS pipeline
+            if ((kt + 2) < nk) load_step();
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(Tl + b_rd);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(Tl + b_rd + 4);
             bf16x8 bq;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { bq[j] = (__bf16)b0[j]; bq[4 + j] = (__bf16)b1[j]; }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(Tl + a_rd + i * 32 * LD);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(Tl + a_rd + i * 32 * LD + 4);
                 bf16x8 aq;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { aq[j] = (__bf16)a0[i][j]; aq[4 + j] = (__bf16)a1[i][j]; }
+                for (int j = 0; j < 4; ++j) { aq[j] = (__bf16)x0[j]; aq[4 + j] = (__bf16)x1[j]; }
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, bq, acc[i], 0, 0, 0);
             }
         } else {
+            // fp32: the step's 8*TM MFMAs in two halves with the refill of the pipeline BETWEEN them --
+            // LDS stores of the next tile, ~130 VALU instructions of gather addressing, 11 global loads.
+            // Issue is in order: placed in front of the MFMAs (as the first version had it) that work
+            // is exposed every step (98 TFLOP/s); behind the first half it runs in their shadow.
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(Tl + b_rd);
+            f32x4 a0[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a0[i] = *reinterpret_cast<const f32x4*>(Tl + a_rd + i * 32 * LD);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][kk], b0[kk], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if ((kt + 1) < nk) store_step(cur ^ 1);      // two-deep register -> LDS pipeline
+            if ((kt + 2) < nk) load_step();
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(Tl + b_rd + 4);
+            f32x4 a1[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a1[i] = *reinterpret_cast<const f32x4*>(Tl + a_rd + i * 32 * LD + 4);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll

@@ -230,24 +230,55 @@ __global__ __launch_bounds__(256) void norm_stats_plane_kernel(const float* __re
     }
 }
 
+// Statistics of group g from its shifted sums (what norm_finalize_kernel computes); when `fin.sums` is set
+// the apply kernel does it itself and the workgroup of image 0 / chunk 0 publishes mean, rstd and the
+// BatchNorm running statistics -- one launch less per layer.
+struct NormFin { const float* sums; float* mean_out; float* rstd_out; float* running_mean; float* running_var;
+                 float eps, momentum; };
+
+__device__ __forceinline__ void og_group_stats(const float* __restrict__ x, const NormFin& fin, const NormGeom& gm,
+                                               int g, bool publish, float& mu, float& rs) {
+    const float cnt = gm.per_channel ? (float)gm.N * gm.HW : (float)gm.HW;
+    const float K = x[(size_t)g * gm.HW];
+    const float m1 = fin.sums[2 * g] / cnt;
+    float var = fin.sums[2 * g + 1] / cnt - m1 * m1;
+    var = fmaxf(var, 0.f);
+    mu = K + m1;
+    rs = 1.0f / sqrtf(var + fin.eps);
+    if (publish && threadIdx.x == 0) {
+        fin.mean_out[g] = mu;
+        fin.rstd_out[g] = rs;
+        if (fin.running_mean) {
+            const float unbiased = cnt > 1.f ? var * cnt / (cnt - 1.f) : var;
+            fin.running_mean[g] = (1.f - fin.momentum) * fin.running_mean[g] + fin.momentum * mu;
+            fin.running_var[g] = (1.f - fin.momentum) * fin.running_var[g] + fin.momentum * unbiased;
+        }
+    }
+}
+
 // grid = (N*Co, chunks)
 template <int MODE>
 __global__ __launch_bounds__(256) void norm_apply_plane_kernel(
     const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ residual, float* __restrict__ y, NormGeom gm) {
+    const float* __restrict__ residual, float* __restrict__ y, NormGeom gm, NormFin fin) {
     const int Co = MODE == OG_NORM_GLU ? gm.C / 2 : gm.C;
     const int plane = blockIdx.x;                       // n*Co + c
     const int n = plane / Co;
     const int c = plane - n * Co;
     const int ga = gm.per_channel ? c : n * gm.C + c;
-    float sa = rstd[ga], ta = -mean[ga] * sa;           // z = x*sa + ta
+    const bool publish = blockIdx.y == 0 && (!gm.per_channel || n == 0);
+    float mua, rsa;
+    if (fin.sums) og_group_stats(x, fin, gm, ga, publish, mua, rsa); else { mua = mean[ga]; rsa = rstd[ga]; }
+    float sa = rsa, ta = -mua * sa;                     // z = x*sa + ta
     if (gamma) { ta = ta * gamma[c] + beta[c]; sa *= gamma[c]; }
     float sb = 0.f, tb = 0.f;
     if (MODE == OG_NORM_GLU) {
         const int cb = c + Co;
         const int gb = gm.per_channel ? cb : n * gm.C + cb;
-        sb = rstd[gb]; tb = -mean[gb] * sb;
+        float mub, rsb;
+        if (fin.sums) og_group_stats(x, fin, gm, gb, publish, mub, rsb); else { mub = mean[gb]; rsb = rstd[gb]; }
+        sb = rsb; tb = -mub * sb;
         if (gamma) { tb = tb * gamma[cb] + beta[cb]; sb *= gamma[cb]; }
     }
     const float4* xa = reinterpret_cast<const float4*>(x + ((size_t)n * gm.C + c) * gm.HW);
@@ -347,7 +378,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void norm_bwd_apply_plane_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ bsums, float* __restrict__ dx, NormGeom gm) {
+    const float* __restrict__ bsums, float* __restrict__ dx, NormGeom gm,
+    float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int Co = MODE == OG_NORM_GLU ? gm.C / 2 : gm.C;
     const int plane = blockIdx.x;
     const int n = plane / Co;
@@ -357,6 +389,11 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_plane_kernel(
     const int gb = gm.per_channel ? cb : n * gm.C + cb;
     const bool affine = gamma != nullptr;
     const float inv_cnt = 1.0f / (gm.per_channel ? (float)gm.N * gm.HW : (float)gm.HW);
+    // BatchNorm parameter gradients (dgamma = sum dz*xhat, dbeta = sum dz): published by image 0 / chunk 0
+    if (dgamma && gm.per_channel && n == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        dbeta[c] = bsums[2 * c]; dgamma[c] = bsums[2 * c + 1];
+        if (MODE == OG_NORM_GLU) { dbeta[cb] = bsums[2 * cb]; dgamma[cb] = bsums[2 * cb + 1]; }
+    }
     const float ma = mean[ga], ra = rstd[ga];
     const float mb = MODE == OG_NORM_GLU ? mean[gb] : 0.f, rb = MODE == OG_NORM_GLU ? rstd[gb] : 0.f;
     const float gaa = affine ? gamma[c] : 1.f, baa = affine ? beta[c] : 0.f;
@@ -631,18 +668,19 @@ int objgan_norm_forward(const float* x, float* y, const float* residual,
         dim3 grid(G, norm_splits(G, per_group));
         hipLaunchKernelGGL(norm_stats_kernel, grid, dim3(256), 0, s, x, sums, gm);
     }
-    hipLaunchKernelGGL(norm_finalize_kernel, dim3(og_cdiv(G, 256)), dim3(256), 0, s, x, sums, mean,
-                       rstd, running_mean, running_var, gm, G, eps, momentum);
     if (planes) {
         dim3 grid(N * Co, chunks);
+        const NormFin fin{sums, mean, rstd, running_mean, running_var, eps, momentum};
         if (mode == OG_NORM_GLU)
-            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_GLU>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm);
+            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_GLU>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm, fin);
         else if (mode == OG_NORM_LRELU)
-            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_LRELU>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm);
+            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_LRELU>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm, fin);
         else
-            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_NONE>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm);
+            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_NONE>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm, fin);
         return og_launch_status();
     }
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3(og_cdiv(G, 256)), dim3(256), 0, s, x, sums, mean,
+                       rstd, running_mean, running_var, gm, G, eps, momentum);
     const long total = (long)N * Co * HW;
     hipLaunchKernelGGL(norm_apply_kernel, dim3(og_stream_grid(total, 256)), dim3(256), 0, s, x, mean,
                        rstd, gamma, beta, residual, y, gm, mode);
@@ -662,12 +700,13 @@ int objgan_norm_apply(const float* x, float* y, const float* residual, const flo
     const int Co = mode == OG_NORM_GLU ? C / 2 : C;
     if ((HW % 4 == 0) && HW >= 256 && (long)N * C < 2000000) {
         dim3 grid(N * Co, og_cdiv(HW, OG_NORM_CHUNK));
+        const NormFin fin{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f};
         if (mode == OG_NORM_GLU)
-            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_GLU>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm);
+            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_GLU>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm, fin);
         else if (mode == OG_NORM_LRELU)
-            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_LRELU>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm);
+            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_LRELU>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm, fin);
         else
-            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_NONE>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm);
+            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_NONE>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm, fin);
         return og_launch_status();
     }
     const long total = (long)N * Co * HW;
@@ -709,9 +748,10 @@ int objgan_norm_backward(const float* x, const float* dy, const float* mean, con
         hipLaunchKernelGGL((norm_bwd_stats_plane_kernel<MODE>), grid, dim3(256), 0, s, x, dy, mean, rstd,   \
                            gamma, beta, bsums, gm);                                                         \
         hipLaunchKernelGGL((norm_bwd_apply_plane_kernel<MODE>), grid, dim3(256), 0, s, x, dy, mean, rstd,   \
-                           gamma, beta, bsums, dx, gm);
+                           gamma, beta, bsums, dx, gm, dgamma, dbeta);
         if (mode == OG_NORM_GLU) { OG_NB(OG_NORM_GLU) } else if (mode == OG_NORM_LRELU) { OG_NB(OG_NORM_LRELU) } else { OG_NB(OG_NORM_NONE) }
 #undef OG_NB
+        return og_launch_status();
     } else {
         dim3 grid(G, norm_splits(G, per_group));
         hipLaunchKernelGGL(norm_bwd_stats_kernel, grid, dim3(256), 0, s, x, dy, mean, rstd, gamma, beta,
