@@ -1149,7 +1149,12 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
         ad[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, adir, kt * (BK * 4), 0));
         ad[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, adir + (BF ? 32u : 16u), kt * (BK * 4), 0));
     };
-    auto mma = [&](const float (&rb)[NB], const f32x4 (&ad)[2], int cur) {
+    // `mid`: the refill of the software pipeline (LDS store of the next row tile, next pixel gather, next
+    // row-tile load).  Issue is in order, so work placed in FRONT of a step's MFMAs is exposed every step;
+    // in the fp32 LDS form it goes behind the first TM MFMAs and runs in the shadow of the rest (r02:
+    // weight-gradient kernel 110 -> 119 TFLOP/s with the same move).
+    auto mma = [&](const float (&rb)[NB], const f32x4 (&ad)[2], int cur, auto&& mid) {
+        if (BF || !ALDS) mid();
         if (BF) {
             bf16x8 bq[2];
 #pragma unroll
@@ -1184,7 +1189,13 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
                 a1[i] = *reinterpret_cast<const f32x4*>(T + a_rd + i * 32 * LD + 4);
             }
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+            for (int i = 0; i < TM; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][0], rb[0], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mid();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 1; kk < 4; ++kk)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][kk], rb[kk], acc[i], 0, 0, 0);
@@ -1232,33 +1243,35 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
         load_adir(ad1, kt0 + 1); load_b(rb1);
         for (; kt + 2 < nk; kt += 3) {
             load_adir(ad2, kt + 2); load_b(rb2);
-            mma(rb0, ad0, 0);
+            mma(rb0, ad0, 0, [] {});
             load_adir(ad0, kt + 3); load_b(rb0);
-            mma(rb1, ad1, 0);
+            mma(rb1, ad1, 0, [] {});
             load_adir(ad1, kt + 4); load_b(rb1);
-            mma(rb2, ad2, 0);
+            mma(rb2, ad2, 0, [] {});
         }
-        if (kt < nk) mma(rb0, ad0, 0);
-        if (kt + 1 < nk) mma(rb1, ad1, 0);
+        if (kt < nk) mma(rb0, ad0, 0, [] {});
+        if (kt + 1 < nk) mma(rb1, ad1, 0, [] {});
         kt = nk;
     }
     for (; kt + 1 < nk; kt += 2) {
-        if (ALDS) store_a(cur ^ 1); else load_adir(ad1, kt + 1);
-        load_b(rb1);
-        if (ALDS && kt + 2 < nk) load_a(kt + 2);
-        mma(rb0, ad0, cur);
+        mma(rb0, ad0, cur, [&]() {
+            if (ALDS) store_a(cur ^ 1); else load_adir(ad1, kt + 1);
+            load_b(rb1);
+            if (ALDS && kt + 2 < nk) load_a(kt + 2);
+        });
         if (ALDS) __syncthreads();
         cur ^= 1;
-        if (kt + 2 < nk) {
-            if (ALDS) store_a(cur ^ 1); else load_adir(ad0, kt + 2);
-            load_b(rb0);
-        }
-        if (ALDS && kt + 3 < nk) load_a(kt + 3);
-        mma(rb1, ad1, cur);
+        mma(rb1, ad1, cur, [&]() {
+            if (kt + 2 < nk) {
+                if (ALDS) store_a(cur ^ 1); else load_adir(ad0, kt + 2);
+                load_b(rb0);
+            }
+            if (ALDS && kt + 3 < nk) load_a(kt + 3);
+        });
         if (ALDS) __syncthreads();
         cur ^= 1;
     }
-    if (kt < nk) mma(rb0, ad0, cur);                   // odd step count: last step
+    if (kt < nk) mma(rb0, ad0, cur, [] {});            // odd step count: last step
 
     // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
     if (!pix_ok) return;
@@ -1471,7 +1484,8 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, con
     for (int j = 0; j < (XR > 0 ? XR : 1); ++j) accx[j] = 0.f;
     float rb0[8], rb1[8];
     f32x4 ad0[2], ad1[2];
-    auto mma = [&](const float (&rb)[8], const f32x4 (&ad)[2], int cur) {
+    auto mma = [&](const float (&rb)[8], const f32x4 (&ad)[2], int cur, auto&& mid) {      // mid: see conv_igemm3_kernel
+        if (BF || !ALDS) mid();
         if (BF) {
             bf16x8 bq;
 #pragma unroll
@@ -1502,7 +1516,13 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, con
                 a1[i] = *reinterpret_cast<const f32x4*>(Tl + a_rd + i * 32 * LD + 4);
             }
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+            for (int i = 0; i < TM; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][0], rb[0], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mid();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 1; kk < 4; ++kk)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][kk], rb[kk], acc[i], 0, 0, 0);
@@ -1545,22 +1565,24 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, con
     int cur = 0;
     int kt = 0;                                       // two steps per trip, see conv_igemm3_kernel
     for (; kt + 1 < nk; kt += 2) {
-        if (ALDS) store_a(cur ^ 1); else load_adir(ad1);
-        load_b(rb1);
-        if (ALDS && kt + 2 < nk) load_a();
-        mma(rb0, ad0, cur);
+        mma(rb0, ad0, cur, [&]() {
+            if (ALDS) store_a(cur ^ 1); else load_adir(ad1);
+            load_b(rb1);
+            if (ALDS && kt + 2 < nk) load_a();
+        });
         if (ALDS) __syncthreads();
         cur ^= 1;
-        if (kt + 2 < nk) {
-            if (ALDS) store_a(cur ^ 1); else load_adir(ad0);
-            load_b(rb0);
-        }
-        if (ALDS && kt + 3 < nk) load_a();
-        mma(rb1, ad1, cur);
+        mma(rb1, ad1, cur, [&]() {
+            if (kt + 2 < nk) {
+                if (ALDS) store_a(cur ^ 1); else load_adir(ad0);
+                load_b(rb0);
+            }
+            if (ALDS && kt + 3 < nk) load_a();
+        });
         if (ALDS) __syncthreads();
         cur ^= 1;
     }
-    if (kt < nk) mma(rb0, ad0, cur);
+    if (kt < nk) mma(rb0, ad0, cur, [] {});
 
     if (XR > 0 && has_x) {
 #pragma unroll
