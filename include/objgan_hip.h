@@ -146,6 +146,11 @@ int objgan_bilinear_backward(const float* dy, float* dx, long planes, int ih, in
                              void* stream);
 int objgan_sum2x2(const float* dy, float* dx, long planes, int h, int w, void* stream);
 int objgan_reflect_fold(const float* dxp, float* dx, long planes, int h, int w, void* stream);
+/* nn.BCELoss()(p, constant target t) on the small probability maps of the discriminator heads (reference
+ * miscc/losses.py:182-204 and every other adversarial term): mean over n elements -> out[0]; log clamped at
+ * -100 and gradient (p - t) / max(p (1 - p), 1e-12) like torch.  g: the upstream scalar gradient (device). */
+int objgan_bce_const_forward(const float* p, float* out, int n, float t, void* stream);
+int objgan_bce_const_backward(const float* p, const float* g, float* dp, int n, float t, void* stream);
 /* Batched re-packing of cached filter banks.  A job is an opaque blob (objgan_conv_pack_job_bytes() bytes) that
  * says "pack w into wt exactly as objgan_conv_igemm -- or phase `phase` of objgan_conv_dgrad_s2_phases --
  * does for these arguments"; a caller that keeps packed banks (wt_packed = 1) stores the blobs of a network

@@ -446,6 +446,33 @@ __global__ __launch_bounds__(256) void bmm_strided_kernel(const BmmArgs a) {
         }
 }
 
+// ---- binary cross-entropy against a constant target -------------------------------------------------------
+// Every adversarial term of the step is nn.BCELoss()(sigmoid output, ones / zeros) on B x 1 x k x k
+// probabilities (reference losses.py:182-204, 230-246, ...: ~60 per step).  torch spends a fill (the label
+// tensor), the loss kernel and a mean on each, and three more launches on the way back; here it is one small
+// workgroup each way.  Same arithmetic as torch: log clamped at -100, backward (p - t) / max(p (1 - p), 1e-12).
+__global__ __launch_bounds__(256) void bce_const_fwd_kernel(const float* __restrict__ p, float* __restrict__ out,
+                                                            int n, float t) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float v = p[i];
+        const float l1 = fmaxf(logf(v), -100.f), l0 = fmaxf(logf(1.f - v), -100.f);
+        s -= t * l1 + (1.f - t) * l0;
+    }
+    s = og_block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = s / (float)n;
+}
+
+__global__ __launch_bounds__(256) void bce_const_bwd_kernel(const float* __restrict__ p, const float* __restrict__ g,
+                                                            float* __restrict__ dp, int n, float t) {
+    const float go = g[0] / (float)n;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float v = p[i];
+        dp[i] = go * (v - t) / fmaxf((1.f - v) * v, 1e-12f);
+    }
+}
+
 extern "C" {
 
 int objgan_attn_general_forward(const float* x, const float* src, const unsigned char* mask,
@@ -567,6 +594,22 @@ int objgan_bmm_strided(const float* A, const float* B, float* C, int batch, int 
     BmmArgs a = {A, B, C, M, N, K, sab, sam, sak, sbb, sbk, sbn, scb, scm, scn};
     dim3 grid(og_cdiv(N, 64), og_cdiv(M, 64), batch);
     hipLaunchKernelGGL(bmm_strided_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    return og_launch_status();
+}
+
+// mean BCE of n probabilities against the constant target t (0 or 1): out[0]; and its gradient g[0] * d/dp.
+int objgan_bce_const_forward(const float* p, float* out, int n, float t, void* stream) {
+    OG_ENTRY();
+    if (n <= 0) return OG_BAD_ARGS;
+    hipLaunchKernelGGL(bce_const_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, out, n, t);
+    return og_launch_status();
+}
+
+int objgan_bce_const_backward(const float* p, const float* g, float* dp, int n, float t, void* stream) {
+    OG_ENTRY();
+    if (n <= 0) return OG_OK;
+    hipLaunchKernelGGL(bce_const_bwd_kernel, dim3(og_cdiv(n, 256) > 64 ? 64 : og_cdiv(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, p, g, dp, n, t);
     return og_launch_status();
 }
 

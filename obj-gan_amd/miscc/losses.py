@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from miscc.config import cfg
-from miscc.utils import permute_seg, feat_select, take_rows
+from miscc.utils import permute_seg, permuted_valid_seg, feat_select, take_rows  # noqa: F401
 from GlobalAttention import func_attention  # noqa: F401  (API parity)
 from objgan_hip import ops
 
@@ -24,7 +24,8 @@ def _net(m):
 
 
 def _bce(prob, target_value):
-    return F.binary_cross_entropy(prob, torch.full_like(prob, float(target_value)))
+    """nn.BCELoss()(prob, labels) with constant labels (reference losses.py:182-204)"""
+    return ops.bce_const(prob, float(target_value))
 
 
 def _class_mask(class_ids, batch_size, device):
@@ -153,11 +154,11 @@ def shpD_loss(netShpD, real_imgs, fake_imgs, seg_conditions, rois, num_rois):
     s_code = net.encode_seg(seg_conditions)
     real_features = netShpD(real_imgs, seg_conditions, s_code=s_code)
     fake_features = netShpD(fake_imgs.detach(), seg_conditions, s_code=s_code)
-    fake_seg, valid = permute_seg(seg_conditions, rois, num_rois)
+    wrong_seg, valid = permuted_valid_seg(seg_conditions, rois, num_rois)
     errD = _bce(net.UNCOND_DNET(real_features), 1)
     fake_err = _bce(net.UNCOND_DNET(fake_features), 0)
     if len(valid) > 0:
-        wrong_features = netShpD(real_imgs[valid], fake_seg[valid])
+        wrong_features = netShpD(real_imgs[valid], wrong_seg)
         wrong_err = _bce(net.UNCOND_DNET(wrong_features), 0)
         return errD + (fake_err + wrong_err) / 2.
     return errD + fake_err
@@ -165,8 +166,12 @@ def shpD_loss(netShpD, real_imgs, fake_imgs, seg_conditions, rois, num_rois):
 
 def _obj_conditions(class_table, classes, bt_c_codes, count=None):
     """[class embedding | bottom-up context] per selected box."""
-    idx = classes if count is None else classes[:count]
-    emb = class_table[idx.to(class_table.device)]
+    idx = getattr(classes, "_og_dev", None)          # device copy made by feat_select (one upload for all indices)
+    if idx is None:
+        idx = classes.to(class_table.device)
+    if count is not None:
+        idx = idx[:count]
+    emb = class_table[idx]
     return torch.cat((emb, bt_c_codes), dim=1)
 
 
@@ -180,11 +185,11 @@ def objD_loss(netObjD, real_imgs, fake_imgs, seg_conditions, raw_conditions, raw
     fake_pooled = netObjD(fake_imgs.detach(), seg_conditions, fm_rois, num_rois, s_code=s_code)
     fake_features, _, _ = feat_select(fake_pooled, raw_bt_c_codes, fm_rois, num_rois,
                                       is_large_scale=is_large_scale)
-    fake_seg, valid = permute_seg(seg_conditions, fm_rois, num_rois)
+    wrong_seg, valid = permuted_valid_seg(seg_conditions, fm_rois, num_rois)
     classes2 = []
     if len(valid) > 0:
         rois_v, num_v = take_rows(fm_rois, valid), take_rows(num_rois, valid)      # host copies stay attached
-        pooled2 = netObjD(real_imgs[valid], fake_seg[valid], rois_v, num_v)
+        pooled2 = netObjD(real_imgs[valid], wrong_seg, rois_v, num_v)
         fake_features2, classes2, bt_c_codes2 = feat_select(pooled2, raw_bt_c_codes, rois_v,
                                                             num_v,
                                                             is_large_scale=is_large_scale)

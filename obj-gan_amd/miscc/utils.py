@@ -87,15 +87,16 @@ def pprocess_bt_attns(fmaps, ih, iw, bt_mask):
 
 
 # ---- class-permuted layout maps ("wrong shape" negatives) ------------------------------------------
-def permute_seg(seg_conditions, rois, num_rois):
-    """Shuffle the class channels present in each sample's layout map (reference utils.py:445-462).
-    Uses python's `random` exactly like the reference, so a seeded run draws the same permutations.
-    Returns (new_seg_conditions, valid_mask) with valid_mask the list of changed sample indices."""
-    new_seg = seg_conditions.clone()
+def _class_permutations(C, rois, num_rois):
+    """Host part of permute_seg: (perm [B, C] int64 channel map -- identity except for the shuffled class
+    channels of the changed samples --, valid_mask).  Draws from python's `random` exactly like the
+    reference loop (utils.py:445-462), so a seeded run shuffles identically."""
     rois_np = _host(rois)
     nr = _host(num_rois).tolist()
+    B = len(nr)
+    perm = np.tile(np.arange(C, dtype=np.int64), (B, 1))
     valid_mask = []
-    for b in range(seg_conditions.size(0)):
+    for b in range(B):
         n = int(nr[b])
         if n == 0:
             continue
@@ -104,8 +105,32 @@ def permute_seg(seg_conditions, rois, num_rois):
         random.shuffle(shuffled)
         if present != shuffled:
             valid_mask.append(b)
-            new_seg[b, present] = seg_conditions[b, shuffled]
+            perm[b, present] = shuffled
+    return perm, valid_mask
+
+
+def permute_seg(seg_conditions, rois, num_rois):
+    """Shuffle the class channels present in each sample's layout map (reference utils.py:445-462).
+    Returns (new_seg_conditions, valid_mask) with valid_mask the list of changed sample indices.  One
+    gather for the whole batch (the reference copies the map and then moves channels sample by sample)."""
+    B, C = seg_conditions.size(0), seg_conditions.size(1)
+    perm, valid_mask = _class_permutations(C, rois, num_rois)
+    dev = seg_conditions.device
+    rows = torch.arange(B, device=dev).unsqueeze(1)
+    new_seg = seg_conditions[rows, torch.from_numpy(perm).to(dev)]
     return new_seg, valid_mask
+
+
+def permuted_valid_seg(seg_conditions, rois, num_rois):
+    """(permuted layout maps of the CHANGED samples only [len(valid), C, H, W], valid_mask): what the
+    discriminator losses consume -- permute_seg(...)[0][valid_mask] without building the unchanged rows."""
+    C = seg_conditions.size(1)
+    perm, valid_mask = _class_permutations(C, rois, num_rois)
+    if not valid_mask:
+        return None, valid_mask
+    dev = seg_conditions.device
+    rows = torch.as_tensor(valid_mask, dtype=torch.long).unsqueeze(1).to(dev)
+    return seg_conditions[rows, torch.from_numpy(perm[valid_mask]).to(dev)], valid_mask
 
 
 def feat_select(pooled_feat, raw_bt_c_codes, fm_rois, num_rois, is_large_scale=False):
@@ -134,13 +159,17 @@ def feat_select(pooled_feat, raw_bt_c_codes, fm_rois, num_rois, is_large_scale=F
     if not sel_b:
         return [], [], []
     dev = pooled_feat.device
-    ib = torch.as_tensor(sel_b, dtype=torch.long, device=dev)
-    ir = torch.as_tensor(sel_r, dtype=torch.long, device=dev)
+    cls = np.concatenate(classes).astype(np.int64)
+    # one upload for the three index vectors (every small host->device copy stalls the enqueueing thread)
+    idx = torch.from_numpy(np.stack([np.asarray(sel_b, np.int64), np.asarray(sel_r, np.int64), cls])).to(dev)
+    ib, ir = idx[0], idx[1]
     x_code_rois = pooled_feat[ib, ir]
     # NB reference quirk (SURVEY.md trap 6): raw_bt_c_codes is indexed with the batch index of the
     # tensors passed in, also when those are a `valid_mask` subset of the batch.
     bt_c_codes = raw_bt_c_codes[ib.to(raw_bt_c_codes.device), ir.to(raw_bt_c_codes.device)]
-    classes = torch.from_numpy(np.concatenate(classes))
+    classes = torch.from_numpy(cls)
+    if dev.type != "cpu":
+        classes._og_dev = idx[2]
     return x_code_rois, classes, bt_c_codes
 
 
@@ -150,14 +179,14 @@ def form_clabels_feat(clabels_emb, rois, num_rois):
     nr = _host(num_rois).tolist()
     B = rois_np.shape[0]
     max_num_roi = int(np.amax(nr))
-    feat = torch.zeros((B, max_num_roi, clabels_emb.size(1)), dtype=clabels_emb.dtype,
-                       device=clabels_emb.device)
+    # one index table for the batch (-1 = empty slot), one upload, one gather
+    idx = np.full((B, max_num_roi), -1, np.int64)
     for i in range(B):
         n = int(nr[i])
-        if n == 0:
-            continue
-        cats = torch.as_tensor(rois_np[i, :n, 4].astype(np.int64), device=clabels_emb.device)
-        feat[i, :n] = clabels_emb[cats]
+        if n:
+            idx[i, :n] = rois_np[i, :n, 4].astype(np.int64)
+    idx_dev = torch.from_numpy(idx).to(clabels_emb.device)
+    feat = clabels_emb[idx_dev.clamp(min=0)] * (idx_dev >= 0).unsqueeze(2).to(clabels_emb.dtype)
     return feat.transpose(1, 2).unsqueeze(3)
 
 

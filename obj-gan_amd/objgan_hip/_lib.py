@@ -59,6 +59,8 @@ SIGNATURES = {
                              _c_int, _ptr, _c_int, _c_int, _c_int, _c_int],
     "objgan_conv_pack_job_phase": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _c_int, _c_int],
     "objgan_conv_pack_jobs_run": [_ptr, _c_int, _ptr],
+    "objgan_bce_const_forward": [_ptr, _ptr, _c_int, _c_float, _ptr],
+    "objgan_bce_const_backward": [_ptr, _ptr, _ptr, _c_int, _c_float, _ptr],
     "objgan_bmm_strided": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int] + [_c_long] * 9 + [_ptr],
     "objgan_lift_taps_forward": [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                  _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],

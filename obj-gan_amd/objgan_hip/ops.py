@@ -745,6 +745,32 @@ def bmm(A, B):
     return _BmmFn.apply(A, B)
 
 
+class _BceConstFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, prob, target):
+        _chk(prob)
+        prob = _c(prob)
+        out = torch.empty((), dtype=_F32, device=prob.device)
+        _lib.call("objgan_bce_const_forward", _p(prob), _p(out), prob.numel(), float(target), _stream())
+        ctx.save_for_backward(prob)
+        ctx.target = float(target)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (prob,) = ctx.saved_tensors
+        g = _c(g)
+        _chk(g)
+        dp = torch.empty_like(prob)
+        _lib.call("objgan_bce_const_backward", _p(prob), _p(g), _p(dp), prob.numel(), ctx.target, _stream())
+        return dp, None
+
+
+def bce_const(prob, target):
+    """F.binary_cross_entropy(prob, full_like(prob, target)) for target 0 / 1, one launch each way."""
+    return _BceConstFn.apply(prob, target)
+
+
 class _SoftmaxStridedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, dim, scale, lens, rowvalid):

@@ -535,6 +535,28 @@ def test_bmm_strided_matches_torch(dev):
         assert rel_l2(Cd, Cr) < 1e-5 and rel_l2(Ad.grad, Ar.grad) < 1e-5 and rel_l2(Bd.grad, Br.grad) < 1e-5
 
 
+def test_bce_const_matches_torch(dev):
+    """One-launch BCE against constant labels, incl. probabilities at 0 / 1 (log clamp at -100)."""
+    import torch.nn.functional as F
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    for shape in [(16, 1, 1, 1), (16, 1, 7, 7), (47, 1, 3, 3), (3000,)]:
+        p = torch.rand(shape, generator=g).clamp(1e-6, 1 - 1e-6)
+        p.view(-1)[0] = 1.0
+        p.view(-1)[-1] = 0.0
+        for t in (0.0, 1.0):
+            pr = p.clone().requires_grad_()
+            lr = F.binary_cross_entropy(pr, torch.full_like(pr, t))
+            (lr * 1.7).backward()
+            pd = p.to(dev).requires_grad_()
+            ld = ops.bce_const(pd, t)
+            (ld * 1.7).backward()
+            torch.cuda.synchronize()
+            assert abs(ld.item() - lr.item()) < 1e-5 * max(1.0, abs(lr.item())), (shape, t)
+            ok = torch.isfinite(pr.grad)
+            assert rel_l2(pd.grad.cpu()[ok], pr.grad[ok]) < 1e-5, (shape, t)
+
+
 def test_gated_adam_follows_the_device_flag(dev):
     """objgan_adam_step_gated: flag <= 0 leaves parameters, moments and the device step counter untouched;
     flag > 0 reproduces torch.optim.Adam step for step (bias corrections from the device counter)."""

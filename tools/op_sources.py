@@ -1,9 +1,8 @@
 #!/usr/bin/env python
-"""Where do the small torch-side launches of a training step come from?  Profiles ONE step with python
-stacks and aggregates the aten ops that launch fills / copies / adds by the innermost frame inside this repo.
+"""Which torch-side operators launch the small fills / copies / adds of a training step?  Profiles ONE step and
+prints the aten operators by call count with their input shapes (the shapes identify the call sites).
     python tools/op_sources.py > gpurun_out/op_sources.txt
 """
-import collections
 import os
 import sys
 
@@ -21,19 +20,14 @@ batch = synth_batch.make_batch(16, seed=1234, device=dev)
 for _ in range(2):
     tr.train_step(batch)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU], record_shapes=True) as prof:
     tr.train_step(batch)
     torch.cuda.synchronize()
-WATCH = ("aten::copy_", "aten::fill_", "aten::zero_", "aten::add_", "aten::add", "aten::mul", "aten::mul_",
-         "aten::cat", "aten::zeros", "aten::index", "aten::clone", "aten::contiguous", "aten::to", "aten::_to_copy",
-         "aten::sum", "aten::div", "aten::sub", "aten::select", "aten::index_select", "aten::gather", "aten::where")
-agg = collections.Counter()
-for ev in prof.events():
-    if ev.name not in WATCH or not ev.stack:
-        continue
-    frame = next((f for f in ev.stack if ROOT in f and "tools/op_sources" not in f), None)
-    if frame is None:
-        frame = "autograd engine / other: " + (ev.stack[0] if ev.stack else "?")
-    agg[(ev.name, frame.replace(ROOT + "/", ""))] += 1
-for (name, frame), n in agg.most_common(70):
-    print("%5d  %-18s %s" % (n, name, frame))
+rows = [e for e in prof.key_averages(group_by_input_shape=True)
+        if e.key.startswith("aten::") and e.key.split("::")[1] in (
+            "copy_", "fill_", "zero_", "add_", "add", "mul", "mul_", "cat", "zeros", "clone", "contiguous", "_to_copy",
+            "index", "index_put_", "sum", "div", "sub", "where", "masked_fill", "full_like", "zeros_like", "empty_like",
+            "select", "slice", "expand", "reshape", "view", "transpose", "sigmoid", "exp", "binary_cross_entropy")]
+rows.sort(key=lambda e: -e.count)
+for e in rows[:90]:
+    print("%5d  %-28s %s" % (e.count, e.key, str(e.input_shapes)[:150]))
