@@ -19,8 +19,8 @@ One JSON line is printed by rank 0: the contract fields plus
                 (events recorded by the library on the launch stream, in a second untimed pass so
                 that the headline carries no event overhead), against the fp32 MFMA peak;
                 traffic = HBM bytes per launch from the rocprofv3 --pmc passes kept in profiles/
-  cpu_baseline  the CPU oracle (oracle/torch_model.py, a port of the reference path) timed on ALL of this
-                host's cores at the BASELINE batch (1 warm-up + 1 timed step at batch 16; child process
+  cpu_baseline  the CPU oracle (oracle/torch_model.py, a port of the reference path) timed on this host's
+                physical cores at the BASELINE batch (1 warm-up + 1 timed step at batch 16; child process
                 with a hard time limit, batch-8 fallback)
 """
 import argparse
@@ -134,12 +134,14 @@ def _cpu_baseline_worker(sample_batch, threads, timed_steps, seed=1234):
         flush=True)
 
 
-def cpu_baseline(sample_batch=16, timed_steps=1, timeout_s=420):
-    """The oracle timed on ALL host cores at the BASELINE batch (1 warm-up + timed steps),
-    in a child process with a hard time limit so that the default bench run always finishes; if the
-    full-batch run does not fit the limit a batch-8 sample is reported instead."""
+def cpu_baseline(sample_batch=16, timed_steps=1, timeout_s=300):
+    """The oracle timed on the host's physical cores at the BASELINE batch (1 warm-up + timed
+    steps), in a child process with a hard time limit so that the default bench run always finishes; if
+    the full-batch run does not fit the limit a batch-8 sample is reported instead.  One thread per
+    PHYSICAL core: with all 256 hardware threads of the GPU box's two EPYC 9575F the same step did not
+    finish in 420 s (fork-join cost of the many small operators), with 128 it takes about a minute."""
     import subprocess
-    threads = max(1, os.cpu_count() or 1)
+    threads = max(1, min(128, (os.cpu_count() or 2) // 2))
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads),
                HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     note = ""
