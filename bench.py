@@ -119,22 +119,25 @@ def _cpu_baseline_worker(sample_batch, threads, timed_steps, seed=1234):
     ema = [p.detach().clone() for p in tm.params_of(sds["G"])]
     enc = torch_encoders.CpuImageEncoder(encoders.CNN_ENCODER(256, encoders.seeded_init_(encoders.inception_v3(), 1)).eval())
     batch = synth_batch.make_batch(sample_batch, seed=seed)
+
+    def report(dt, note):
+        print("CPU_BASELINE " + json.dumps(
+            {"value": round(sample_batch / dt, 4), "unit": "images/sec", "cores": threads, "kind": "port",
+             "cpu": _cpu_model(), "host_cores": os.cpu_count() or 1,
+             "sample": "full G+D step at batch %d (same networks, 256x256, fp32) on %d threads: %s"
+                       % (sample_batch, threads, note)}), flush=True)
     t0 = time.time()
     tm.train_step(sds, opts, ema, batch, image_encoder=enc)
     warm = time.time() - t0
+    report(warm, "first (un-warmed) step %.1f s" % warm)      # provisional: replaced by the timed steps below
     t0 = time.time()
     for _ in range(timed_steps):
         tm.train_step(sds, opts, ema, batch, image_encoder=enc)
     dt = (time.time() - t0) / max(1, timed_steps)
-    print("CPU_BASELINE " + json.dumps(
-        {"value": round(sample_batch / dt, 4), "unit": "images/sec", "cores": threads, "kind": "port",
-         "cpu": _cpu_model(), "host_cores": os.cpu_count() or 1,
-         "sample": "full G+D step at batch %d (same networks, 256x256, fp32): 1 warm-up (%.1f s) + %d timed "
-                   "step(s) of %.1f s each on %d threads" % (sample_batch, warm, timed_steps, dt, threads)}),
-        flush=True)
+    report(dt, "1 warm-up (%.1f s) + %d timed step(s) of %.1f s each" % (warm, timed_steps, dt))
 
 
-def cpu_baseline(sample_batch=16, timed_steps=1, timeout_s=300):
+def cpu_baseline(sample_batch=16, timed_steps=1, timeout_s=240):
     """The oracle timed on the host's physical cores at the BASELINE batch (1 warm-up + timed
     steps), in a child process with a hard time limit so that the default bench run always finishes; if
     the full-batch run does not fit the limit a batch-8 sample is reported instead.  One thread per
@@ -145,18 +148,25 @@ def cpu_baseline(sample_batch=16, timed_steps=1, timeout_s=300):
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads),
                HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     note = ""
-    for batch, limit in ((sample_batch, timeout_s), (8, timeout_s // 2)):
+    for batch, limit in ((sample_batch, timeout_s), (8, timeout_s // 3)):
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(batch), str(threads),
                str(timed_steps)]
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
         try:
-            out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
-                                 timeout=limit).stdout.decode(errors="replace")
-            for line in out.splitlines():
-                if line.startswith("CPU_BASELINE "):
-                    return json.loads(line[len("CPU_BASELINE "):])
-            note += "batch %d: worker produced no result; " % batch
+            out = proc.communicate(timeout=limit)[0]
         except subprocess.TimeoutExpired:
-            note += "batch %d: not finished within %d s on %d threads; " % (batch, limit, threads)
+            proc.kill()
+            out = proc.communicate()[0]
+            note += "batch %d: stopped at the %d s limit; " % (batch, limit)
+        last = None
+        for line in out.decode(errors="replace").splitlines():
+            if line.startswith("CPU_BASELINE "):
+                last = json.loads(line[len("CPU_BASELINE "):])
+        if last is not None:          # the timed result when it got that far, else the un-warmed first step
+            if note:
+                last["sample"] += " (" + note.strip() + ")"
+            return last
+        note += "batch %d: no step finished; " % batch
     return {"value": None, "unit": "images/sec", "cores": threads, "kind": "port", "cpu": _cpu_model(),
             "sample": note}
 
