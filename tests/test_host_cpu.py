@@ -1,6 +1,7 @@
 """Host-side logic of the conv wrappers that needs no GPU: the algebra of the phased upBlock
 convolution (ops._UpConv3x3Fn) with the three device kernels replaced by their torch CPU
 definitions, and the filter-bank caches."""
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -218,3 +219,30 @@ def test_main_cli_mirrors_the_reference_arguments(tmp_path):
         cfg.clear()
         for k, v in saved.items():
             cfg[k] = v
+
+
+def test_bench_gpus_n_starts_n_ranks_itself(monkeypatch):
+    """`python bench.py --gpus N` outside a launcher must start N ranks (one per GPU, RCCL) -- the round-1
+    bench silently ran one process: the re-exec goes through torch.distributed.run on 127.0.0.1
+    and hands the original flags on."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
