@@ -75,7 +75,12 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
                       int Tg, const int* dh, const int* dw, const int* src_tap,
                       int PH, int PW, int stride,
                       int OHf, int OWf, int osh, int osw, int ooh, int oow,
-                      int act, int y_prezeroed, int wt_packed, int math, void* stream);
+                      int act, int y_prezeroed, int wt_packed, int math, float* ring, void* stream);
+/* ring (may be NULL): data gradient of a ReflectionPad2d(1) convolution without the padded intermediate -- the
+ * GEMM runs over the padded pixel grid (PH = OHf + 2, PW = OWf + 2, y is the UNPADDED gradient), interior
+ * pixels are stored into y, the one-pixel border into ring [N*M][2*PW + 2*PH]; objgan_reflect_ring_fold then
+ * adds the border back at its mirror positions.  Only for calls objgan_conv_bank_layout classifies as 1. */
+int objgan_reflect_ring_fold(const float* ring, float* y, long planes, int H, int W, void* stream);
 /* Data gradient of a stride-2 convolution whose four output parity phases have the same number
  * of taps (k=4, pad 1, even sizes): one launch for all phases.  x = dY [N,Cout,OH,OW],
  * y = dX [N,Cin,2*PH,2*PW], fully written (no pre-zeroing).  dh/dw/src_tap: 4 x Tg entries, phase

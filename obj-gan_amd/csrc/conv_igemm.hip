@@ -68,6 +68,11 @@ struct IgemmArgs {
     int ksplit_steps;    // > 0: split-K -- blockIdx.y owns this many BK steps, epilogue = atomicAdd
     int nphase;          // > 1 (v2 kernel only): blockIdx.z = output phase p with its own tap table
                          // tap[p*8 ..], packed bank wt + p*M*Kpad and output offset (ooh, oow) = (p>>1, p&1)
+    float* ring;         // != nullptr (conv_igemm3_kernel only): data gradient of a ReflectionPad2d(1) convolution.
+                         // The GEMM runs over the PADDED grid (PH = OHf + 2, PW = OWf + 2); interior pixels are
+                         // stored straight into the unpadded y, the one-pixel ring into ring[n*M + m][2*PW + 2*PH]
+                         // (top row, bottom row, left column, right column) for objgan_reflect_ring_fold to add
+                         // back -- instead of writing the padded tensor and folding it in a second full pass.
     int tap[OG_MAX_TAPS];   // (dw << 16) | (dh & 0xffff): one scalar load per (uniform) tap
 };
 
@@ -1282,8 +1287,19 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
     const int pb = rem - pa * a.PW;
     const int oh = pa * a.osh + (a.nphase > 1 ? (phase >> 1) : a.ooh);
     const int ow = pb * a.osw + (a.nphase > 1 ? (phase & 1) : a.oow);
-    const size_t plane = (size_t)a.OHf * a.OWf;
+    size_t plane = (size_t)a.OHf * a.OWf;
     float* yb = a.y + (size_t)n * a.M * plane + (size_t)oh * a.OWf + ow;
+    if (a.ring) {        // padded grid -> unpadded y (interior) or the ring buffer (see IgemmArgs::ring)
+        const bool inner = pa >= 1 && pa <= a.PH - 2 && pb >= 1 && pb <= a.PW - 2;
+        if (inner) {
+            yb = a.y + (size_t)n * a.M * plane + (size_t)(pa - 1) * a.OWf + (pb - 1);
+        } else {
+            const int R = 2 * a.PW + 2 * a.PH;
+            const int ri = pa == 0 ? pb : (pa == a.PH - 1 ? a.PW + pb : (pb == 0 ? 2 * a.PW + pa : 2 * a.PW + a.PH + pa));
+            yb = a.ring + (size_t)n * a.M * R + ri;
+            plane = (size_t)R;
+        }
+    }
     const bool split = a.ksplit_steps > 0;
     const bool lrelu = a.act == OG_ACT_LRELU, relu = a.act == OG_ACT_RELU;
 #pragma unroll
@@ -1604,6 +1620,27 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, con
     }
 }
 
+// Adds the ring of a padded-grid data gradient (IgemmArgs::ring) onto the unpadded gradient: padded index p
+// mirrors to 1 (p = 0) / H - 2 (p = H + 1), interior p to p - 1.  A few hundred atomics per plane.
+__global__ __launch_bounds__(256) void reflect_ring_fold_kernel(const float* __restrict__ ring, float* __restrict__ y,
+                                                                long planes, int H, int W) {
+    const int PH = H + 2, PW = W + 2, R = 2 * PW + 2 * PH;
+    const long total = planes * R;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long p = e / R;
+        const int ri = (int)(e - p * R);
+        int pa, pb;
+        if (ri < PW) { pa = 0; pb = ri; }
+        else if (ri < 2 * PW) { pa = PH - 1; pb = ri - PW; }
+        else if (ri < 2 * PW + PH) { pa = ri - 2 * PW; pb = 0; }
+        else { pa = ri - 2 * PW - PH; pb = PW - 1; }
+        if (ri >= 2 * PW && (pa == 0 || pa == PH - 1)) continue;      // corners belong to the row arrays
+        const int oh = pa == 0 ? 1 : (pa == PH - 1 ? H - 2 : pa - 1);
+        const int ow = pb == 0 ? 1 : (pb == PW - 1 ? W - 2 : pb - 1);
+        atomicAdd(&y[p * (long)H * W + (long)oh * W + ow], ring[e]);
+    }
+}
+
 // ---- optional per-launch timing (bench.py's roofline leg) -------------------------------------
 // When enabled, every conv launch is bracketed by hipEvents on its own stream and tagged with a
 // category (kind, taps / ksize, tile config) and its ALGORITHMIC flops 2*M*K*Npix.  Off by default;
@@ -1903,7 +1940,7 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed) {
     og_row_plan(groups, tiles_n * nph, 0, &TM, &full_rows, &rest);
     const int tiles = (full_rows + (rest ? 1 : 0)) * tiles_n;
     const int nk = a.math == 1 ? a.Krow / 32 : a.Kpad / 16;      // loop iterations of the kernel
-    const bool full_cover = (a.osh == 1 && a.osw == 1 && a.PH == a.OHf && a.PW == a.OWf);
+    const bool full_cover = (a.osh == 1 && a.osw == 1 && a.PH == a.OHf && a.PW == a.OWf) || a.ring != nullptr;
     int splits = 1;
     if (tiles < 128 && nk >= 16 && (full_cover || y_prezeroed) && nph == 1) {
         splits = og_cdiv(512, tiles);
@@ -1923,6 +1960,8 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed) {
         a.bias = nullptr; a.act = OG_ACT_NONE;
         if (!y_prezeroed)
             (void)hipMemsetAsync(a.y, 0, sizeof(float) * (size_t)a.N * a.M * a.OHf * a.OWf, s);
+        if (a.ring)
+            (void)hipMemsetAsync(a.ring, 0, sizeof(float) * (size_t)a.N * a.M * (2 * a.PW + 2 * a.PH), s);
     } else {
         a.ksplit_steps = 0;
         if (act_later) { a.bias = nullptr; a.act = OG_ACT_NONE; }
@@ -2067,9 +2106,11 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
                       int Tg, const int* dh, const int* dw, const int* src_tap,
                       int PH, int PW, int stride,
                       int OHf, int OWf, int osh, int osw, int ooh, int oow,
-                      int act, int y_prezeroed, int wt_packed, int math, void* stream) {
+                      int act, int y_prezeroed, int wt_packed, int math, float* ring, void* stream) {
     OG_ENTRY();
     if (Tg < 1 || Tg > OG_MAX_TAPS) return OG_BAD_ARGS;
+    if (ring && !(osh == 1 && osw == 1 && ooh == 0 && oow == 0 && PH == OHf + 2 && PW == OWf + 2 && !bias && !act))
+        return OG_BAD_ARGS;
     if (math != 0 && math != 1) return OG_BAD_ARGS;
     if (Torig < 1 || Torig > 127) return OG_BAD_ARGS;
     const int M = transpose ? Cin : Cout;
@@ -2101,11 +2142,13 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
     a.stride = stride; a.pad_mode = pad_mode; a.upsample = upsample; a.act = act;
     a.ksplit_steps = 0;
     a.nphase = 0;
+    a.ring = ring;
     for (int t = 0; t < OG_MAX_TAPS; ++t) {
         const int h = t < Tg ? dh[t] : 0, w_ = t < Tg ? dw[t] : 0;
         a.tap[t] = (int)(((unsigned)w_ << 16) | ((unsigned)h & 0xffffu));
     }
     if (!(osh == 1 && osw == 1 && PH == OHf && PW == OWf) && (bias || act)) return OG_BAD_ARGS;
+    if (ring && p.m_major != 1) return OG_BAD_ARGS;     // ring mode: fp32 MFMA kernel only (ask objgan_conv_bank_layout)
     if (thin) return run_thin(a, MT, s);
     return v2 ? run_igemm2(a, s, y_prezeroed) : run_igemm(a, s, y_prezeroed);
 }
@@ -2151,12 +2194,24 @@ int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float*
     a.osh = 2; a.osw = 2; a.ooh = 0; a.oow = 0;
     a.stride = 1; a.pad_mode = 0; a.upsample = 0; a.act = OG_ACT_NONE;
     a.ksplit_steps = 0;
+    a.ring = nullptr;
     a.nphase = 4;
     for (int t = 0; t < OG_MAX_TAPS; ++t) a.tap[t] = 0;
     for (int ph = 0; ph < 4; ++ph)
         for (int t = 0; t < Tg; ++t)
             a.tap[ph * 8 + t] = (int)(((unsigned)dw[ph * Tg + t] << 16) | ((unsigned)dh[ph * Tg + t] & 0xffffu));
     return run_igemm2(a, s, 0);
+}
+
+// y [planes, H, W] += mirror of ring [planes, 2*(W+2) + 2*(H+2)] (written by objgan_conv_igemm in ring mode).
+int objgan_reflect_ring_fold(const float* ring, float* y, long planes, int H, int W, void* stream) {
+    OG_ENTRY();
+    if (H < 3 || W < 3) return OG_BAD_ARGS;
+    if (planes <= 0) return OG_OK;
+    const long total = planes * (2 * (W + 2) + 2 * (H + 2));
+    hipLaunchKernelGGL(reflect_ring_fold_kernel, dim3(og_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       ring, y, planes, H, W);
+    return og_launch_status();
 }
 
 // dw must be zero-initialised by the caller (or hold a gradient to accumulate into).

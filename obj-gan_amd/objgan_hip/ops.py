@@ -152,7 +152,7 @@ def _job_blob():
 
 
 def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, transpose,
-           dh, dw, src_tap, PH, PW, stride, OHf, OWf, osh, osw, ooh, oow, act, y_prezeroed=0):
+           dh, dw, src_tap, PH, PW, stride, OHf, OWf, osh, osw, ooh, oow, act, y_prezeroed=0, ring=None):
     Tg = len(dh)
     M = Cin if transpose else Cout
     # the library picks the kernel -- hence the bank layout -- from sizes, taps and math: ask it
@@ -173,7 +173,7 @@ def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, tran
     _lib.call("objgan_conv_igemm", _p(x), _p(w), _p(bias), _p(y), _p(wt),
               N, C, H, W, int(upsample), int(pad_mode), Cout, Cin, Torig, int(transpose),
               Tg, _iarr(dh), _iarr(dw), _iarr(src_tap), PH, PW, stride,
-              OHf, OWf, osh, osw, ooh, oow, act, int(y_prezeroed), packed, _MATH["mode"], _stream())
+              OHf, OWf, osh, osw, ooh, oow, act, int(y_prezeroed), packed, _MATH["mode"], _p(ring), _stream())
 
 
 def _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad_h, pad_w, LH, LW, cacheable=True):
@@ -246,13 +246,24 @@ def _conv_dgrad(g, w, N, Cin, H, W, stride, pad, refl, upsample, cacheable=True)
         dh = [pe - kh for kh in range(k) for kw in range(k)]
         dw = [pe - kw for kh in range(k) for kw in range(k)]
         st = list(range(k * k))
-        dxl = torch.empty((N, Cin, TH, TW), dtype=_F32, device=g.device)
-        _igemm(g, w, None, dxl, N, Cout, OH, OW, 0, 0, Cout, Cin, k * k, 1,
-               dh, dw, st, TH, TW, 1, TH, TW, 1, 1, 0, 0, 0)
-        if refl:
-            folded = torch.empty((N, Cin, LH, LW), dtype=_F32, device=g.device)
-            _lib.call("objgan_reflect_fold", _p(dxl), _p(folded), N * Cin, LH, LW, _stream())
-            dxl = folded
+        ring_ok = (refl and pad == 1 and LH >= 3 and LW >= 3 and _MATH["mode"] == 0 and
+                   _lib.load().objgan_conv_bank_layout(N, Cout, OH, OW, Cin, k * k, TH, TW, 0, 0) == 1)
+        if ring_ok:
+            # gradient of the reflect-padded conv without the padded intermediate: interior pixels go straight
+            # into dX, the one-pixel border into a small ring buffer that is mirrored back afterwards
+            dxl = torch.empty((N, Cin, LH, LW), dtype=_F32, device=g.device)
+            ring = torch.empty((N * Cin, 2 * TW + 2 * TH), dtype=_F32, device=g.device)
+            _igemm(g, w, None, dxl, N, Cout, OH, OW, 0, 0, Cout, Cin, k * k, 1,
+                   dh, dw, st, TH, TW, 1, LH, LW, 1, 1, 0, 0, 0, ring=ring)
+            _lib.call("objgan_reflect_ring_fold", _p(ring), _p(dxl), N * Cin, LH, LW, _stream())
+        else:
+            dxl = torch.empty((N, Cin, TH, TW), dtype=_F32, device=g.device)
+            _igemm(g, w, None, dxl, N, Cout, OH, OW, 0, 0, Cout, Cin, k * k, 1,
+                   dh, dw, st, TH, TW, 1, TH, TW, 1, 1, 0, 0, 0)
+            if refl:
+                folded = torch.empty((N, Cin, LH, LW), dtype=_F32, device=g.device)
+                _lib.call("objgan_reflect_fold", _p(dxl), _p(folded), N * Cin, LH, LW, _stream())
+                dxl = folded
     elif stride == 2:
         if refl:
             raise _lib.ObjganHipError("stride-2 reflect conv is not on the hot path")
