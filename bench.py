@@ -20,8 +20,8 @@ One JSON line is printed by rank 0: the contract fields plus
                 that the headline carries no event overhead), against the fp32 MFMA peak;
                 traffic = HBM bytes per launch from the rocprofv3 --pmc passes kept in profiles/
   cpu_baseline  the CPU oracle (oracle/torch_model.py, a port of the reference path) timed on this host's
-                physical cores at the BASELINE batch (1 warm-up + 1 timed step at batch 16; child process
-                with a hard time limit, batch-8 fallback)
+                physical cores at the BASELINE batch (one step at batch 16, ~90 s; `--cpu-baseline-steps K`
+                adds K warmed steps; child process with a hard time limit, batch-8 fallback)
 """
 import argparse
 import ctypes
@@ -130,6 +130,8 @@ def _cpu_baseline_worker(sample_batch, threads, timed_steps, seed=1234):
     tm.train_step(sds, opts, ema, batch, image_encoder=enc)
     warm = time.time() - t0
     report(warm, "first (un-warmed) step %.1f s" % warm)      # provisional: replaced by the timed steps below
+    if timed_steps <= 0:
+        return
     t0 = time.time()
     for _ in range(timed_steps):
         tm.train_step(sds, opts, ema, batch, image_encoder=enc)
@@ -137,12 +139,15 @@ def _cpu_baseline_worker(sample_batch, threads, timed_steps, seed=1234):
     report(dt, "1 warm-up (%.1f s) + %d timed step(s) of %.1f s each" % (warm, timed_steps, dt))
 
 
-def cpu_baseline(sample_batch=16, timed_steps=1, timeout_s=240):
+def cpu_baseline(sample_batch=16, timed_steps=0, timeout_s=200):
     """The oracle timed on the host's physical cores at the BASELINE batch (1 warm-up + timed
     steps), in a child process with a hard time limit so that the default bench run always finishes; if
     the full-batch run does not fit the limit a batch-8 sample is reported instead.  One thread per
     PHYSICAL core: with all 256 hardware threads of the GPU box's two EPYC 9575F the same step did not
-    finish in 420 s (fork-join cost of the many small operators), with 128 it takes about a minute."""
+    finish in 420 s (fork-join cost of the many small operators), with 128 it takes about 90 s.  Default
+    sample: ONE step at batch 16 (timed_steps = 0: the first, un-warmed step -- a warmed step was measured at
+    88.2 s against 93.2 s for the first, profiles/r02_bench_n1.json -- so that the default bench run stays
+    within a few minutes; `--cpu-baseline-steps K` adds K timed steps after it)."""
     import subprocess
     threads = max(1, min(128, (os.cpu_count() or 2) // 2))
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads),
@@ -222,6 +227,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 16; 32 with --math bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-steps", type=int, default=0,
+                    help="timed CPU steps after the first one (default 0: report the first step)")
     ap.add_argument("--no-is-monitor", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--force-ddp", action="store_true",
@@ -358,7 +365,8 @@ def main():
                                      "tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
                                      "frac_of_peak": round(conv_fl / (conv_ms * 1e-3) / 1e12 / peak, 4)}
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline()
+            res["cpu_baseline"] = cpu_baseline(timed_steps=args.cpu_baseline_steps,
+                                               timeout_s=200 + 110 * args.cpu_baseline_steps)
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.destroy_process_group()
