@@ -139,7 +139,7 @@ def _cpu_baseline_worker(sample_batch, threads, timed_steps, seed=1234):
     report(dt, "1 warm-up (%.1f s) + %d timed step(s) of %.1f s each" % (warm, timed_steps, dt))
 
 
-def cpu_baseline(sample_batch=16, timed_steps=0, timeout_s=200):
+def cpu_baseline(sample_batch=16, timed_steps=0, timeout_s=300):
     """The oracle timed on the host's physical cores at the BASELINE batch (1 warm-up + timed
     steps), in a child process with a hard time limit so that the default bench run always finishes; if
     the full-batch run does not fit the limit a batch-8 sample is reported instead.  One thread per
@@ -366,7 +366,7 @@ def main():
                                      "frac_of_peak": round(conv_fl / (conv_ms * 1e-3) / 1e12 / peak, 4)}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(timed_steps=args.cpu_baseline_steps,
-                                               timeout_s=200 + 110 * args.cpu_baseline_steps)
+                                               timeout_s=300 + 110 * args.cpu_baseline_steps)
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.destroy_process_group()
