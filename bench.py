@@ -48,11 +48,23 @@ CAT_NAMES = (["conv_igemm3_kernel<%d, false>" % tm for tm in range(1, 8)] +
 PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
-def build_trainer(device, batch_size, seed, with_is_monitor=True):
+WORKLOADS = {
+    # BASELINE.json configs[3] (the configuration `metric` is quoted on, per GPU) -- the default
+    "stage3_obj": (3, True, "stage3_256x256_full_GD_step: RNN_ENCODER+G_NET(3 stages)+PatD x3+ShpD x3+"
+                            "ObjSSD+ObjLSD(ROIAlign)+DAMSM+KL+Adam x9+EMA"),
+    # configs[2]: the three-stage tree without the two ROIAlign object discriminators
+    "stage3": (3, False, "stage3_256x256_GD_step_without_object_discriminators: RNN_ENCODER+G_NET(3 stages)+"
+                         "PatD x3+ShpD x3+DAMSM+KL+Adam x7+EMA"),
+    # configs[1]: the stage-1 tree at 64x64
+    "stage1": (1, False, "stage1_64x64_GD_step: RNN_ENCODER+G_NET(stage 1)+PatD64+ShpD64+DAMSM+KL+Adam x3+EMA"),
+}
+
+
+def build_trainer(device, batch_size, seed, with_is_monitor=True, workload="stage3_obj"):
     import encoders
     import trainer as T
     from miscc.config import cfg
-    cfg.TREE.BRANCH_NUM = 3
+    cfg.TREE.BRANCH_NUM = WORKLOADS[workload][0]
     cfg.TRAIN.BATCH_SIZE = batch_size
     cfg.TRAIN.NET_G = ''
     torch.manual_seed(seed)                     # same initial weights on every rank
@@ -74,6 +86,8 @@ def build_trainer(device, batch_size, seed, with_is_monitor=True):
         ds.inception_model = encoders.INCEPTION_V3(trunk).to(device).eval()
     tr = T.condGANTrainer('', None, ds, device=device)
     tr.batch_size = batch_size
+    if not WORKLOADS[workload][1]:
+        tr.use_obj = False
     tr.setup()
     return tr
 
@@ -235,6 +249,9 @@ def main():
                     help="initialise the RCCL process group even at world size 1 (exercises the data-parallel "
                          "code path -- arena all-reduces, gated optimizer steps -- on a single-GPU box)")
     ap.add_argument("--shape-table", default=None, help="write the per-layer conv table of the profiling pass here")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="stage3_obj",
+                    help="stage3_obj: the configuration BASELINE's metric is quoted on (default); stage3 / stage1: "
+                         "BASELINE configs 3 and 2 (parity-test cases; their lines are side records, not the metric)")
     ap.add_argument("--math", choices=("fp32", "bf16"), default="fp32",
                     help="fp32: exact fp32 MFMA (headline, parity path); bf16: mixed precision of BASELINE "
                          "config 5 (bf16 matrix-core inputs, fp32 accumulation / storage / norms / optimizer)")
@@ -260,11 +277,15 @@ def main():
     import synth_batch
     from objgan_hip import _lib, ops
     ops.set_conv_math(args.math)
-    tr = build_trainer(device, args.batch, seed=1234, with_is_monitor=not args.no_is_monitor)
+    tr = build_trainer(device, args.batch, seed=1234, with_is_monitor=not args.no_is_monitor,
+                       workload=args.workload)
+    branch_num, _, workload_name = WORKLOADS[args.workload]
+    side = 64 << (branch_num - 1)
     # a new minibatch every step, like training: four distinct per-rank batches in rotation (the trainer
     # carries nothing from step to step)
     nb = max(1, min(4, args.steps + args.warmup))
-    batches = [synth_batch.make_batch(args.batch, seed=1234 + rank + 1000 * i, device=device) for i in range(nb)]
+    batches = [synth_batch.make_batch(args.batch, seed=1234 + rank + 1000 * i, device=device, branch_num=branch_num)
+               for i in range(nb)]
     it = [0]
 
     def step():
@@ -311,15 +332,14 @@ def main():
     if rank == 0:
         n_img = args.batch * world * args.steps
         res = {
-            "metric": "G+D train-step images/sec at 256x256, batch 16 per GPU",
+            "metric": "G+D train-step images/sec at %dx%d, batch %d per GPU" % (side, side, args.batch)
+                      if args.workload != "stage3_obj" else "G+D train-step images/sec at 256x256, batch 16 per GPU",
             "value": round(n_img / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp32" if args.math == "fp32" else "bf16-in/fp32-acc (mixed precision, config 5)",
             "data": "synthetic",
-            "config": {"workload": "stage3_256x256_full_GD_step: RNN_ENCODER+G_NET(3 stages)+PatD x3+ShpD x3+"
-                                   "ObjSSD+ObjLSD(ROIAlign)+DAMSM+KL+Adam x9+EMA"
-                                   + ("" if args.no_is_monitor else "+IS-monitor"),
+            "config": {"workload": workload_name + ("" if args.no_is_monitor else "+IS-monitor"),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": "dp%d" % world + (" (RCCL path forced)" if args.force_ddp and world == 1 else ""),
                        "fresh_batch_every_step": True},
@@ -364,7 +384,7 @@ def main():
                 res["conv_total"] = {"ms_per_step": round(conv_ms, 2), "tflop_per_step": round(conv_fl / 1e12, 3),
                                      "tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
                                      "frac_of_peak": round(conv_fl / (conv_ms * 1e-3) / 1e12 / peak, 4)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "stage3_obj":
             res["cpu_baseline"] = cpu_baseline(timed_steps=args.cpu_baseline_steps,
                                                timeout_s=300 + 110 * args.cpu_baseline_steps)
         print(json.dumps(res), flush=True)

@@ -246,3 +246,24 @@ def test_bench_gpus_n_starts_n_ranks_itself(monkeypatch):
     assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_bench_workloads_build_and_step_on_the_cpu_shim(monkeypatch):
+    """bench.py --workload stage1 (BASELINE configs 1-2: stage-1 tree at 64x64, no object discriminators):
+    the trainer bench.py builds for it steps once on the CPU definitions of the kernels and returns the
+    stage-1 loss set; the default workload keeps the object discriminators."""
+    import bench
+    import cpu_ops_shim
+    import synth_batch
+    from miscc.config import cfg
+    cpu_ops_shim.install(monkeypatch)
+    saved = cfg.TREE.BRANCH_NUM
+    try:
+        assert bench.WORKLOADS["stage3_obj"][:2] == (3, True) and bench.WORKLOADS["stage3"][:2] == (3, False)
+        tr = bench.build_trainer(torch.device("cpu"), 2, seed=5, with_is_monitor=False, workload="stage1")
+        assert cfg.TREE.BRANCH_NUM == 1 and not tr.use_obj and len(tr.netsPatD) == 1
+        out = tr.train_step(synth_batch.make_batch(2, seed=3, branch_num=1))
+        assert len(out["fake_imgs"]) == 1 and tuple(out["fake_imgs"][0].shape) == (2, 3, 64, 64)
+        assert "errObjSSD" not in out and torch.isfinite(out["errG"]).all()
+    finally:
+        cfg.TREE.BRANCH_NUM = saved
