@@ -504,77 +504,116 @@ struct PackArgs {
     signed char src_tap[OG_MAX_TAPS];
 };
 
+// Work items of a job.  Row-major banks (m_major 1 / 3: wt[m][t*Cp + ck]) are packed per (m, ck) PAIR: a
+// thread reads the Torig taps of its pair -- one contiguous 36..64-byte run of w, adjacent pairs adjacent runs
+// for the forward banks -- and writes one element per GEMM tap, adjacent threads adjacent addresses.  The first
+// version walked the bank element by element: for the transposed (data-gradient) banks adjacent elements are a
+// whole filter apart in w, every 4-byte read pulled its own 64-byte line and the line was gone from the L2
+// before its neighbours were wanted (PMC: 1.2 GB fetched per launch for 0.1 GB of banks; 2.2 ms per step).
+__device__ __forceinline__ long pack_total(const PackArgs& a, int Kpad, int Krow) {
+    return a.m_major == 2 ? (long)(a.Ck + 1) * a.Tg * a.Mpad        // + one zero channel
+                          : (a.m_major ? (long)a.M * a.Cp : (long)Kpad * a.Mpad);
+}
+
+// element i of the small layouts (0: wt[k][Mpad], 2: wt[ck][t][MT])
+__device__ __forceinline__ void pack_element(const PackArgs& a, unsigned i, int Kpad) {
+    int m, t, ck;
+    if (a.m_major == 2) {
+        const unsigned r = i / (unsigned)a.Mpad;
+        m = (int)(i - r * (unsigned)a.Mpad);
+        t = (int)(r % (unsigned)a.Tg);
+        ck = (int)(r / (unsigned)a.Tg);
+    } else {
+        const unsigned k = i / (unsigned)a.Mpad;
+        m = (int)(i - k * (unsigned)a.Mpad);
+        t = (int)(k / (unsigned)a.Cp);
+        ck = (int)k - t * a.Cp;
+    }
+    float v = 0.f;
+    if (m < a.M && ck < a.Ck) {
+        const int st = a.src_tap[t];
+        if (st >= 0) {
+            const int co = a.transpose ? ck : m;
+            const int ci = a.transpose ? m : ck;
+            v = a.w[((size_t)co * a.Cin + ci) * a.Torig + st];
+        }
+    }
+    a.wt[i] = v;
+}
+
+// pair i = m * Cp + ck of the row-major layouts
+__device__ __forceinline__ void pack_pair(const PackArgs& a, unsigned i, int Kpad, int Krow) {
+    const unsigned m = i / (unsigned)a.Cp;
+    const int ck = (int)(i - m * (unsigned)a.Cp);
+    const bool live = ck < a.Ck;
+    const int co = a.transpose ? ck : (int)m;
+    const int ci = a.transpose ? (int)m : ck;
+    const float* src = a.w + ((size_t)co * a.Cin + ci) * a.Torig;
+    const size_t row = (size_t)m * Krow;
+    if (a.Torig == 16) {
+        // 4x4 filters (most of the bank bytes): the pair's 16 taps are one aligned 64-byte line -- four 16-byte
+        // loads instead of sixteen 4-byte ones that each walk 64 different lines per wave
+        float r[16];
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 f = live ? s4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            r[4 * q] = f.x; r[4 * q + 1] = f.y; r[4 * q + 2] = f.z; r[4 * q + 3] = f.w;
+        }
+        for (int t = 0; t < a.Tg; ++t) {
+            const int st = a.src_tap[t];                 // uniform: a select chain, no register indexing
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v = st == j ? r[j] : v;
+            const size_t o = row + (size_t)t * a.Cp + ck;
+            if (a.m_major == 3) reinterpret_cast<__bf16*>(a.wt)[o] = (__bf16)v;
+            else a.wt[o] = v;
+        }
+    } else {
+        for (int t = 0; t < a.Tg; ++t) {
+            const int st = a.src_tap[t];
+            const float v = (live && st >= 0) ? src[st] : 0.f;
+            const size_t o = row + (size_t)t * a.Cp + ck;
+            if (a.m_major == 3) reinterpret_cast<__bf16*>(a.wt)[o] = (__bf16)v;
+            else a.wt[o] = v;
+        }
+    }
+    if (a.m_major == 3 && ck < Krow - Kpad)               // bf16 rows are padded to a multiple of 32
+        reinterpret_cast<__bf16*>(a.wt)[row + Kpad + ck] = (__bf16)0.f;
+}
+
+__device__ __forceinline__ void pack_item(const PackArgs& a, long i, int Kpad, int Krow) {
+    if (a.m_major == 1 || a.m_major == 3) pack_pair(a, (unsigned)i, Kpad, Krow);
+    else pack_element(a, (unsigned)i, Kpad);
+}
+
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
     const int Kpad = a.Tg * a.Cp;
     const int Krow = a.m_major == 3 ? (Kpad + 31) / 32 * 32 : Kpad;
-    const long total = a.m_major == 2 ? (long)(a.Ck + 1) * a.Tg * a.Mpad   // + one zero channel
-                                      : (a.m_major ? (long)a.M * Krow : (long)Kpad * a.Mpad);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long)gridDim.x * blockDim.x) {
-        int m, t, ck;
-        bool pad = false;
-        if (a.m_major == 2) {
-            m = (int)(i % a.Mpad);
-            const int r = (int)(i / a.Mpad);
-            t = r % a.Tg;
-            ck = r / a.Tg;
-        } else {
-            m = a.m_major ? (int)(i / Krow) : (int)(i % a.Mpad);
-            const int k = a.m_major ? (int)(i % Krow) : (int)(i / a.Mpad);
-            pad = k >= Kpad;
-            t = pad ? 0 : k / a.Cp;
-            ck = k - t * a.Cp;
-        }
-        float v = 0.f;
-        if (!pad && m < a.M && ck < a.Ck) {
-            const int st = a.src_tap[t];
-            if (st >= 0) {
-                const int co = a.transpose ? ck : m;
-                const int ci = a.transpose ? m : ck;
-                v = a.w[((size_t)co * a.Cin + ci) * a.Torig + st];
-            }
-        }
-        if (a.m_major == 3) reinterpret_cast<__bf16*>(a.wt)[i] = (__bf16)v;
-        else a.wt[i] = v;
-    }
+    const long total = pack_total(a, Kpad, Krow);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        pack_item(a, i, Kpad, Krow);
 }
 
 // Many banks in one launch: blockIdx.y = job.  After an optimizer step every cached bank of the updated
 // network is stale at once -- ~60 banks per network, 499 7-us launches per training step when each is
 // re-packed at its next use; the host keeps the jobs of a network in a device table instead and refreshes
-// them right behind the Adam kernel (objgan_conv_pack_jobs_run).
+// them right behind the Adam kernel (objgan_conv_pack_jobs_run).  Bank sizes span three orders of magnitude
+// (a 3-channel to-RGB bank .. 768 x 1024 x 9): a workgroup takes OG_PACK_CHUNK consecutive work items per
+// sweep and workgroups beyond a small bank's end leave at once.
+#define OG_PACK_BLOCKS 256
+#define OG_PACK_CHUNK 512
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackArgs* __restrict__ jobs) {
     const PackArgs a = jobs[blockIdx.y];
     const int Kpad = a.Tg * a.Cp;
     const int Krow = a.m_major == 3 ? (Kpad + 31) / 32 * 32 : Kpad;
-    const long total = a.m_major == 2 ? (long)(a.Ck + 1) * a.Tg * a.Mpad
-                                      : (a.m_major ? (long)a.M * Krow : (long)Kpad * a.Mpad);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int m, t, ck;
-        bool pad = false;
-        if (a.m_major == 2) {
-            m = (int)(i % a.Mpad);
-            const int r = (int)(i / a.Mpad);
-            t = r % a.Tg;
-            ck = r / a.Tg;
-        } else {
-            m = a.m_major ? (int)(i / Krow) : (int)(i % a.Mpad);
-            const int k = a.m_major ? (int)(i % Krow) : (int)(i / a.Mpad);
-            pad = k >= Kpad;
-            t = pad ? 0 : k / a.Cp;
-            ck = k - t * a.Cp;
+    const long total = pack_total(a, Kpad, Krow);
+    for (long base = (long)blockIdx.x * OG_PACK_CHUNK; base < total; base += (long)gridDim.x * OG_PACK_CHUNK) {
+#pragma unroll
+        for (int u = 0; u < OG_PACK_CHUNK / 256; ++u) {
+            const long i = base + u * 256 + threadIdx.x;
+            if (i < total) pack_item(a, i, Kpad, Krow);
         }
-        float v = 0.f;
-        if (!pad && m < a.M && ck < a.Ck) {
-            const int st = a.src_tap[t];
-            if (st >= 0) {
-                const int co = a.transpose ? ck : m;
-                const int ci = a.transpose ? m : ck;
-                v = a.w[((size_t)co * a.Cin + ci) * a.Torig + st];
-            }
-        }
-        if (a.m_major == 3) reinterpret_cast<__bf16*>(a.wt)[i] = (__bf16)v;
-        else a.wt[i] = v;
     }
 }
 
@@ -2076,7 +2115,7 @@ int objgan_conv_pack_jobs_run(const void* jobs_dev, int njobs, void* stream) {
     OG_ENTRY();
     if (njobs <= 0) return OG_OK;
     if (!jobs_dev || njobs > 65535) return OG_BAD_ARGS;
-    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(128, njobs), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(OG_PACK_BLOCKS, njobs), dim3(256), 0, (hipStream_t)stream,
                        (const PackArgs*)jobs_dev);
     return og_launch_status();
 }

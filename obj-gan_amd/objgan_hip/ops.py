@@ -114,7 +114,7 @@ def _bank_lookup(key, w, nfloats, device):
     if ent is None or ent.w is not w:
         if len(_PACK_CACHE) >= _PACK_CACHE_MAX:
             invalidate_packed()
-        ent = _Bank(w, torch.empty(nfloats, dtype=_F32, device=device))   # holding w keeps its address from being reused
+        ent = _Bank(w, torch.zeros(nfloats, dtype=_F32, device=device))   # holding w keeps its address from being reused
         _PACK_CACHE[key] = ent
         cell = getattr(w, "_og_epoch", None)
         if cell is not None:

@@ -788,3 +788,51 @@ def test_upblock_conv_takes_the_phased_form_and_follows_weight_updates(dev):
     y2 = ops.conv2d(xd, wd, None, 1, 1, "zeros", True, None)
     torch.cuda.synchronize()
     assert rel_l2(y2, tr.conv2d(x, -0.5 * w, None, 1, 1, "zeros", True, None)) < TOL
+
+
+def test_one_launch_bank_refresh_equals_banks_packed_from_scratch(dev):
+    """ops.repack_arena: the fused optimizer step writes the weights of a network through a raw pointer
+    and bumps the network's epoch cell; ONE launch over the device table of pack jobs then refreshes every
+    cached bank of that network (forward, data-gradient, phased stride-2 layouts; banks from a 3-row to-RGB
+    filter to 768 x 384 x 16).  The refreshed banks must equal, bit for bit, the banks packed again by their
+    own launches after the cache was dropped, and the convolutions on them must agree."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(41)
+    cell = [0]
+    layers = [(96, 15, 4, 2, 32), (192, 96, 4, 2, 16), (768, 384, 4, 2, 8), (194, 194, 3, 1, 16), (3, 96, 3, 1, 32),
+              (12, 80, 3, 1, 32), (384, 194, 3, 1, 8)]
+    ws, xs = [], []
+    for co, ci, k, s, hw in layers:
+        w = (torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5).to(dev).requires_grad_(True)
+        w._og_epoch = cell
+        ws.append(w)
+        xs.append(torch.randn(2, ci, hw, hw, generator=g).to(dev).requires_grad_(True))
+
+    def run():
+        outs = []
+        for (co, ci, k, s, hw), w, x in zip(layers, ws, xs):
+            y = ops.conv2d(x, w, None, s, 1)
+            dx, = torch.autograd.grad(y, x, torch.ones_like(y))
+            outs += [y.detach(), dx]
+        torch.cuda.synchronize()
+        return outs
+    ops.invalidate_packed()
+    run()                                              # creates and registers the banks
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(-0.75).add_(0.01)
+    cell[0] += 1
+    n = ops.repack_arena(cell)
+    assert n >= 2 * len(layers)                        # at least a forward and a data-gradient bank per layer
+    torch.cuda.synchronize()
+    refreshed = {k: e.wt.clone() for k, e in ops._PACK_CACHE.items() if getattr(e.w, "_og_epoch", None) is cell}
+    assert len(refreshed) >= 2 * len(layers)
+    got = run()                                        # on the banks refreshed by the one launch
+    assert all(torch.equal(ops._PACK_CACHE[k].wt, v) for k, v in refreshed.items())   # taken as fresh, not re-packed
+    ops.invalidate_packed()
+    want = run()                                       # every bank packed from scratch
+    for k, v in refreshed.items():
+        assert torch.equal(ops._PACK_CACHE[k].wt, v), k[1:5]
+    for a, b in zip(got, want):                        # split-K sums are atomics: equal up to their order
+        assert rel_l2(a, b) < 1e-6
+    assert float(got[0].abs().max()) > 0.0

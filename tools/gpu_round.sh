@@ -20,6 +20,7 @@ benchcfg) for w in stage3 stage1; do ( time timeout 300 python bench.py --steps 
 bench8t) ( time timeout 600 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --shape-table gpurun_out/${TAG}_conv_shapes.txt ) > gpurun_out/${TAG}_bench8t.log 2>&1; tail -3 gpurun_out/${TAG}_bench8t.log | cut -c1-400 ;;
 bench8) ( time timeout 600 python bench.py --steps 8 --warmup 2 --no-cpu-baseline ) > gpurun_out/${TAG}_bench8.log 2>&1; tail -3 gpurun_out/${TAG}_bench8.log | cut -c1-400 ;;
 smoke) ( timeout 300 python __graft_entry__.py --smoke ) > gpurun_out/${TAG}_smoke.log 2>&1; tail -2 gpurun_out/${TAG}_smoke.log ;;
+pmcstep) bash tools/pmc_step.sh ${TAG} > gpurun_out/${TAG}_pmcstep.log 2>&1; tail -3 gpurun_out/${TAG}_pmcstep.log ;;
 pmc) bash tools/pmc_bench.sh ${TAG} > gpurun_out/${TAG}_pmc.log 2>&1; tail -20 gpurun_out/${TAG}_pmc_traffic.log ;;
 opsrc) ( timeout 600 python tools/op_sources.py ) > gpurun_out/${TAG}_opsrc.txt 2> gpurun_out/${TAG}_opsrc.err; head -40 gpurun_out/${TAG}_opsrc.txt ;;
 benchenv) ( time env $OG_ENV timeout 600 python bench.py --steps 8 --warmup 2 --no-cpu-baseline ) > gpurun_out/${TAG}_benchenv.log 2>&1; tail -3 gpurun_out/${TAG}_benchenv.log | cut -c1-400 ;;
