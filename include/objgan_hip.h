@@ -212,6 +212,19 @@ int objgan_adam_step_gated(float* p, const float* g, float* m, float* v, long n,
 int objgan_ema_update(float* avg, const float* p, long n, float decay, float one_minus_decay,
                       void* stream);
 
+/* ---- training images on the device (the loader side of the path) -------------------------
+ * Replaces, per batch, the host-side `transforms.Resize((s, s))(img)` + ToTensor + Normalize(0.5, 0.5) of
+ * reference image_generation/miscc/load.py:141-150 (Pillow's antialiased bilinear Image.resize, once per
+ * branch size and image): the decoded 8-bit RGB images of a batch arrive back to back in one byte buffer
+ * (rows of W*3 bytes; image b at byte offs[b], hs[b] x ws[b] pixels; offs / hs / ws are DEVICE arrays) and
+ * out [B, 3, S, S] is bit for bit what Pillow + torch compute on the host.  Hmax >= every height,
+ * kmax >= objgan_resize_pil_kmax(largest side of the batch, S) (the tap count Pillow allots per pixel).
+ * coef_scratch: B*2*S*(kmax+2) ints, tmp_scratch: B*Hmax*S*3 bytes. */
+int objgan_resize_pil_kmax(int max_in, int S);
+int objgan_resize_pil_rgb8(const unsigned char* src, const long* offs, const int* hs, const int* ws, int B,
+                           int Hmax, int kmax, int S, int* coef_scratch, unsigned char* tmp_scratch, float* out,
+                           void* stream);
+
 /* ---- measurement aid (bench.py roofline leg): hipEvent-bracketed conv launches ------------------ */
 int objgan_prof_enable(int on);
 int objgan_prof_collect(double* ms, double* flops, long* count);   /* arrays of 32 categories */

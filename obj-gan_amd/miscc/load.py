@@ -252,6 +252,14 @@ def _normalize_to_tensor(img):
     return t.sub_(0.5).div_(0.5)
 
 
+def decode_rgb(img_bytes):
+    """The decoded image as a uint8 [H, W, 3] tensor: the `device_imgs` hand-over of trainDataset (the
+    branch sizes are produced on the device, objgan_hip.ops.resize_pil_bilinear)."""
+    from PIL import Image
+    img = Image.open(io.BytesIO(img_bytes)).convert('RGB')
+    return torch.from_numpy(np.array(img, dtype=np.uint8))
+
+
 def get_imgs(img_bytes, imsize, normalize=None):
     """Decode and resize to every branch size (torchvision Resize((s, s)) on a PIL image is PIL's
     bilinear resize with its built-in antialiasing)."""

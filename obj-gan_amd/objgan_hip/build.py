@@ -17,7 +17,8 @@ OBJ_DIR = os.path.join(CSRC, "build")
 
 BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
 # ROIAlign index math must be bit-exact with the reference C loop: no FMA contraction.
-PER_FILE_FLAGS = {"roi_align.hip": ["-ffp-contract=off"]}
+# The Pillow-exact image resize evaluates its filter coefficients in double in Pillow's operation order.
+PER_FILE_FLAGS = {"roi_align.hip": ["-ffp-contract=off"], "resize_pil.hip": ["-ffp-contract=off"]}
 
 
 def _hipcc():

@@ -940,6 +940,46 @@ def bilinear_resize(x, oh, ow):
     return _BilinearFn.apply(x, int(oh), int(ow))
 
 
+# ---- training images: Pillow's antialiased bilinear resize + ToTensor + Normalize on the device -------
+def resize_pil_bilinear(images, sizes, device):
+    """images: the decoded RGB images of a batch as uint8 [H, W, 3] host tensors / arrays (any sizes);
+    -> [B, 3, S, S] float32 on `device` for every S in `sizes`, bit for bit
+    Normalize(.5, .5)(ToTensor(transforms.Resize((S, S))(img))) of reference miscc/load.py:141-150.
+    The images cross PCIe once, as bytes (csrc/resize_pil.hip)."""
+    import numpy as np
+    arrs = [np.ascontiguousarray(im.numpy() if torch.is_tensor(im) else im, dtype=np.uint8) for im in images]
+    for a in arrs:
+        if a.ndim != 3 or a.shape[2] != 3 or a.shape[0] < 1 or a.shape[1] < 1:
+            raise _lib.ObjganHipError("resize_pil_bilinear: images must be uint8 [H, W, 3], got %s" % (a.shape,))
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.ObjganHipError("resize_pil_bilinear: needs a HIP device (no CPU path)")
+    B = len(arrs)
+    sizes_b = [a.size for a in arrs]
+    offs = np.concatenate(([0], np.cumsum(sizes_b)[:-1])).astype(np.int64) if B else np.zeros(0, np.int64)
+    host = torch.empty(int(sum(sizes_b)), dtype=torch.uint8).pin_memory()
+    flat = host.numpy()
+    for a, o in zip(arrs, offs):
+        flat[o:o + a.size] = a.reshape(-1)
+    src = host.to(device, non_blocking=True)
+    hs = torch.tensor([a.shape[0] for a in arrs], dtype=torch.int32).to(device)
+    ws = torch.tensor([a.shape[1] for a in arrs], dtype=torch.int32).to(device)
+    offs_d = torch.from_numpy(offs).to(device)
+    Hmax = max(a.shape[0] for a in arrs)
+    side = max(max(a.shape[0], a.shape[1]) for a in arrs)
+    outs = []
+    for S in sizes:
+        S = int(S)
+        kmax = int(_lib.load().objgan_resize_pil_kmax(side, S))
+        coef = torch.empty(B * 2 * S * (kmax + 2), dtype=torch.int32, device=device)
+        tmp = torch.empty(B * Hmax * S * 3, dtype=torch.uint8, device=device)
+        out = torch.empty((B, 3, S, S), dtype=_F32, device=device)
+        _lib.call("objgan_resize_pil_rgb8", _p(src), _p(offs_d), _p(hs), _p(ws), B, Hmax, kmax, S,
+                  _p(coef), _p(tmp), _p(out), _stream())
+        outs.append(out)
+    return outs
+
+
 # ---- layout-map stem of the object discriminators, evaluated below the 512x512 lift -------------------
 # conv3x3(reflect_pad(lift(seg)))[co] = sum_taps (shift_tap o reflect o lift)(conv1x1(seg; W[:, :, tap])[co]):
 # the channel contraction is a 1x1 convolution at the source resolution (MFMA kernel), the pixel operators

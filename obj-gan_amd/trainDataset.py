@@ -12,7 +12,9 @@ import torch.utils.data as data
 from miscc.config import cfg
 from miscc.utils import attach_host, _host
 from miscc.load import (load_filenames, load_text_data, load_glove_emb, load_cat_label, load_class_id,
-                        load_cats, load_imgs_data, load_anns_data, get_imgs, get_caption, get_hmaps_rois)
+                        load_cats, load_imgs_data, load_anns_data, get_imgs, decode_rgb, get_caption,
+                        get_hmaps_rois)
+from objgan_hip import ops
 
 
 class TrainDataset(data.Dataset):
@@ -26,8 +28,9 @@ class TrainDataset(data.Dataset):
     cat_labels / cat_label_lens / sorted_cat_label_indices, class_id, cats_dict / cats_index_dict,
     img_bytes, insanns_dict."""
 
-    def __init__(self, data_dir, split='train', base_size=64, device_hmaps=False):
+    def __init__(self, data_dir, split='train', base_size=64, device_hmaps=False, device_imgs=False):
         self.device_hmaps = device_hmaps
+        self.device_imgs = device_imgs
         self.data_dir = data_dir
         self.embeddings_num = cfg.TEXT.CAPTIONS_PER_IMAGE
         self.imsize = [base_size * (2 ** b) for b in range(cfg.TREE.BRANCH_NUM)]
@@ -60,7 +63,8 @@ class TrainDataset(data.Dataset):
         hmaps, rois, fm_rois, num_rois, bt_masks, fm_bt_masks = maps[0], maps[4], maps[5], maps[6], maps[7], maps[8]
         pick = index * self.embeddings_num + random.randint(0, self.embeddings_num)    # one of the image's captions
         caps, glove_caps, cap_len = get_caption(self.captions, self.glove_captions, pick)
-        return (get_imgs(self.img_bytes[index], self.imsize), caps, glove_caps, cap_len, hmaps, rois, fm_rois,
+        imgs = decode_rgb(self.img_bytes[index]) if self.device_imgs else get_imgs(self.img_bytes[index], self.imsize)
+        return (imgs, caps, glove_caps, cap_len, hmaps, rois, fm_rois,
                 num_rois, bt_masks, fm_bt_masks, self.class_id[index], key)
 
 
@@ -94,8 +98,15 @@ def prepare_data(data, device=None, num_classes=None):
     def take_small(t):      # box tables / counts: the host copy stays attached (miscc.utils._host)
         h = t[order]
         return h if device is None else attach_host(h.to(device, non_blocking=True), h)
-    branches = range(len(imgs))
-    out_imgs = [take(imgs[b]) for b in branches]
+    branches = range(len(bt_masks))
+    if len(imgs) and torch.is_tensor(imgs[0]) and imgs[0].dtype == torch.uint8:
+        # `device_imgs` hand-over: one decoded [H, W, 3] image per sample (collate_keep_images)
+        if device is None:
+            raise ValueError("prepare_data: decoded images are resized on the device; pass `device`")
+        out_imgs = ops.resize_pil_bilinear([imgs[i] for i in order.tolist()],
+                                           [bt_masks[b].shape[-1] for b in branches], device)
+    else:
+        out_imgs = [take(imgs[b]) for b in branches]
     out_rois = [take_small(rois[b]) for b in branches]
     out_masks, out_hmaps = [], []
     for b in branches:
@@ -125,6 +136,13 @@ def batch_dict(prepared, clabels_emb):
             "class_ids": class_ids, "keys": keys, "clabels_emb": clabels_emb}
 
 
+def collate_keep_images(samples):
+    """default_collate for every field but the first: decoded images have different sizes and stay a
+    list of uint8 [H, W, 3] tensors (the `device_imgs` hand-over)."""
+    rest = data.default_collate([s[1:] for s in samples])
+    return [[s[0] for s in samples]] + list(rest)
+
+
 def build_loader(dataset, batch_size, workers=0, rank=0, world=1, seed=0, shuffle=True):
     """The reference's loader settings (main.py: shuffle, drop_last) with one shard per rank: under
     DDP every process draws a disjoint 1/world of each epoch's permutation (DistributedSampler),
@@ -135,4 +153,5 @@ def build_loader(dataset, batch_size, workers=0, rank=0, world=1, seed=0, shuffl
                                                       shuffle=shuffle, seed=seed, drop_last=True)
     return data.DataLoader(dataset, batch_size=batch_size, drop_last=True,
                            shuffle=(shuffle and sampler is None), sampler=sampler,
-                           num_workers=int(workers), pin_memory=True, persistent_workers=int(workers) > 0)
+                           num_workers=int(workers), pin_memory=True, persistent_workers=int(workers) > 0,
+                           collate_fn=collate_keep_images if getattr(dataset, "device_imgs", False) else None)

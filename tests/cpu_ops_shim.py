@@ -143,6 +143,13 @@ def ema_update_(avg, p, decay):
     avg.mul_(decay).add_(p, alpha=1.0 - decay)
 
 
+def resize_pil_bilinear(images, sizes, device):
+    from oracle import pil_resize as pr
+    arrs = [np.asarray(im.numpy() if torch.is_tensor(im) else im, dtype=np.uint8) for im in images]
+    return [torch.from_numpy(np.stack([pr.to_normalized_chw(pr.resize_rgb8(a, int(S))) for a in arrs])).to(device)
+            for S in sizes]
+
+
 def set_conv_math(mode):
     pass
 
@@ -153,7 +160,8 @@ def get_conv_math():
 
 API = ("conv2d", "conv2d_frozen", "linear", "norm_act", "norm_act_eval", "attn_general", "attn_bu", "masked_max",
        "softmax_strided", "roi_align", "avgpool2s1", "bilinear_resize", "lstm_bidir_forward", "adam_step_",
-       "adam_step_gated_", "ema_update_", "max_pool2d", "avg_pool2d", "lift_stem_conv", "bmm", "repack_arena", "bce_const")
+       "adam_step_gated_", "ema_update_", "max_pool2d", "avg_pool2d", "lift_stem_conv", "bmm", "repack_arena", "bce_const",
+       "resize_pil_bilinear")
 
 
 def install(monkeypatch):
@@ -164,10 +172,11 @@ def install(monkeypatch):
     import model
     import trainer
     import encoders
+    import trainDataset
     from miscc import losses, utils
     shim = types.SimpleNamespace(**{k: globals()[k] for k in API})
     shim.set_conv_math, shim.get_conv_math = set_conv_math, get_conv_math
-    for mod in (model, GlobalAttention, trainer, losses, utils, encoders):
+    for mod in (model, GlobalAttention, trainer, losses, utils, encoders, trainDataset):
         if hasattr(mod, "ops"):
             monkeypatch.setattr(mod, "ops", shim)
     for name in ("models.roi_align.modules.roi_align", "models.roi_align.functions.roi_align"):

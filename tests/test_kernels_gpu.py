@@ -836,3 +836,38 @@ def test_one_launch_bank_refresh_equals_banks_packed_from_scratch(dev):
     for a, b in zip(got, want):                        # split-K sums are atomics: equal up to their order
         assert rel_l2(a, b) < 1e-6
     assert float(got[0].abs().max()) > 0.0
+
+
+def test_images_resized_on_the_device_equal_pillow_bit_for_bit(dev):
+    """csrc/resize_pil.hip: a batch of decoded 8-bit images of different sizes -> the three branch sizes,
+    against the oracle (oracle/pil_resize.py) AND against Pillow + ToTensor + Normalize themselves
+    (reference miscc/load.py:141-150): every float equal.  Cases: COCO-sized landscape / portrait images
+    (down-scaling by up to 10), images smaller than the target (up-scaling), an identity axis, degenerate
+    sizes, and a ramp that contains every byte value (the u8 -> float normalisation is exhaustive)."""
+    from PIL import Image
+    from oracle import pil_resize as pr
+    from miscc.load import _normalize_to_tensor
+    ops = _ops()
+    rng = np.random.RandomState(5)
+    shapes = [(480, 640), (427, 640), (640, 480), (100, 37), (64, 64), (30, 200), (256, 300), (1, 5), (333, 256)]
+    imgs = []
+    for h, w in shapes:
+        a = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        yy, xx = np.mgrid[0:h, 0:w]
+        a[h // 2:] = np.stack([(xx * 255) // max(w - 1, 1), (yy * 255) // max(h - 1, 1), (xx + yy) % 256],
+                              2).astype(np.uint8)[h // 2:]
+        imgs.append(a)
+    imgs.append(np.tile(np.arange(256, dtype=np.uint8).reshape(1, 256, 1), (256, 1, 3)))     # identity at 256
+    sizes = [64, 128, 256]
+    outs = ops.resize_pil_bilinear([torch.from_numpy(a) for a in imgs], sizes, dev)
+    torch.cuda.synchronize()
+    for S, out in zip(sizes, outs):
+        assert tuple(out.shape) == (len(imgs), 3, S, S) and out.dtype == torch.float32
+        for b, a in enumerate(imgs):
+            want = _normalize_to_tensor(Image.fromarray(a, "RGB").resize((S, S), Image.BILINEAR))
+            assert torch.equal(out[b].cpu(), want), (S, a.shape)
+            assert torch.equal(want, torch.from_numpy(pr.to_normalized_chw(pr.resize_rgb8(a, S))))
+    ramp = outs[2][-1].cpu()
+    assert torch.equal(ramp[0, 0], torch.arange(256, dtype=torch.float32).div(255).sub(0.5).div(0.5))
+    with pytest.raises(Exception):
+        ops.resize_pil_bilinear([torch.zeros(4, 4, dtype=torch.uint8)], [64], dev)
