@@ -332,8 +332,7 @@ def main():
     if rank == 0:
         n_img = args.batch * world * args.steps
         res = {
-            "metric": "G+D train-step images/sec at %dx%d, batch %d per GPU" % (side, side, args.batch)
-                      if args.workload != "stage3_obj" else "G+D train-step images/sec at 256x256, batch 16 per GPU",
+            "metric": "G+D train-step images/sec at %dx%d, batch %d per GPU" % (side, side, args.batch),
             "value": round(n_img / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
