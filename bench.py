@@ -314,18 +314,21 @@ def main():
 
     # second, UNTIMED pass with every conv launch bracketed by hipEvents on its stream (the headline
     # above carries no event overhead): per-kernel durations for the roofline leg
+    # EVERY rank runs these steps (a step holds collectives under data parallelism); rank 0 records the events
     timing = (rank == 0) and not args.no_kernel_timing
     prof_steps = max(1, min(args.steps, 10))
-    if timing:
-        lib.objgan_prof_enable(1)
+    if not args.no_kernel_timing:
+        if timing:
+            lib.objgan_prof_enable(1)
         t1 = time.perf_counter()
         for _ in range(prof_steps):
             step()
         torch.cuda.synchronize()
         prof_dt = (time.perf_counter() - t1) / prof_steps
-        lib.objgan_prof_enable(0)
-        if args.shape_table:
-            _write_shape_table(lib, args.shape_table, prof_steps)
+        if timing:
+            lib.objgan_prof_enable(0)
+            if args.shape_table:
+                _write_shape_table(lib, args.shape_table, prof_steps)
     if use_dist:
         dist.barrier()
 

@@ -109,27 +109,31 @@ class ParamArena(object):
 
     def arm(self, on_bucket):
         """Until disarm(): on_bucket(start, end) is called once per bucket, as soon as every parameter of the
-        bucket has reported its gradient (each parameter of the network is used once per forward)."""
+        bucket has reported its gradient (each parameter of the network is used once per forward) AND every
+        higher bucket has been handed over: buckets leave in descending order, always.  The backward pass
+        completes them in that order anyway (the last layers first); pinning it makes the sequence of
+        collectives identical on every rank even when a rank's batch prunes a branch of its graph."""
         self.make_buckets()
-        self._armed = (on_bucket, [set(mem) for (_, _, mem) in self.buckets], set())
+        self._armed = (on_bucket, [set(mem) for (_, _, mem) in self.buckets], [len(self.buckets) - 1])
 
     def _mark(self, i):
         if self._armed is None:
             return
-        on_bucket, waiting, fired = self._armed
-        b = self._bucket_of[i]
-        waiting[b].discard(i)
-        if not waiting[b] and b not in fired:
-            fired.add(b)
+        on_bucket, waiting, nxt = self._armed
+        waiting[self._bucket_of[i]].discard(i)
+        while nxt[0] >= 0 and not waiting[nxt[0]]:
+            b = nxt[0]
+            nxt[0] -= 1
             on_bucket(self.buckets[b][0], self.buckets[b][1])
 
     def disarm(self):
-        """-> the (start, end) ranges that never fired (a parameter without a gradient this step)."""
+        """-> the (start, end) ranges that were not handed over during the backward pass (a parameter
+        without a gradient this step holds its bucket and the lower ones back), in the same descending order."""
         if self._armed is None:
             return []
-        _, _, fired = self._armed
+        _, _, nxt = self._armed
         self._armed = None
-        return [(s0, e0) for b, (s0, e0, _) in enumerate(self.buckets) if b not in fired]
+        return [self.buckets[b][:2] for b in range(nxt[0], -1, -1)]
 
     def sync_grads(self):
         """Make sure every gradient lives in the arena (callers may have used

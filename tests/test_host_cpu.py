@@ -267,3 +267,33 @@ def test_bench_workloads_build_and_step_on_the_cpu_shim(monkeypatch):
         assert "errObjSSD" not in out and torch.isfinite(out["errG"]).all()
     finally:
         cfg.TREE.BRANCH_NUM = saved
+
+
+def test_gradient_buckets_leave_in_descending_order_whatever_the_completion_order():
+    """ParamArena.arm / _mark / disarm: under data parallelism every rank must issue the generator's bucket
+    all-reduces in the same sequence, even if a rank's batch prunes a branch of its graph and its parameters
+    report in a different order (or not at all): buckets are handed over highest first, a bucket with a
+    missing gradient holds the lower ones back until disarm()."""
+    import trainer as T
+    net = torch.nn.Sequential(*[torch.nn.Linear(8, 8) for _ in range(6)])
+    arena = T.ParamArena(net)
+    buckets = arena.make_buckets(k=4)
+    assert len(buckets) == 4 and buckets[0][0] == 0 and buckets[-1][1] == arena.n
+    assert all(a[1] == b[0] for a, b in zip(buckets, buckets[1:]))            # contiguous, whole parameters
+    for order, skip in ((list(range(len(arena.params))), ()),                 # forward order: everything waits
+                        (list(range(len(arena.params)))[::-1], ()),           # backward order: fires as it goes
+                        ([5, 0, 11, 3, 2, 9, 1, 7, 10, 4, 8, 6], ()),
+                        (list(range(len(arena.params)))[::-1], (arena.buckets[2][2][0],))):
+        fired = []
+        arena.arm(lambda s0, e0: fired.append((s0, e0)))
+        for i in order:
+            if i not in skip:
+                arena._mark(i)
+        during = list(fired)
+        rest = arena.disarm()
+        assert during + rest == [b[:2] for b in buckets[::-1]]                # the same sequence in every case
+        if skip:
+            assert during == [buckets[3][:2]] and rest == [b[:2] for b in buckets[2::-1]]
+        elif order == list(range(len(arena.params)))[::-1]:
+            assert rest == []
+    arena._mark(0)                                                            # disarmed: hooks are inert
