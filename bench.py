@@ -232,6 +232,35 @@ def _write_shape_table(lib, path, steps):
                 (kinds.get(key[0], "?"),) + key[1:] + (cnt / steps, tms / steps, tfl / (tms * 1e-3) / 1e12 if tms > 0 else 0)))
 
 
+def timed_passes(step, barrier, max_over_ranks, steps, warmup, prof_steps, prof_begin=None, prof_end=None):
+    """The measurement protocol, on EVERY rank alike (a step holds collectives under data parallelism, so no
+    pass may run on a subset of the ranks): `warmup` untimed steps; exactly `steps` steps bracketed by
+    barrier + device synchronize on both sides, the MAX over ranks of that time; then a second, UNTIMED pass
+    of `prof_steps` steps during which rank 0 brackets every conv launch with hipEvents on its stream
+    (`prof_begin` / `prof_end` are None on the other ranks) -- the headline carries no event overhead.
+    -> (seconds of the timed pass, seconds per step of the profiling pass or None)"""
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    prof_dt = None
+    if prof_steps > 0:
+        if prof_begin is not None:
+            prof_begin()
+        t1 = time.perf_counter()
+        for _ in range(prof_steps):
+            step()
+        barrier()
+        prof_dt = (time.perf_counter() - t1) / prof_steps
+        if prof_end is not None:
+            prof_end()
+    return dt, prof_dt
+
+
 def main():
     if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-baseline-worker":
         return _cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
@@ -298,37 +327,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    lib = _lib.load()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
-    if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    def max_over_ranks(v):
+        t = torch.tensor([v], dtype=torch.float64, device=device)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    # second, UNTIMED pass with every conv launch bracketed by hipEvents on its stream (the headline
-    # above carries no event overhead): per-kernel durations for the roofline leg
-    # EVERY rank runs these steps (a step holds collectives under data parallelism); rank 0 records the events
+    lib = _lib.load()
     timing = (rank == 0) and not args.no_kernel_timing
-    prof_steps = max(1, min(args.steps, 10))
-    if not args.no_kernel_timing:
-        if timing:
-            lib.objgan_prof_enable(1)
-        t1 = time.perf_counter()
-        for _ in range(prof_steps):
-            step()
-        torch.cuda.synchronize()
-        prof_dt = (time.perf_counter() - t1) / prof_steps
-        if timing:
-            lib.objgan_prof_enable(0)
-            if args.shape_table:
-                _write_shape_table(lib, args.shape_table, prof_steps)
+    prof_steps = 0 if args.no_kernel_timing else max(1, min(args.steps, 10))
+    dt, prof_dt = timed_passes(step, barrier, max_over_ranks, args.steps, args.warmup, prof_steps,
+                               (lambda: lib.objgan_prof_enable(1)) if timing else None,
+                               (lambda: lib.objgan_prof_enable(0)) if timing else None)
+    if timing and args.shape_table:
+        _write_shape_table(lib, args.shape_table, prof_steps)
     if use_dist:
         dist.barrier()
 

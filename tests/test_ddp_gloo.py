@@ -220,3 +220,59 @@ def test_two_rank_trainer_step_keeps_replicas_identical():
     assert np.array_equal(g0, g1) and np.array_equal(d0, d1) and np.array_equal(ema0, ema1), "replicas diverged"
     assert np.array_equal(objls0, objls1), "conditional object-discriminator update diverged across ranks"
     assert not np.array_equal(objls0, init0), "the large-scale object discriminator was not updated at all"
+
+
+def _bench_protocol_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "obj-gan_amd")]
+    import time
+    import bench
+    calls = {"step": 0, "begin": 0, "end": 0}
+    acc = torch.zeros(1)
+
+    def step():                                   # a "training step": one collective, like the gradient exchange
+        calls["step"] += 1
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        acc.add_(t)
+        if rank == 1:
+            time.sleep(0.01)                      # the slow rank sets the time
+
+    def max_over_ranks(v):
+        t = torch.tensor([v], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def hook(name):
+        return (lambda: calls.__setitem__(name, calls[name] + 1)) if rank == 0 else None
+    dt, prof_dt = bench.timed_passes(step, dist.barrier, max_over_ranks, 5, 2, 3, hook("begin"), hook("end"))
+    dt0, none = bench.timed_passes(step, dist.barrier, max_over_ranks, 2, 0, 0)
+    q.put((rank, calls, float(acc), dt, prof_dt, none))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_bench_measurement_protocol_runs_every_pass_on_every_rank():
+    """bench.timed_passes on two gloo ranks with a step that contains a collective: warm-up, the timed
+    steps and the untimed profiling pass run on BOTH ranks (a pass on rank 0 alone leaves its collectives
+    unmatched -- the test would hang into its timeout), only rank 0 gets the profiling hooks, and the reported
+    time is the maximum over the ranks."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_protocol_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=100) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    (r0, c0, acc0, dt0, prof0, n0), (r1, c1, acc1, dt1, prof1, n1) = res
+    assert c0["step"] == c1["step"] == 2 + 5 + 3 + 2 and acc0 == acc1 == 2.0 * 12
+    assert (c0["begin"], c0["end"]) == (1, 1) and (c1["begin"], c1["end"]) == (0, 0)
+    assert dt0 == dt1 and dt0 >= 5 * 0.01 and prof0 is not None and prof1 is not None and n0 is None and n1 is None
