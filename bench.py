@@ -232,6 +232,11 @@ def _write_shape_table(lib, path, steps):
                 (kinds.get(key[0], "?"),) + key[1:] + (cnt / steps, tms / steps, tfl / (tms * 1e-3) / 1e12 if tms > 0 else 0)))
 
 
+def _rank_device(local_rank):
+    torch.cuda.set_device(local_rank)
+    return torch.device("cuda", local_rank)
+
+
 def timed_passes(step, barrier, max_over_ranks, steps, warmup, prof_steps, prof_begin=None, prof_end=None):
     """The measurement protocol, on EVERY rank alike (a step holds collectives under data parallelism, so no
     pass may run on a subset of the ranks): `warmup` untimed steps; exactly `steps` steps bracketed by
@@ -295,8 +300,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    device = _rank_device(local_rank)
     use_dist = world > 1 or args.force_ddp
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

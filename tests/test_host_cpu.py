@@ -297,3 +297,61 @@ def test_gradient_buckets_leave_in_descending_order_whatever_the_completion_orde
         elif order == list(range(len(arena.params)))[::-1]:
             assert rest == []
     arena._mark(0)                                                            # disarmed: hooks are inert
+
+
+def test_bench_main_end_to_end_on_the_cpu_shim(monkeypatch, capsys):
+    """bench.main() from argument parsing to the JSON line, with the kernels replaced by their CPU
+    definitions and the device calls stubbed (stage-1 workload, batch 2, one timed step + the profiling
+    pass): the line carries the contract's fields, the step count of the protocol is right, and the roofline
+    object is derived from the library's per-kernel records (here: two synthetic launches, 100 TFLOP/s)."""
+    import json
+    import sys
+    import bench
+    import cpu_ops_shim
+    import objgan_hip._lib as L
+    import trainer as T
+    from miscc.config import cfg
+    cpu_ops_shim.install(monkeypatch)
+
+    class FakeLib(object):
+        enabled = []
+
+        def objgan_prof_enable(self, on):
+            self.enabled.append(on)
+            return 1
+
+        def objgan_prof_collect(self, ms, fl, cnt):      # two recorded launches of one kernel instance
+            i = bench.CAT_NAMES.index("conv_igemm3_kernel<6, false>")
+            ms[i], fl[i], cnt[i] = 2.0, 2.0e11, 2
+            return 1
+    fake = FakeLib()
+    monkeypatch.setattr(L, "load", lambda *a, **k: fake)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(bench, "_rank_device", lambda r: torch.device("cpu"))
+    steps = []
+    real_step = T.condGANTrainer.train_step
+    monkeypatch.setattr(T.condGANTrainer, "train_step",
+                        lambda self, *a, **k: (steps.append(1), real_step(self, *a, **k))[1])
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--workload", "stage1", "--batch", "2", "--steps", "1",
+                                      "--warmup", "1", "--no-cpu-baseline", "--no-is-monitor"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    saved = cfg.TREE.BRANCH_NUM
+    try:
+        bench.main()
+    finally:
+        cfg.TREE.BRANCH_NUM = saved
+    line = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert len(steps) == 1 + 1 + 1 and fake.enabled == [1, 0]            # warm-up, timed, profiling pass
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config"):
+        assert k in res
+    assert res["n_gpus"] == 1 and res["steps"] == 1 and res["unit"] == "images/sec" and res["value"] > 0
+    assert res["metric"].endswith("at 64x64, batch 2 per GPU") and res["config"]["workload"].startswith("stage1_64x64")
+    roof = res["roofline"]
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["kernel"] == "conv_igemm3_kernel<6, false>"
+    assert abs(roof["achieved"] - 100.0) < 1e-6 and abs(roof["frac"] - 100.0 / roof["peak"]) < 1e-3
+    assert roof["traffic"] is None or roof["traffic"] > 1e8             # committed PMC record of that kernel
+    assert res["conv_total"]["tflops"] == roof["achieved"] and res["kernel_breakdown"][0]["launches_per_step"] == 2.0
+    assert "cpu_baseline" not in res and res["dtype"] == "fp32"
