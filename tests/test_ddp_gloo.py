@@ -276,3 +276,64 @@ def test_bench_measurement_protocol_runs_every_pass_on_every_rank():
     assert c0["step"] == c1["step"] == 2 + 5 + 3 + 2 and acc0 == acc1 == 2.0 * 12
     assert (c0["begin"], c0["end"]) == (1, 1) and (c1["begin"], c1["end"]) == (0, 0)
     assert dt0 == dt1 and dt0 >= 5 * 0.01 and prof0 is not None and prof1 is not None and n0 is None and n1 is None
+
+
+def _bench_main_worker(rank, world, port, q):
+    import io
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "obj-gan_amd"), os.path.join(root, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    torch.set_num_threads(4)
+    import bench
+    import cpu_ops_shim
+    import objgan_hip._lib as L
+    cpu_ops_shim.install_plain()
+
+    class FakeLib(object):
+        def objgan_prof_enable(self, on):
+            return 1
+
+        def objgan_prof_collect(self, ms, fl, cnt):
+            return 1
+    L.load = lambda *a, **k: FakeLib()
+    torch.cuda.is_available = lambda: True
+    torch.cuda.synchronize = lambda *a, **k: None
+    bench._rank_device = lambda r: torch.device("cpu")
+    real_init = dist.init_process_group
+    dist.init_process_group = lambda backend=None, rank=None, world_size=None, device_id=None, **k: \
+        real_init("gloo", rank=rank, world_size=world_size)
+    sys.argv = ["bench.py", "--gpus", str(world), "--workload", "stage1", "--batch", "2", "--steps", "1",
+                "--warmup", "1", "--no-is-monitor"]
+    out, real_stdout = io.StringIO(), sys.stdout
+    sys.stdout = out
+    try:
+        bench.main()
+    finally:
+        sys.stdout = real_stdout
+    q.put((rank, [ln for ln in out.getvalue().splitlines() if ln.startswith("{")]))
+
+
+@pytest.mark.timeout(300)
+def test_bench_main_on_two_ranks_prints_one_whole_job_line():
+    """`bench.py --gpus 2` as the driver launches it (RANK / WORLD_SIZE in the environment), on two gloo
+    ranks with the kernels' CPU definitions: both ranks walk through warm-up, timed steps, the profiling pass
+    and the teardown (every collective matched -- otherwise this test hangs into its timeout), rank 0 alone
+    prints the line, and the line counts the images of BOTH ranks."""
+    import json
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_main_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=280) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert len(res[0]) == 1 and res[1] == []
+    line = json.loads(res[0][0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["config"]["parallelism"] == "dp2"
+    assert line["scaling"] == "weak" and "cpu_baseline" not in line
+    assert abs(line["value"] - 4 * 1000.0 / line["ms_per_step"]) < 0.05 * line["value"]
