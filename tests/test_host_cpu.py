@@ -213,6 +213,12 @@ def test_main_cli_mirrors_the_reference_arguments(tmp_path):
         assert os.path.isdir(algo.model_dir) and algo.model_dir.startswith(str(tmp_path))
         ref_defaults = cli.parse_args([])
         assert ref_defaults.BATCH_SIZE == 24 and ref_defaults.gpu_ids == '-1' and not ref_defaults.FLAG
+        assert not ref_defaults.device_imgs and not ref_defaults.device_hmaps and not dataset.device_imgs
+        lean_args = cli.parse_args(["--data_dir", data_dir, "--device_imgs", "--device_hmaps", "--BATCH_SIZE", "2",
+                                    "--output_dir", str(tmp_path)])
+        lean_ds, lean_loader, _ = cli.build_training(lean_args, rank=0, world=1, device=torch.device("cpu"))
+        assert lean_ds.device_imgs and lean_ds.device_hmaps
+        assert lean_loader.collate_fn.__name__ == "collate_keep_images"
         cli.apply_args(ref_defaults)
         assert cfg.CUDA is False                      # '--gpu -1' switches CUDA off, like the reference
     finally:

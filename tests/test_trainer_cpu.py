@@ -180,9 +180,11 @@ def test_real_data_directory_through_the_training_step(monkeypatch):
     assert all(torch.isfinite(v).all() for v in got.values() if torch.is_tensor(v))
 
 
-def test_train_loop_checkpoints_and_resume(monkeypatch, tmp_path):
+@pytest.mark.parametrize("device_imgs", [False, True])
+def test_train_loop_checkpoints_and_resume(monkeypatch, tmp_path, device_imgs):
     """condGANTrainer.train() over a DataLoader of the committed data directory (reference loader
-    tuples), one epoch of two steps on the CPU shim: the checkpoint files have the reference's names,
+    tuples; with `device_imgs` the decoded 8-bit images, resized inside prepare_data), one epoch of two steps
+    on the CPU shim: the checkpoint files have the reference's names,
     the generator is saved with the EMA weights swapped in, and cfg.TRAIN.NET_G resumes from them
     (reference trainer.py:155-193, 251-273)."""
     import os
@@ -200,7 +202,7 @@ def test_train_loop_checkpoints_and_resume(monkeypatch, tmp_path):
     monkeypatch.setattr(cfg.TRAIN, "FLAG", True)
     torch.set_num_threads(8)
     ds = trainDataset.TrainDataset(os.path.join(ROOT, "tests", "golden", "data_tiny"), "train", base_size=64,
-                                   device_hmaps=True)
+                                   device_hmaps=True, device_imgs=device_imgs)
     g0 = torch.Generator().manual_seed(12)
     ds.image_encoder = _ConstEncoder(torch.randn(2, 256, 17, 17, generator=g0), torch.randn(2, 256, generator=g0))
     ds.text_encoder = rh.seeded_state_(M.RNN_ENCODER(ds.n_words, nhidden=cfg.TEXT.EMBEDDING_DIM), 91).eval()
