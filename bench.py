@@ -41,10 +41,19 @@ import torch.distributed as dist                # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3                   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0                  # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
 # timing categories of the library = kernel instances, named as rocprofv3 prints them
-CAT_NAMES = (["conv_igemm3_kernel<%d, false>" % tm for tm in range(1, 8)] +
-             ["conv_wgrad2_kernel<%d>" % tm for tm in range(1, 8)] +
-             ["conv_thin_kernel", "conv_thin3x3_kernel", "conv_igemm_kernel", "conv_wgrad_kernel",
-              "conv_igemm3_kernel<1, true>"] + ["conv_wgrad3_kernel<%d>" % tm for tm in range(1, 8)])
+MATH_IDS = {"fp32": 0, "bf16": 1, "bf16x3": 2}
+# bf16x3: six bf16 MFMAs (K = 16) do the work of eight fp32 ones (K = 2) at 16x their rate
+BF16X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
+
+
+def cat_names(math):
+    """rocprofv3's names of the kernel instances behind the library's timing categories (leading template
+    arguments: tile height, LDS-free form / arithmetic)."""
+    m = MATH_IDS[math]
+    return (["conv_igemm3_kernel<%d, false, %d>" % (tm, m) for tm in range(1, 8)] +
+            ["conv_wgrad2_kernel<%d, %d" % (tm, m) for tm in range(1, 8)] +
+            ["conv_thin_kernel", "conv_thin3x3_kernel", "conv_igemm_kernel", "conv_wgrad_kernel",
+             "conv_igemm3_kernel<1, true, %d>" % m] + ["conv_wgrad3_kernel<%d, %d" % (tm, m) for tm in range(1, 8)])
 PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
@@ -286,9 +295,10 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="stage3_obj",
                     help="stage3_obj: the configuration BASELINE's metric is quoted on (default); stage3 / stage1: "
                          "BASELINE configs 3 and 2 (parity-test cases; their lines are side records, not the metric)")
-    ap.add_argument("--math", choices=("fp32", "bf16"), default="fp32",
-                    help="fp32: exact fp32 MFMA (headline, parity path); bf16: mixed precision of BASELINE "
-                         "config 5 (bf16 matrix-core inputs, fp32 accumulation / storage / norms / optimizer)")
+    ap.add_argument("--math", choices=("fp32", "bf16x3", "bf16"), default="fp32",
+                    help="fp32: fp32 operands on the fp32 MFMA; bf16x3: fp32 operands split exactly three ways on the "
+                         "bf16 MFMA, six partial products, fp32 accumulation (fp32 results); bf16: mixed precision of "
+                         "BASELINE config 5 (bf16 matrix-core inputs, fp32 accumulation / storage / norms / optimizer)")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 16
@@ -355,7 +365,8 @@ def main():
             "value": round(n_img / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp32" if args.math == "fp32" else "bf16-in/fp32-acc (mixed precision, config 5)",
+            "dtype": {"fp32": "fp32", "bf16x3": "fp32 (operands split 3-way on the bf16 MFMA, fp32 accumulate)",
+                      "bf16": "bf16-in/fp32-acc (mixed precision, config 5)"}[args.math],
             "data": "synthetic",
             "config": {"workload": workload_name + ("" if args.no_is_monitor else "+IS-monitor"),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
@@ -367,6 +378,7 @@ def main():
             fl = (ctypes.c_double * 32)()
             cnt = (ctypes.c_long * 32)()
             lib.objgan_prof_collect(ms, fl, cnt)
+            CAT_NAMES = cat_names(args.math)
             cats = [(CAT_NAMES[i], ms[i], fl[i], cnt[i]) for i in range(len(CAT_NAMES)) if cnt[i] > 0]
             cats.sort(key=lambda c: -c[1])
             if cats:
@@ -382,7 +394,8 @@ def main():
                         traffic = ent["hbm_bytes_per_launch"] if ent else None
                     except (ValueError, KeyError, OSError):
                         traffic = None
-                peak = FP32_MFMA_PEAK_TFLOPS if args.math == "fp32" else BF16_MFMA_PEAK_TFLOPS
+                peak = {"fp32": FP32_MFMA_PEAK_TFLOPS, "bf16": BF16_MFMA_PEAK_TFLOPS,
+                        "bf16x3": round(BF16X3_PEAK_TFLOPS, 1)}[args.math]
                 res["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2),
                                    "peak": peak, "unit": "TFLOP/s",
                                    "frac": round(ach / peak, 4), "traffic": traffic if args.math == "fp32" else None,

@@ -54,7 +54,7 @@ int objgan_avgpool2s1_backward(const float* grad_out, float* grad_in, long plane
 
 /* ---- implicit-GEMM convolution on MFMA (reference model.py conv stacks, via cuDNN) ---------- */
 long objgan_conv_packed_floats(int M, int C, int T);
-/* layout class (0..3) of the packed bank objgan_conv_igemm uses for these arguments: part of the key of
+/* layout class (0..4) of the packed bank objgan_conv_igemm uses for these arguments: part of the key of
  * any caller-side bank cache (the same filter is served by different kernels at different sizes) */
 int objgan_conv_bank_layout(int N, int C, int H, int W, int M, int Tg, int PH, int PW, int act, int math);
 /* y[n,m,a*osh+ooh,b*osw+oow] = act(bias[m] + sum_{c,t} Wp[m][c*Tg+t] * x[n,c,a*s+dh[t],b*s+dw[t]])
@@ -67,8 +67,10 @@ int objgan_conv_bank_layout(int N, int C, int H, int W, int M, int Tg, int PH, i
  * wt_packed=1: wt still holds the packed bank written by an earlier call with the same w, taps,
  * transpose flag, math and input size class (the caller caches it while w is unchanged); 0: pack now.
  * math: 0 = fp32 MFMA (exact fp32 fmaf chains); 1 = mixed precision (BASELINE config 5): operands rounded
- * to bf16 (RNE) at the matrix-core inputs, fp32 accumulation, fp32 tensors in HBM.  Outputs with <= 32
- * channels always run on the fp32 VALU kernels. */
+ * to bf16 (RNE) at the matrix-core inputs, fp32 accumulation, fp32 tensors in HBM; 2 = "bf16x3": fp32 results on
+ * the bf16 matrix pipe -- every fp32 operand is split exactly into three bf16 pieces (24 = 8 + 8 + 8 significand
+ * bits) and the six largest of the nine partial products are accumulated in fp32; what is dropped is below 2^-24
+ * of a product.  Outputs with <= 32 channels always run on the fp32 VALU kernels. */
 int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* y, float* wt,
                       int N, int C, int H, int W, int upsample, int pad_mode,
                       int Cout, int Cin, int Torig, int transpose,
@@ -79,12 +81,12 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
 /* ring (may be NULL): data gradient of a ReflectionPad2d(1) convolution without the padded intermediate -- the
  * GEMM runs over the padded pixel grid (PH = OHf + 2, PW = OWf + 2, y is the UNPADDED gradient), interior
  * pixels are stored into y, the one-pixel border into ring [N*M][2*PW + 2*PH]; objgan_reflect_ring_fold then
- * adds the border back at its mirror positions.  Only for calls objgan_conv_bank_layout classifies as 1. */
+ * adds the border back at its mirror positions.  Only for calls objgan_conv_bank_layout classifies as 1 or 4. */
 int objgan_reflect_ring_fold(const float* ring, float* y, long planes, int H, int W, void* stream);
 /* Data gradient of a stride-2 convolution whose four output parity phases have the same number
  * of taps (k=4, pad 1, even sizes): one launch for all phases.  x = dY [N,Cout,OH,OW],
  * y = dX [N,Cin,2*PH,2*PW], fully written (no pre-zeroing).  dh/dw/src_tap: 4 x Tg entries, phase
- * p = (row parity << 1) | column parity.  wt: 4*Cin*Tg*ceil16(Cout) floats; wt_packed as above. */
+ * p = (row parity << 1) | column parity.  wt: 4*ceil(1.5*Cin*Tg*ceil16(Cout)) floats; wt_packed as above. */
 int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float* wt,
                                 int N, int Cout, int OH, int OW, int Cin, int Torig,
                                 int Tg, const int* dh, const int* dw, const int* src_tap,

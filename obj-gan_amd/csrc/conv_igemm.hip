@@ -38,6 +38,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #define OG_MAX_TAPS 32
 #define OG_ACT_NONE 0
@@ -83,6 +84,59 @@ __device__ __forceinline__ float og_act(float v, int act) {
     if (act == OG_ACT_RELU) return fmaxf(v, 0.f);
     return v;
 }
+
+// ---- fp32 on the bf16 matrix pipe ("bf16x3": the name oneMKL uses for the same scheme) -------------------
+// gfx950 runs v_mfma_f32_32x32x16_bf16 at 16x the rate of v_mfma_f32_32x32x2_f32.  An fp32 value is EXACTLY the
+// sum of three bf16 values (24 significand bits = 8 + 8 + 8, round-to-nearest at every cut, the residuals are
+// exact in fp32): x = h + m + l.  A product of two such values is the sum of nine bf16 x bf16 products, each
+// exact in the fp32 accumulator; the six largest -- hh, hm, mh, mm, hl, lh -- leave out terms below
+// 2^-24 |x||y| per product (measured on K = 1746 rows: 5.9e-9 relative against 1.9e-7 of fp32 accumulation
+// rounding itself; tests/test_kernels_gpu.py pins split-mode error <= 1.1 x native fp32 error against an fp64
+// evaluation).  Six MFMAs per 16-deep K step instead of eight f32 ones at 1/16 of the rate: 2.67x the fp32
+// matrix peak (416.7 TFLOP/s of fp32-equivalent work).
+// (plain v_sub_f32 through asm: hipcc SLP-packs adjacent fp32 subtractions into v_pk_add_f32, which costs the
+// MFMA stream beside it ~13 cycles each -- MI355X_MICROARCH.md, "price of one filler beside MFMAs")
+__device__ __forceinline__ float og_sub(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void og_split8_h(const float* v, bf16x8& h) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (__bf16)v[j];
+}
+__device__ __forceinline__ void og_split8_ml(const float* v, const bf16x8& h, bf16x8& m, bf16x8& l) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float r1 = og_sub(v[j], (float)h[j]);
+        const __bf16 mj = (__bf16)r1;
+        m[j] = mj; l[j] = (__bf16)og_sub(r1, (float)mj);
+    }
+}
+__device__ __forceinline__ void og_split8(const float* v, bf16x8& h, bf16x8& m, bf16x8& l) {
+    og_split8_h(v, h);
+    og_split8_ml(v, h, m, l);
+}
+// after a sched_barrier: pin `pairs` x (one MFMA, then `valu` VALU instructions) in issue order
+template <int PAIRS, int VALU>
+__device__ __forceinline__ void og_interleave() {
+#pragma unroll
+    for (int j = 0; j < PAIRS; ++j) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, VALU, 0);
+    }
+}
+__device__ __forceinline__ void og_split4(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const __bf16 hj = (__bf16)v[j];
+        const float r1 = og_sub(v[j], (float)hj);
+        const __bf16 mj = (__bf16)r1;
+        h[j] = hj; m[j] = mj; l[j] = (__bf16)og_sub(r1, (float)mj);
+    }
+}
+// the six products of one row group and K step, smallest terms first
+#define OG_MFMA_BF(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
 
 // bijective XCD-aware remap of a linear workgroup id (dispatcher places id b on XCD b % 8)
 __device__ __forceinline__ int og_xcd_remap(int id, int nwg) {
@@ -501,6 +555,8 @@ struct PackArgs {
     int m_major;         // 0: wt[K][Mpad] (v1 kernels), 1: wt[M][Kpad] (k contiguous, v2 kernel),
                          // 2: wt[Ck][Tg][Mpad] with Mpad = MT (thin direct kernel)
                          // 3: bf16 wt[M][Krow], Krow = Kpad rounded up to 32 (bf16 MFMA kernels)
+                         // 4: bf16x3 split wt[M][Kpad/16][3][16]: every fp32 entry as its exact three-way bf16
+                         //    split h + m + l (og_split8), the three pieces of a 16-deep K step back to back
     signed char src_tap[OG_MAX_TAPS];
 };
 
@@ -541,6 +597,21 @@ __device__ __forceinline__ void pack_element(const PackArgs& a, unsigned i, int 
     a.wt[i] = v;
 }
 
+// element k of the bank row starting at `row` (element units of the layout)
+__device__ __forceinline__ void pack_store(const PackArgs& a, size_t row, int k, float v) {
+    if (a.m_major == 4) {
+        __bf16* o = reinterpret_cast<__bf16*>(a.wt) + row + (size_t)(k >> 4) * 48 + (k & 15);
+        const __bf16 h = (__bf16)v;
+        const float r1 = v - (float)h;
+        const __bf16 m = (__bf16)r1;
+        o[0] = h; o[16] = m; o[32] = (__bf16)(r1 - (float)m);
+    } else if (a.m_major == 3) {
+        reinterpret_cast<__bf16*>(a.wt)[row + k] = (__bf16)v;
+    } else {
+        a.wt[row + k] = v;
+    }
+}
+
 // pair i = m * Cp + ck of the row-major layouts
 __device__ __forceinline__ void pack_pair(const PackArgs& a, unsigned i, int Kpad, int Krow) {
     const unsigned m = i / (unsigned)a.Cp;
@@ -565,17 +636,13 @@ __device__ __forceinline__ void pack_pair(const PackArgs& a, unsigned i, int Kpa
             float v = 0.f;
 #pragma unroll
             for (int j = 0; j < 16; ++j) v = st == j ? r[j] : v;
-            const size_t o = row + (size_t)t * a.Cp + ck;
-            if (a.m_major == 3) reinterpret_cast<__bf16*>(a.wt)[o] = (__bf16)v;
-            else a.wt[o] = v;
+            pack_store(a, row, t * a.Cp + ck, v);
         }
     } else {
         for (int t = 0; t < a.Tg; ++t) {
             const int st = a.src_tap[t];
             const float v = (live && st >= 0) ? src[st] : 0.f;
-            const size_t o = row + (size_t)t * a.Cp + ck;
-            if (a.m_major == 3) reinterpret_cast<__bf16*>(a.wt)[o] = (__bf16)v;
-            else a.wt[o] = v;
+            pack_store(a, row, t * a.Cp + ck, v);
         }
     }
     if (a.m_major == 3 && ck < Krow - Kpad)               // bf16 rows are padded to a multiple of 32
@@ -583,13 +650,13 @@ __device__ __forceinline__ void pack_pair(const PackArgs& a, unsigned i, int Kpa
 }
 
 __device__ __forceinline__ void pack_item(const PackArgs& a, long i, int Kpad, int Krow) {
-    if (a.m_major == 1 || a.m_major == 3) pack_pair(a, (unsigned)i, Kpad, Krow);
+    if (a.m_major == 1 || a.m_major >= 3) pack_pair(a, (unsigned)i, Kpad, Krow);
     else pack_element(a, (unsigned)i, Kpad);
 }
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
     const int Kpad = a.Tg * a.Cp;
-    const int Krow = a.m_major == 3 ? (Kpad + 31) / 32 * 32 : Kpad;
+    const int Krow = a.m_major == 3 ? (Kpad + 31) / 32 * 32 : (a.m_major == 4 ? 3 * Kpad : Kpad);
     const long total = pack_total(a, Kpad, Krow);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
         pack_item(a, i, Kpad, Krow);
@@ -606,7 +673,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackArgs* __restrict__ jobs) {
     const PackArgs a = jobs[blockIdx.y];
     const int Kpad = a.Tg * a.Cp;
-    const int Krow = a.m_major == 3 ? (Kpad + 31) / 32 * 32 : Kpad;
+    const int Krow = a.m_major == 3 ? (Kpad + 31) / 32 * 32 : (a.m_major == 4 ? 3 * Kpad : Kpad);
     const long total = pack_total(a, Kpad, Krow);
     for (long base = (long)blockIdx.x * OG_PACK_CHUNK; base < total; base += (long)gridDim.x * OG_PACK_CHUNK) {
 #pragma unroll
@@ -804,17 +871,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 // SCALAR (n, oh, ow0 .. ow0+7), the per-lane part is the column's (ci, kh, kw) -- dy rows are read
 // as aligned 16-byte pieces with a constant per-lane offset, x elements as dwords whose validity
 // (zero padding) rides on the buffer range check.
-template <int TM, bool BF = false, int XR = 0>
+template <int TM, int MATH = 0, int XR = 0>
 __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, const int KS) {
+    // MATH as in conv_igemm3_kernel.  SP (bf16x3): both operands are activations, so both are split when they are
+    // written to LDS -- by the thread that loaded them, once per element (not once per wave that reads them) --
+    // into the row image [h 16 | m 16 | l 16] bf16 + 16 bytes of padding (112-byte pitch).
+    constexpr bool BF = MATH == 1, SP = MATH == 2;
     constexpr int BM = 32 * TM;
     constexpr int BN = 128;
     constexpr int BK = 16;
-    constexpr int LD = BK + 4;
+    constexpr int LD = SP ? 28 : BK + 4;
     constexpr int NA4 = BM * 4;
     constexpr int NA_PER = (NA4 + 255) / 256;
     constexpr int AROWS = BM + XR;                     // dy rows in LDS (XR extra rows, see WgradArgs)
     constexpr int TILE = (AROWS + BN) * LD;
-    static_assert(XR == 0 || !BF, "extra rows: fp32 only");
+    static_assert(XR == 0 || MATH == 0, "extra rows: fp32 only");
 
     __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
 
@@ -872,7 +943,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
         const int row = idx >> 2, q = idx & 3;
         const bool on = (NA4 % 256 == 0 || idx < NA4) && (m0 + row) < a.m_end;
         avoff[i] = on ? ((unsigned)(m0 + row) * (unsigned)OHW + q * 4u) * 4u : OG_OOB;
-        alds[i] = (NA4 % 256 == 0 || idx < NA4) ? row * LD + q * 4 : -1;
+        alds[i] = (NA4 % 256 == 0 || idx < NA4) ? row * LD + q * (SP ? 2 : 4) : -1;   // SP: 8-byte h piece of 4 pixels
     }
 
     const bool has_x = XR > 0 && tile_m == 0 && a.xr_count > 0;
@@ -923,6 +994,24 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
     auto store_step = [&](int buf) {
         float* As = lds + buf * TILE;
         float* Bs = As + AROWS * LD;
+        if (SP) {
+#pragma unroll
+            for (int i = 0; i < NA_PER; ++i) {
+                bf16x4 h, m, l;
+                og_split4(ra[i], h, m, l);
+                if (NA4 % 256 == 0 || alds[i] >= 0) {
+                    *reinterpret_cast<bf16x4*>(As + alds[i]) = h;
+                    *reinterpret_cast<bf16x4*>(As + alds[i] + 8) = m;
+                    *reinterpret_cast<bf16x4*>(As + alds[i] + 16) = l;
+                }
+            }
+            bf16x8 h, m, l;
+            og_split8(rb, h, m, l);
+            *reinterpret_cast<bf16x8*>(Bs + bc * LD + bg * 4) = h;
+            *reinterpret_cast<bf16x8*>(Bs + bc * LD + bg * 4 + 8) = m;
+            *reinterpret_cast<bf16x8*>(Bs + bc * LD + bg * 4 + 16) = l;
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NA_PER; ++i)
             if (NA4 % 256 == 0 || alds[i] >= 0) *reinterpret_cast<f32x4*>(As + alds[i]) = ra[i];
@@ -940,8 +1029,8 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
 
     const int lrow = lane >> 5;
     const int lcol = lane & 31;
-    const int a_rd = lcol * LD + lrow * 8;
-    const int b_rd = AROWS * LD + (wid * 32 + lcol) * LD + lrow * 8;
+    const int a_rd = lcol * LD + lrow * (SP ? 4 : 8);
+    const int b_rd = AROWS * LD + (wid * 32 + lcol) * LD + lrow * (SP ? 4 : 8);
 
     f32x16 acc[TM];
 #pragma unroll
@@ -954,7 +1043,34 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const float* Tl = lds + cur * TILE;
-        if (BF) {           // bf16 inputs (RNE of the fp32 tiles), one 32x32x16 MFMA per row group and K step
+        if (SP) {           // bf16x3: fragments are the pre-split LDS rows; refill behind the first TM MFMAs
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Tl + b_rd);
+            const bf16x8 bm = *reinterpret_cast<const bf16x8*>(Tl + b_rd + 8);
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Tl + b_rd + 16);
+            bf16x8 ah[TM], am[TM], al[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                al[i] = *reinterpret_cast<const bf16x8*>(Tl + a_rd + i * 32 * LD + 16);
+                ah[i] = *reinterpret_cast<const bf16x8*>(Tl + a_rd + i * 32 * LD);
+                am[i] = *reinterpret_cast<const bf16x8*>(Tl + a_rd + i * 32 * LD + 8);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OG_MFMA_BF(al[i], bh, acc[i]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OG_MFMA_BF(ah[i], bl, acc[i]);
+            __builtin_amdgcn_sched_barrier(0);
+            if ((kt + 1) < nk) store_step(cur ^ 1);      // (splits the tile loaded one step ago: ~110 VALU)
+            if ((kt + 2) < nk) load_step();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OG_MFMA_BF(am[i], bm, acc[i]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OG_MFMA_BF(am[i], bh, acc[i]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OG_MFMA_BF(ah[i], bm, acc[i]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OG_MFMA_BF(ah[i], bh, acc[i]);
+        } else if (BF) {    // bf16 inputs (RNE of the fp32 tiles), one 32x32x16 MFMA per row group and K step
             if ((kt + 1) < nk) store_step(cur ^ 1);      // two-deep register -> LDS pipeline
             if ((kt + 2) < nk) load_step();
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(Tl + b_rd);
@@ -1045,24 +1161,33 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
 // barriers at all: waves are independent and latency is hidden by occupancy.
 // (A chunk-major K order -- all taps of a 16-channel chunk back to back, hoping for L1 hits between the
 // shifted windows -- was measured in round 2 and lost on every shape: profiles/r02_ab_convbench_variants.txt.)
-template <int TM, bool ADIRECT = false, bool BF = false>
+template <int TM, bool ADIRECT = false, int MATH = 0>
 __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
+    // MATH 0: fp32 MFMA; 1 (BF): bf16-rounded operands; 2 (SP): fp32 operands split three ways on the bf16 MFMA
+    // (og_split8).  SP: one iteration = one 16-deep K step like fp32; the bank holds the PRE-SPLIT filter rows,
+    // [M][Kpad/16][h,m,l][16] bf16 = 96 bytes per row and step, LDS row pitch 112 bytes (an odd multiple of 16:
+    // the 16 lanes of a ds_read_b128 group fall on 16 different 16-byte slots); the pixel fragment is split in
+    // registers (~44 VALU instructions per step next to 6 * TM MFMAs).
+    constexpr bool BF = MATH == 1, SP = MATH == 2;
     constexpr int BM = 32 * TM;
     constexpr int BN = 128;
     constexpr int BK = 16;
-    constexpr int LD = BK + 4;
-    constexpr int NA4 = BM * 4;
+    constexpr int LD = SP ? 28 : BK + 4;              // floats per LDS row
+    constexpr int PIECES = SP ? 6 : 4;                // 16-byte pieces of a bank row per iteration
+    constexpr int ABYTES = PIECES * 16;
+    constexpr int NA4 = BM * PIECES;
     constexpr int NA_PER = (NA4 + 255) / 256;
     constexpr int TILE = BM * LD;
+    constexpr int NAD = SP ? 3 : 2;                   // direct row fragments per lane (TM = 1 LDS-free form)
     constexpr bool ALDS = !(ADIRECT && TM == 1);      // row operand through LDS (shared by 4 waves)
     // BF: bf16 inputs (round-to-nearest-even of the fp32 operands) on v_mfma_f32_32x32x16_bf16, fp32
     // accumulation.  One loop iteration then covers 32 k (two 16-channel gathers, two MFMAs per row
     // group); the bank is bf16 [M][Krow], so a row piece is again 64 bytes per iteration and the
     // LDS image / fragment reads keep their 80-byte pitch.
-    constexpr int ESZ = BF ? 2 : 4;
+    constexpr int ESZ = (BF || SP) ? 2 : 4;
     constexpr int NB = BF ? 16 : 8;                   // gathered pixel-operand values per lane and iteration
 
-    __shared__ __attribute__((aligned(16))) float lds[ALDS ? 2 * TILE : 4];
+    __shared__ __attribute__((aligned(16))) float lds[ALDS ? (SP ? 3 : 2) * TILE : 4];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1149,19 +1274,22 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
 #pragma unroll
         for (int i = 0; i < NA_PER; ++i) {
             const int idx = tid + 256 * i;
-            const int row = idx >> 2, q = idx & 3;
+            const int row = idx / PIECES, q = idx - row * PIECES;
             const bool on = (NA4 % 256 == 0 || idx < NA4) && (m0 + row) < a.m_end;
             avoff[i] = on ? (unsigned)(m0 + row) * (unsigned)a.Krow * (unsigned)ESZ + q * 16u : OG_OOB;
             alds[i] = (NA4 % 256 == 0 || idx < NA4) ? row * LD + q * 4 : -1;
         }
     }
     const unsigned adir = (m0 + lcol) < a.m_end
-        ? (unsigned)(m0 + lcol) * (unsigned)a.Krow * (unsigned)ESZ + lrow * (BF ? 16u : 32u) : OG_OOB;
+        ? (unsigned)(m0 + lcol) * (unsigned)a.Krow * (unsigned)ESZ + lrow * ((BF || SP) ? 16u : 32u) : OG_OOB;
     f32x4 ra[NA_PER];
     auto load_a = [&](int kt) {
+        // (SP: hipcc keeps the strength-reduced offset of the three-step loop in a VGPR -- SGPR pressure -- and would
+        // wrap every load in a waterfall loop; one readfirstlane instead)
+        const int so = SP ? __builtin_amdgcn_readfirstlane(kt * ABYTES) : kt * ABYTES;
 #pragma unroll
         for (int i = 0; i < NA_PER; ++i)
-            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, avoff[i], kt * (BK * 4), 0));
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, avoff[i], so, 0));
     };
     auto store_a = [&](int buf) {
         float* As = lds + buf * TILE;
@@ -1188,17 +1316,59 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
 
     const int a_rd = lcol * LD + lrow * 8;
     float rb0[NB], rb1[NB];
-    f32x4 ad0[2], ad1[2];                              // TM == 1: direct row fragments (ping-pong)
-    auto load_adir = [&](f32x4 (&ad)[2], int kt) {
-        ad[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, adir, kt * (BK * 4), 0));
-        ad[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, adir + (BF ? 32u : 16u), kt * (BK * 4), 0));
+    f32x4 ad0[NAD], ad1[NAD];                          // TM == 1: direct row fragments (ping-pong)
+    auto load_adir = [&](f32x4 (&ad)[NAD], int kt) {
+        const int so = SP ? __builtin_amdgcn_readfirstlane(kt * ABYTES) : kt * ABYTES;
+        ad[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, adir, so, 0));
+        ad[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, adir + ((BF || SP) ? 32u : 16u), so, 0));
+        if (SP) ad[NAD - 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, adir + 64u, so, 0));
     };
     // `mid`: the refill of the software pipeline (LDS store of the next row tile, next pixel gather, next
     // row-tile load).  Issue is in order, so work placed in FRONT of a step's MFMAs is exposed every step;
     // in the fp32 LDS form it goes behind the first TM MFMAs and runs in the shadow of the rest (r02:
     // weight-gradient kernel 110 -> 119 TFLOP/s with the same move).
-    auto mma = [&](const float (&rb)[NB], const f32x4 (&ad)[2], int cur, auto&& mid) {
-        if (BF || !ALDS) mid();
+    auto mma = [&](const float (&rb)[NB], const f32x4 (&ad)[NAD], int cur, auto&& mid) {
+        if (BF || !ALDS) mid();       // (SP with LDS: behind its first TM MFMAs, below)
+        if (SP) {
+            // Order: the three products that need only the h piece of the pixel fragment first (4 conversions), the
+            // refill behind the first TM of them, the m / l pieces (~40 VALU) pinned between the next 2 TM MFMAs.
+            bf16x8 bh, bm, bl;
+            og_split8_h(rb, bh);
+            bf16x8 ah[TM], am[TM], al[TM];
+            if (ALDS) {
+                const char* T = reinterpret_cast<const char*>(lds + cur * TILE) + lcol * (LD * 4) + lrow * 16;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    al[i] = *reinterpret_cast<const bf16x8*>(T + i * 32 * LD * 4 + 64);
+                    am[i] = *reinterpret_cast<const bf16x8*>(T + i * 32 * LD * 4 + 32);
+                    ah[i] = *reinterpret_cast<const bf16x8*>(T + i * 32 * LD * 4);
+                }
+            } else {
+                ah[0] = __builtin_bit_cast(bf16x8, ad[0]);
+                am[0] = __builtin_bit_cast(bf16x8, ad[1]);
+                al[0] = __builtin_bit_cast(bf16x8, ad[NAD - 1]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OG_MFMA_BF(al[i], bh, acc[i]);
+            if (ALDS) {
+                __builtin_amdgcn_sched_barrier(0);
+                mid();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            og_split8_ml(rb, bh, bm, bl);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OG_MFMA_BF(am[i], bh, acc[i]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OG_MFMA_BF(ah[i], bh, acc[i]);
+            if (ALDS) og_interleave<2 * TM, (40 + 2 * TM - 1) / (2 * TM)>();
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OG_MFMA_BF(am[i], bm, acc[i]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OG_MFMA_BF(ah[i], bm, acc[i]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OG_MFMA_BF(ah[i], bl, acc[i]);
+            return;
+        }
         if (BF) {
             bf16x8 bq[2];
 #pragma unroll
@@ -1262,11 +1432,12 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
     if (ALDS) {
         load_a(kt0);
         store_a(0);
-        if (kt0 + 1 < nk) load_a(kt0 + 1);
+        if (SP || kt0 + 1 < nk) load_a(kt0 + 1);
     } else {
         load_adir(ad0, kt0);
     }
     load_b(rb0);
+    if (SP && ALDS) load_b(rb1);
     if (ALDS) __syncthreads();
     int cur = 0;
     // Two steps per trip with the fragment registers in fixed ping-pong roles (rb0/ad0 even, rb1/ad1
@@ -1280,7 +1451,7 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
         // (8 MFMAs, ~0.25 us) is shorter than a loaded L2 round trip whenever fewer than ~5 waves
         // share a SIMD, which is exactly the small-grid case this form serves.
         float rb2[NB];
-        f32x4 ad2[2];
+        f32x4 ad2[NAD];
         // (the loads run up to two steps past the end, unconditionally: a branch around them makes
         // hipcc's wait-count insertion drain everything at the next MFMA block; the surplus reads
         // land inside the buffers or on the range check and are never used)
@@ -1295,6 +1466,36 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
         }
         if (kt < nk) mma(rb0, ad0, 0, [] {});
         if (kt + 1 < nk) mma(rb1, ad1, 0, [] {});
+        kt = nk;
+    }
+    if (SP && ALDS) {
+        // Split mode: a step is 6 * TM MFMAs of 32 cycles -- shorter than a loaded gather round trip for the
+        // short tiles -- so the pixel gather runs TWO steps ahead (three fragment sets in fixed rotation, three
+        // steps per trip).  Order inside the refill: LDS store of the row tile loaded one step ago, load of the
+        // next row tile, THEN the gather: vector-memory results return in order, so the wait for the row tile in
+        // the next step leaves the younger gather in flight.  Loads run up to two steps past the end,
+        // unconditionally (inside the buffers or on the range check, never used).  Three LDS row tiles in the
+        // same rotation: every buffer index is a literal (a run-time `cur` ended up in a VGPR here -- hipcc merged
+        // its initial 0 with the zero of the accumulator init -- and with it every LDS address and the scalar
+        // offsets of the row loads: waterfall loops around each buffer_load).
+        float rb2[NB];
+        int ks = kt0;
+        if (ks + 2 < nk) {
+            do {
+                mma(rb0, ad0, 0, [&]() { store_a(1); load_a(ks + 2); load_b(rb2); });
+                __syncthreads();
+                mma(rb1, ad0, 1, [&]() { store_a(2); load_a(ks + 3); load_b(rb0); });
+                __syncthreads();
+                mma(rb2, ad0, 2, [&]() { store_a(0); load_a(ks + 4); load_b(rb1); });
+                __syncthreads();
+                ks += 3;
+            } while (ks + 2 < nk);
+        }
+        if (ks < nk) {
+            mma(rb0, ad0, 0, [&]() { store_a(1); });
+            __syncthreads();
+        }
+        if (ks + 1 < nk) mma(rb1, ad0, 1, [] {});
         kt = nk;
     }
     for (; kt + 1 < nk; kt += 2) {
@@ -1366,19 +1567,23 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
 // B128: on the stride-1 interior fast path the eight consecutive pixels of a lane are fetched as two
 // 16-byte loads (4-byte aligned) instead of eight dwords -- the lanes of a wave sit on different
 // (channel, tap) planes, so every gather instruction touches ~20 cache lines.
-template <int TM, bool BF = false, bool B128 = false, int XR = 0>
+template <int TM, int MATH = 0, bool B128 = false, int XR = 0>
 __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, const int KS) {
+    // MATH as in conv_igemm3_kernel.  SP (bf16x3): the dy rows are split by their loader thread on the way into
+    // LDS (row image [h 16 | m 16 | l 16] bf16, 112-byte pitch), the gathered x fragment in registers; the gather
+    // runs two steps ahead (three fragment sets), see conv_igemm3_kernel.
+    constexpr bool BF = MATH == 1, SP = MATH == 2;
     constexpr int BM = 32 * TM;
     constexpr int BN = 128;
     constexpr int BK = 16;
-    constexpr int LD = BK + 4;
+    constexpr int LD = SP ? 28 : BK + 4;
     constexpr int NA4 = BM * 4;
     constexpr int NA_PER = (NA4 + 255) / 256;
     constexpr int TILE = (BM + XR) * LD;
     constexpr bool ALDS = TM > 1;
-    static_assert(XR == 0 || (!BF && TM > 1), "extra rows: fp32 LDS form only");
+    static_assert(XR == 0 || (MATH == 0 && TM > 1), "extra rows: fp32 LDS form only");
 
-    __shared__ __attribute__((aligned(16))) float lds[ALDS ? 2 * TILE : 4];
+    __shared__ __attribute__((aligned(16))) float lds[ALDS ? (SP ? 3 : 2) * TILE : 4];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1489,7 +1694,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, con
             const int row = idx >> 2, q = idx & 3;
             const bool on = (NA4 % 256 == 0 || idx < NA4) && (m0 + row) < a.m_end;
             avoff[i] = on ? ((unsigned)(m0 + row) * (unsigned)OHW + q * 4u) * 4u : OG_OOB;
-            alds[i] = (NA4 % 256 == 0 || idx < NA4) ? row * LD + q * 4 : -1;
+            alds[i] = (NA4 % 256 == 0 || idx < NA4) ? row * LD + q * (SP ? 2 : 4) : -1;
         }
     }
     const unsigned adir = (m0 + lcol) < a.m_end ? ((unsigned)(m0 + lcol) * (unsigned)OHW + lrow * 8u) * 4u : OG_OOB;
@@ -1517,6 +1722,19 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, con
     };
     auto store_a = [&](int buf) {
         float* As = lds + buf * TILE;
+        if (SP) {
+#pragma unroll
+            for (int i = 0; i < NA_PER; ++i) {
+                bf16x4 h, m, l;
+                og_split4(ra[i], h, m, l);
+                if (NA4 % 256 == 0 || alds[i] >= 0) {
+                    *reinterpret_cast<bf16x4*>(As + alds[i]) = h;
+                    *reinterpret_cast<bf16x4*>(As + alds[i] + 8) = m;
+                    *reinterpret_cast<bf16x4*>(As + alds[i] + 16) = l;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NA_PER; ++i)
             if (NA4 % 256 == 0 || alds[i] >= 0) *reinterpret_cast<f32x4*>(As + alds[i]) = ra[i];
@@ -1533,7 +1751,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, con
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    const int a_rd = lcol * LD + lrow * 8;
+    const int a_rd = lcol * LD + lrow * (SP ? 4 : 8);
     float accx[XR > 0 ? XR : 1];
 #pragma unroll
     for (int j = 0; j < (XR > 0 ? XR : 1); ++j) accx[j] = 0.f;
@@ -1541,6 +1759,43 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, con
     f32x4 ad0[2], ad1[2];
     auto mma = [&](const float (&rb)[8], const f32x4 (&ad)[2], int cur, auto&& mid) {      // mid: see conv_igemm3_kernel
         if (BF || !ALDS) mid();
+        if (SP) {                                       // order and pinning: see conv_igemm3_kernel
+            bf16x8 bh, bm, bl;
+            og_split8_h(rb, bh);
+            bf16x8 ah[TM], am[TM], al[TM];
+            if (ALDS) {
+                const float* Tl = lds + cur * TILE;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    al[i] = *reinterpret_cast<const bf16x8*>(Tl + a_rd + i * 32 * LD + 16);
+                    am[i] = *reinterpret_cast<const bf16x8*>(Tl + a_rd + i * 32 * LD + 8);
+                    ah[i] = *reinterpret_cast<const bf16x8*>(Tl + a_rd + i * 32 * LD);
+                }
+            } else {
+                const float d[8] = {ad[0][0], ad[0][1], ad[0][2], ad[0][3], ad[1][0], ad[1][1], ad[1][2], ad[1][3]};
+                og_split8(d, ah[0], am[0], al[0]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OG_MFMA_BF(al[i], bh, acc[i]);
+            if (ALDS) {
+                __builtin_amdgcn_sched_barrier(0);
+                mid();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            og_split8_ml(rb, bh, bm, bl);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OG_MFMA_BF(am[i], bh, acc[i]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OG_MFMA_BF(ah[i], bh, acc[i]);
+            if (ALDS) og_interleave<2 * TM, (40 + 2 * TM - 1) / (2 * TM)>();
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OG_MFMA_BF(am[i], bm, acc[i]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OG_MFMA_BF(ah[i], bm, acc[i]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OG_MFMA_BF(ah[i], bl, acc[i]);
+            return;
+        }
         if (BF) {
             bf16x8 bq;
 #pragma unroll
@@ -1611,14 +1866,36 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, con
     if (ALDS) {
         load_a();
         store_a(0);
-        if (nk > 1) load_a();
+        if (SP || nk > 1) load_a();
     } else {
         load_adir(ad0);
     }
     load_b(rb0);
+    if (SP && ALDS) load_b(rb1);
     if (ALDS) __syncthreads();
     int cur = 0;
     int kt = 0;                                       // two steps per trip, see conv_igemm3_kernel
+    if (SP && ALDS) {               // three fragment sets / three LDS tiles, gather two steps ahead (conv_igemm3_kernel)
+        float rb2[8];
+        int ks = 0;
+        if (ks + 2 < nk) {
+            do {
+                mma(rb0, ad0, 0, [&]() { store_a(1); load_a(); load_b(rb2); });
+                __syncthreads();
+                mma(rb1, ad0, 1, [&]() { store_a(2); load_a(); load_b(rb0); });
+                __syncthreads();
+                mma(rb2, ad0, 2, [&]() { store_a(0); load_a(); load_b(rb1); });
+                __syncthreads();
+                ks += 3;
+            } while (ks + 2 < nk);
+        }
+        if (ks < nk) {
+            mma(rb0, ad0, 0, [&]() { store_a(1); });
+            __syncthreads();
+        }
+        if (ks + 1 < nk) mma(rb1, ad0, 1, [] {});
+        kt = nk;
+    }
     for (; kt + 1 < nk; kt += 2) {
         mma(rb0, ad0, cur, [&]() {
             if (ALDS) store_a(cur ^ 1); else load_adir(ad1);
@@ -1929,20 +2206,21 @@ static int launch_igemm2(const IgemmArgs& a, int TM, dim3 grid, hipStream_t s) {
     if (og_trace())
         fprintf(stderr, "OGTRACE igemm TM=%d M=%d rows=%d C=%d T=%d Npix=%d grid=%u,%u,%u H=%d W=%d stride=%d\n", TM, a.M,
                 a.m_end - a.m_begin, a.C, a.T, a.N * a.PH * a.PW, grid.x, grid.y, grid.z, a.H, a.W, a.stride);
-    if (a.math == 1) {
-        switch (TM) {
-            case 1: if (a.M <= 32) hipLaunchKernelGGL((conv_igemm3_kernel<1, true, true>), grid, dim3(256), 0, s, a);
-                    else hipLaunchKernelGGL((conv_igemm3_kernel<1, false, true>), grid, dim3(256), 0, s, a);
-                    break;
-            case 2: hipLaunchKernelGGL((conv_igemm3_kernel<2, false, true>), grid, dim3(256), 0, s, a); break;
-            case 3: hipLaunchKernelGGL((conv_igemm3_kernel<3, false, true>), grid, dim3(256), 0, s, a); break;
-            case 4: hipLaunchKernelGGL((conv_igemm3_kernel<4, false, true>), grid, dim3(256), 0, s, a); break;
-            case 5: hipLaunchKernelGGL((conv_igemm3_kernel<5, false, true>), grid, dim3(256), 0, s, a); break;
-            case 6: hipLaunchKernelGGL((conv_igemm3_kernel<6, false, true>), grid, dim3(256), 0, s, a); break;
-            default: hipLaunchKernelGGL((conv_igemm3_kernel<7, false, true>), grid, dim3(256), 0, s, a); break;
+#define OG_IG3(MATHv)                                                                                             \
+        switch (TM) {                                                                                                 \
+            case 1: if (a.M <= 32) hipLaunchKernelGGL((conv_igemm3_kernel<1, true, MATHv>), grid, dim3(256), 0, s, a); \
+                    else hipLaunchKernelGGL((conv_igemm3_kernel<1, false, MATHv>), grid, dim3(256), 0, s, a);         \
+                    break;                                                                                            \
+            case 2: hipLaunchKernelGGL((conv_igemm3_kernel<2, false, MATHv>), grid, dim3(256), 0, s, a); break;       \
+            case 3: hipLaunchKernelGGL((conv_igemm3_kernel<3, false, MATHv>), grid, dim3(256), 0, s, a); break;       \
+            case 4: hipLaunchKernelGGL((conv_igemm3_kernel<4, false, MATHv>), grid, dim3(256), 0, s, a); break;       \
+            case 5: hipLaunchKernelGGL((conv_igemm3_kernel<5, false, MATHv>), grid, dim3(256), 0, s, a); break;       \
+            case 6: hipLaunchKernelGGL((conv_igemm3_kernel<6, false, MATHv>), grid, dim3(256), 0, s, a); break;       \
+            default: hipLaunchKernelGGL((conv_igemm3_kernel<7, false, MATHv>), grid, dim3(256), 0, s, a); break;      \
         }
-        return og_launch_status();
-    }
+    if (a.math == 1) { OG_IG3(1) return og_launch_status(); }
+    if (a.math == 2) { OG_IG3(2) return og_launch_status(); }
+#undef OG_IG3
     switch (TM) {
         // TM = 1: the LDS-free form reads the filter rows directly, which only pays while the bank is tiny
         case 1: if (a.M <= 32) hipLaunchKernelGGL((conv_igemm3_kernel<1, true>), grid, dim3(256), 0, s, a);
@@ -2033,6 +2311,12 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed) {
     return OG_OK;
 }
 
+// Row pitch of a packed bank in elements: fp32 Kpad floats; bf16 Kpad rounded up to 32 (one iteration = 32 k);
+// bf16x3 three bf16 per k (the h / m / l pieces of a 16-deep step back to back: 96 bytes).
+static inline int og_krow(int Kpad, int math) {
+    return math == 1 ? (Kpad + 31) / 32 * 32 : (math == 2 ? 3 * Kpad : Kpad);
+}
+
 // Which packed-bank layout (PackArgs::m_major) a call with these arguments uses; MT_out = accumulator
 // count of the thin kernel when the answer is 2.  The single source of truth for
 // objgan_conv_igemm and objgan_conv_bank_layout.
@@ -2047,7 +2331,7 @@ static int og_bank_layout(int N, int C, int H, int W, int M, int Tg, int PH, int
     const bool thin = !og_nothin() && M <= 32 && (Tg == 9 || Tg == 4) && (long)N * PH * PW >= 65536
                       && (MT <= 4 || (act != OG_ACT_TANH && act != OG_ACT_SIGMOID));
     if (thin) return 2;
-    return math == 1 ? 3 : 1;
+    return math == 1 ? 3 : (math == 2 ? 4 : 1);
 }
 
 // The PackArgs of objgan_conv_igemm for these arguments (single source of truth for the call itself and for
@@ -2072,11 +2356,11 @@ static void og_fill_pack_phase(PackArgs& p, const float* w, float* wt, int Cout,
     const int M = Cin, C = Cout;
     const int Cp = (C + 15) / 16 * 16;
     const int Kpad = Tg * Cp;
-    const int Krow = math == 1 ? (Kpad + 31) / 32 * 32 : Kpad;
-    const long bank = math == 1 ? (long)M * Krow / 2 : (long)M * Krow;
+    const int Krow = og_krow(Kpad, math);
+    const long bank = math ? (long)M * Krow / 2 : (long)M * Krow;
     p.w = w; p.wt = wt + phase * bank; p.Cout = Cout; p.Cin = Cin; p.Torig = Torig; p.Tg = Tg;
     p.M = M; p.Mpad = (M + 127) / 128 * 128; p.Ck = C; p.Cp = Cp;
-    p.transpose = 1; p.m_major = math == 1 ? 3 : 1;
+    p.transpose = 1; p.m_major = math == 1 ? 3 : (math == 2 ? 4 : 1);
     for (int t = 0; t < OG_MAX_TAPS; ++t) p.src_tap[t] = (signed char)(t < Tg ? src_tap_phase[t] : -1);
 }
 
@@ -2131,7 +2415,7 @@ int objgan_conv_bank_layout(int N, int C, int H, int W, int M, int Tg, int PH, i
 long objgan_conv_packed_floats(int M, int C, int T) {
     const long Mpad = ((long)M + 127) / 128 * 128;
     const long Cp = ((long)C + 15) / 16 * 16;
-    return Mpad * Cp * T;
+    return (Mpad * Cp * T * 3 + 1) / 2;      // the pre-split bank of the bf16x3 mode takes 6 bytes per element
 }
 
 // General entry: see the formula at the top of this file.
@@ -2150,7 +2434,7 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
     if (Tg < 1 || Tg > OG_MAX_TAPS) return OG_BAD_ARGS;
     if (ring && !(osh == 1 && osw == 1 && ooh == 0 && oow == 0 && PH == OHf + 2 && PW == OWf + 2 && !bias && !act))
         return OG_BAD_ARGS;
-    if (math != 0 && math != 1) return OG_BAD_ARGS;
+    if (math < 0 || math > 2) return OG_BAD_ARGS;
     if (Torig < 1 || Torig > 127) return OG_BAD_ARGS;
     const int M = transpose ? Cin : Cout;
     const int Ck = transpose ? Cout : Cin;
@@ -2160,7 +2444,8 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
     PackArgs p;
     int MT = 32;
     og_fill_pack(p, w, wt, N, C, H, W, Cout, Cin, Torig, transpose, Tg, src_tap, PH, PW, act, math, &MT);
-    const bool v2 = p.m_major != 0, thin = p.m_major == 2, bf = p.m_major == 3;
+    const bool v2 = p.m_major != 0, thin = p.m_major == 2;
+    const int kmath = p.m_major == 3 ? 1 : (p.m_major == 4 ? 2 : 0);       // arithmetic of the kernel that runs
     if (!wt_packed) {       // wt_packed: the caller kept wt from an earlier call with the same
         const long ptotal = (long)Tg * p.Cp * p.Mpad;   // filter bank, taps, math and geometry class
         hipLaunchKernelGGL(pack_weights_kernel, dim3(og_stream_grid(ptotal, 256)), dim3(256), 0, s, p);
@@ -2173,8 +2458,8 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
     a.N = N; a.C = C; a.H = H; a.W = W;
     a.LH = upsample ? 2 * H : H; a.LW = upsample ? 2 * W : W;
     a.M = M; a.Mpad = p.Mpad; a.K = C * Tg; a.Kpad = Tg * p.Cp; a.T = Tg; a.Cp = p.Cp;
-    a.math = bf ? 1 : 0;
-    a.Krow = bf ? (a.Kpad + 31) / 32 * 32 : a.Kpad;
+    a.math = kmath;
+    a.Krow = og_krow(a.Kpad, kmath);
     a.m_begin = 0; a.m_end = M;
     a.PH = PH; a.PW = PW; a.OHf = OHf; a.OWf = OWf;
     a.osh = osh; a.osw = osw; a.ooh = ooh; a.oow = oow;
@@ -2187,7 +2472,7 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
         a.tap[t] = (int)(((unsigned)w_ << 16) | ((unsigned)h & 0xffffu));
     }
     if (!(osh == 1 && osw == 1 && PH == OHf && PW == OWf) && (bias || act)) return OG_BAD_ARGS;
-    if (ring && p.m_major != 1) return OG_BAD_ARGS;     // ring mode: fp32 MFMA kernel only (ask objgan_conv_bank_layout)
+    if (ring && p.m_major != 1 && p.m_major != 4) return OG_BAD_ARGS;     // ring mode: conv_igemm3_kernel only (ask objgan_conv_bank_layout)
     if (thin) return run_thin(a, MT, s);
     return v2 ? run_igemm2(a, s, y_prezeroed) : run_igemm(a, s, y_prezeroed);
 }
@@ -2196,14 +2481,14 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
 // (k = 4, pad 1, even sizes: 2x2 taps each): ONE launch, blockIdx.z = phase.  x = dY [N, Cout, OH, OW],
 // y = dX [N, Cin, 2*PH, 2*PW] (every element is written by exactly one phase: no pre-zeroing).
 // dh/dw/src_tap: 4 phases x Tg entries, phase p = (row parity << 1) | column parity.
-// wt: 4 * Cin * Tg * ceil16(Cout) floats (<= 4 x objgan_conv_packed_floats(Cin, Cout, Tg)).
+// wt: 4 * ceil(1.5 * Cin * Tg * ceil16(Cout)) floats (<= 4 x objgan_conv_packed_floats(Cin, Cout, Tg)).
 int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float* wt,
                                 int N, int Cout, int OH, int OW, int Cin, int Torig,
                                 int Tg, const int* dh, const int* dw, const int* src_tap,
                                 int PH, int PW, int wt_packed, int math, void* stream) {
     OG_ENTRY();
     if (Tg < 1 || Tg > 8) return OG_BAD_ARGS;
-    if (math != 0 && math != 1) return OG_BAD_ARGS;
+    if (math < 0 || math > 2) return OG_BAD_ARGS;
     if (Torig < 1 || Torig > 127) return OG_BAD_ARGS;
     if (N <= 0 || PH <= 0 || PW <= 0 || Cin <= 0) return OG_OK;
     const int M = Cin, C = Cout;
@@ -2211,9 +2496,9 @@ int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float*
     if ((double)N * C * OH * OW * 4.0 >= 4.0e9 || (double)M * Tg * Cp * 4.0 >= 4.0e9) return OG_BAD_ARGS;
     hipStream_t s = (hipStream_t)stream;
     const int Kpad = Tg * Cp;
-    const int Krow = math == 1 ? (Kpad + 31) / 32 * 32 : Kpad;
-    // phase banks are stored back to back: `bank` floats apart (a bf16 bank takes half of its slot)
-    const long bank = math == 1 ? (long)M * Krow / 2 : (long)M * Krow;
+    const int Krow = og_krow(Kpad, math);
+    // phase banks are stored back to back: `bank` floats apart (Krow counts bf16 elements in the bf16 modes)
+    const long bank = math ? (long)M * Krow / 2 : (long)M * Krow;
     if (!wt_packed) {
         for (int ph = 0; ph < 4; ++ph) {
             PackArgs p;
@@ -2260,7 +2545,7 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
                       int math, void* stream) {
     OG_ENTRY();
     if (ksize != 1 && ksize != 3 && ksize != 4) return OG_BAD_ARGS;
-    if (math != 0 && math != 1) return OG_BAD_ARGS;
+    if (math < 0 || math > 2) return OG_BAD_ARGS;
     if (N <= 0 || Cout <= 0 || Cin <= 0) return OG_OK;
     hipStream_t s = (hipStream_t)stream;
     WgradArgs a;
@@ -2278,12 +2563,12 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
                     && (double)N * Cin * H * W * 4.0 < 4.0e9 && (double)N * Cout * OHW * 4.0 < 4.0e9;
     a.math = math;
     if (v2) {
-        const bool bf = math == 1;
+        const bool bf = math == 1, sp = math == 2;
         int groups = og_cdiv(Cout, 32);
         const int tiles_n = og_cdiv(a.ncol, 128);
         // 1..4 output channels beyond a multiple of 32: on the VALU of block row 0 (see WgradArgs)
         const int tail_rows = Cout & 31;
-        bool xrows = !og_no_xrows() && !bf && tail_rows >= 1 && tail_rows <= 4 && Cout >= 64;
+        bool xrows = !og_no_xrows() && math == 0 && tail_rows >= 1 && tail_rows <= 4 && Cout >= 64;
         int TM, full_rows, rest;
         if (xrows) {
             og_row_plan(groups - 1, tiles_n, 1, &TM, &full_rows, &rest);
@@ -2334,7 +2619,7 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
                         ksize, N, OH, OW, stride, grid.x, grid.y, math);
             const bool wide_s1 = stride == 1 && !upsample && OW >= 64;
             const bool b128 = wide_s1 && !og_wgrad_nob128() && !bf;
-            const bool use3 = bf ? tm <= 2 : (tm <= og_wgrad3_maxtm() || b128);
+            const bool use3 = bf ? tm <= 2 : (tm <= og_wgrad3_maxtm() || b128);   // (b128 is false in bf16 mode)
             ProfRec* pr = prof_begin(use3 ? OG_CAT_WGRAD3(tm) : OG_CAT_WGRAD2(tm),
                                      2.0 * (a.m_end - a.m_begin + a.xr_count) * (double)a.ncol * (double)Npix, s);
             prof_meta(pr, 1, tm, a.m_end - a.m_begin + a.xr_count, Cin, ksize * ksize, N, OH, OW,
@@ -2346,12 +2631,15 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
             // maps without upsampling (r02 A/B: res1_128 100 -> 107 TF, shp_512 33 -> 37), the LDS-staged
             // kernel (wgrad2) elsewhere: narrow maps spend half of their spans on the border path, the
             // up-sampling gather keeps its per-element address math.
-#define OG_WG2X(TMv) if (use3 && b128) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, false, true, 4>), grid, dim3(256), 0, s, a, ksize); \
-                     else if (use3) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, false, false, 4>), grid, dim3(256), 0, s, a, ksize); \
-                     else hipLaunchKernelGGL((conv_wgrad2_kernel<TMv, false, 4>), grid, dim3(256), 0, s, a, ksize);
-#define OG_WG2(TMv) if (bf && TMv <= 2) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, true>), grid, dim3(256), 0, s, a, ksize); \
-                    else if (bf) hipLaunchKernelGGL((conv_wgrad2_kernel<TMv, true>), grid, dim3(256), 0, s, a, ksize); \
-                    else if (use3 && b128) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, false, true>), grid, dim3(256), 0, s, a, ksize); \
+#define OG_WG2X(TMv) if (use3 && b128) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, 0, true, 4>), grid, dim3(256), 0, s, a, ksize); \
+                     else if (use3) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, 0, false, 4>), grid, dim3(256), 0, s, a, ksize); \
+                     else hipLaunchKernelGGL((conv_wgrad2_kernel<TMv, 0, 4>), grid, dim3(256), 0, s, a, ksize);
+#define OG_WG2(TMv) if (bf && TMv <= 2) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, 1>), grid, dim3(256), 0, s, a, ksize); \
+                    else if (bf) hipLaunchKernelGGL((conv_wgrad2_kernel<TMv, 1>), grid, dim3(256), 0, s, a, ksize); \
+                    else if (sp && use3 && b128) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, 2, true>), grid, dim3(256), 0, s, a, ksize); \
+                    else if (sp && use3) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, 2>), grid, dim3(256), 0, s, a, ksize); \
+                    else if (sp) hipLaunchKernelGGL((conv_wgrad2_kernel<TMv, 2>), grid, dim3(256), 0, s, a, ksize); \
+                    else if (use3 && b128) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, 0, true>), grid, dim3(256), 0, s, a, ksize); \
                     else if (use3) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv>), grid, dim3(256), 0, s, a, ksize); \
                     else hipLaunchKernelGGL((conv_wgrad2_kernel<TMv>), grid, dim3(256), 0, s, a, ksize);
             if (a.xr_count > 0) {

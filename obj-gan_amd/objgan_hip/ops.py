@@ -49,21 +49,28 @@ def _iarr(vals):
 # ----------------------------------------------------------------------------------------------
 _ACT = {None: 0, "none": 0, "lrelu": 1, "tanh": 2, "sigmoid": 3, "relu": 4}
 
-# Arithmetic of the MFMA convolution kernels: "fp32" (default: exact fp32 fmaf chains, the parity
-# path) or "bf16" (mixed precision, BASELINE config 5: operands rounded to bf16 at the matrix-core
-# inputs, fp32 accumulation, fp32 tensors / master weights / norm statistics).
+# Arithmetic of the MFMA convolution kernels:
+#   "fp32"    fp32 operands on v_mfma_f32_32x32x2_f32 (the matrix pipe's native fp32 rate: 157 TFLOP/s)
+#   "bf16x3"  fp32 operands, each split EXACTLY into three bf16 pieces (24 = 8 + 8 + 8 significand bits), the six
+#             largest of the nine partial products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32 results
+#             (the dropped products are below 2^-24 of a product, 30x below the accumulation rounding both modes
+#             share) at 2.67x the native fp32 matrix rate -- csrc/conv_igemm.hip `og_split8`; the same scheme as
+#             oneMKL's BF16x3 / cuBLAS's BF16x9 fp32 emulation
+#   "bf16"    mixed precision (BASELINE config 5): operands ROUNDED to bf16 at the matrix-core inputs, fp32
+#             accumulation, fp32 tensors / master weights / norm statistics
 import os as _os
-_MATH = {"mode": 1 if _os.environ.get("OBJGAN_CONV_MATH", "fp32") == "bf16" else 0}
+_MATH_IDS = {"fp32": 0, "bf16": 1, "bf16x3": 2}
+_MATH = {"mode": _MATH_IDS.get(_os.environ.get("OBJGAN_CONV_MATH", "fp32"), 0)}
 
 
 def set_conv_math(mode):
-    if mode not in ("fp32", "bf16"):
-        raise _lib.ObjganHipError("conv math must be 'fp32' or 'bf16'")
-    _MATH["mode"] = 1 if mode == "bf16" else 0
+    if mode not in _MATH_IDS:
+        raise _lib.ObjganHipError("conv math must be one of %s" % (sorted(_MATH_IDS),))
+    _MATH["mode"] = _MATH_IDS[mode]
 
 
 def get_conv_math():
-    return "bf16" if _MATH["mode"] else "fp32"
+    return [k for k, v in _MATH_IDS.items() if v == _MATH["mode"]][0]
 
 
 
@@ -196,7 +203,7 @@ def _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad_h, pad_w, LH, LW, cachea
     if Tg > 8:
         return None
     dx = torch.empty((N, Cin, LH, LW), dtype=_F32, device=g.device)
-    n = 4 * Cin * Tg * ((Cout + 15) // 16 * 16)
+    n = 4 * ((Cin * Tg * ((Cout + 15) // 16 * 16) * 3 + 1) // 2)      # bf16x3 banks: 6 bytes per element
     key = _pack_key(w, 2, st, False) if cacheable else None
     if key is not None:
         ent, fresh = _bank_lookup(key, w, n, g.device)
@@ -246,8 +253,8 @@ def _conv_dgrad(g, w, N, Cin, H, W, stride, pad, refl, upsample, cacheable=True)
         dh = [pe - kh for kh in range(k) for kw in range(k)]
         dw = [pe - kw for kh in range(k) for kw in range(k)]
         st = list(range(k * k))
-        ring_ok = (refl and pad == 1 and LH >= 3 and LW >= 3 and _MATH["mode"] == 0 and
-                   _lib.load().objgan_conv_bank_layout(N, Cout, OH, OW, Cin, k * k, TH, TW, 0, 0) == 1)
+        ring_ok = (refl and pad == 1 and LH >= 3 and LW >= 3 and _MATH["mode"] != 1 and
+                   _lib.load().objgan_conv_bank_layout(N, Cout, OH, OW, Cin, k * k, TH, TW, 0, _MATH["mode"]) in (1, 4))
         if ring_ok:
             # gradient of the reflect-padded conv without the padded intermediate: interior pixels go straight
             # into dX, the one-pixel border into a small ring buffer that is mirrored back afterwards
@@ -364,7 +371,7 @@ class _Conv2dFn(torch.autograd.Function):
 # data-gradient kernel -- and the gradients are the forward / weight gradient of that stride-2
 # convolution: three kernels the discriminators already use, nothing new on the device.  The only
 # arithmetic difference to the lifted form is the pre-summation of filter taps (re-association at
-# the 1e-7 level).  fp32 math only: the bf16 mode is defined on the rounded ORIGINAL filters.
+# the 1e-7 level).  fp32 / bf16x3 math only: the bf16 mode is defined on the rounded ORIGINAL filters.
 _UP_A = ((0., 0., 1.), (0., 1., 1.), (1., 1., 0.), (1., 0., 0.))
 _UP4 = {}           # (weight address, shape) -> [w, _version, epoch, W4]
 
@@ -398,7 +405,7 @@ def _up_bank(w):
 def _up_phased_ok(x, w, bias, stride, pad, pad_mode, upsample, act):
     return (upsample and stride == 1 and pad == 1 and pad_mode != "reflect" and bias is None
             and act in (None, "none") and w.shape[2] == 3 and w.shape[3] == 3 and w.shape[0] > 32
-            and x.shape[1] > 32 and x.shape[2] >= 2 and x.shape[3] >= 2 and _MATH["mode"] == 0
+            and x.shape[1] > 32 and x.shape[2] >= 2 and x.shape[3] >= 2 and _MATH["mode"] != 1
             and float(x.shape[0]) * max(x.shape[1], 4 * w.shape[0]) * x.shape[2] * x.shape[3] * 4.0 < 4.0e9)
 
 

@@ -59,8 +59,19 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(params=["fp32", "bf16x3"])
+def fp32_math(request):
+    """The two arithmetic modes that deliver fp32 results: fp32 operands on the fp32 MFMA, and fp32 operands split
+    exactly three ways on the bf16 MFMA (six partial products, fp32 accumulation).  Same tolerance for both."""
+    ops = _ops()
+    prev = ops.get_conv_math()
+    ops.set_conv_math(request.param)
+    yield request.param
+    ops.set_conv_math(prev)
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv2d_forward_backward(dev, case):
+def test_conv2d_forward_backward(dev, case, fp32_math):
     ops, tr = _ops(), _tref()
     N, Cin, H, W, Cout, k, s, p, pm, up, has_b, act = case
     g = torch.Generator().manual_seed(1234)
@@ -683,6 +694,7 @@ def test_conv2d_bf16_math_equals_fp32_conv_of_bf16_rounded_operands(dev, case):
     yr = tr.conv2d(xr, wr, None, s, p, pm, up, None)
     gy = torch.randn(yr.shape, generator=g)
     yr.backward(rnd(gy))
+    prev = ops.get_conv_math()
     ops.set_conv_math("bf16")
     try:
         xd, wd = x.to(dev).requires_grad_(), w.to(dev).requires_grad_()
@@ -690,7 +702,7 @@ def test_conv2d_bf16_math_equals_fp32_conv_of_bf16_rounded_operands(dev, case):
         yd.backward(gy.to(dev))
         torch.cuda.synchronize()
     finally:
-        ops.set_conv_math("fp32")
+        ops.set_conv_math(prev)
     assert rel_l2(yd, yr) < TOL, ("fwd", rel_l2(yd, yr))
     assert rel_l2(xd.grad, xr.grad) < TOL, ("dgrad", rel_l2(xd.grad, xr.grad))
     OW = yr.shape[3]
@@ -703,6 +715,56 @@ def test_conv2d_bf16_math_equals_fp32_conv_of_bf16_rounded_operands(dev, case):
     # and it is a bf16-level approximation of the fp32 result
     y32 = tr.conv2d(x, w, None, s, p, pm, up, None)
     assert 1e-4 < rel_l2(yd, y32) < 2e-2
+
+
+X3_CASES = [
+    # N, Cin, H, W, Cout, k, stride, pad, pad_mode, upsample            long reductions: where product errors would show
+    (2, 1024, 16, 16, 768, 3, 1, 1, "zeros", False),      # K = 9216 (joint conv of the discriminator heads)
+    (2, 194, 32, 32, 388, 3, 1, 1, "reflect", False),     # residual block, two block rows, weight gradient over 2048 px
+    (4, 96, 64, 64, 192, 4, 2, 1, "zeros", False),        # D encoder: phased dgrad, weight gradient over 4096 px
+    (2, 194, 16, 16, 96, 3, 1, 1, "zeros", True),         # upBlock on the 4x4 stride-2 transposed form
+    (4, 384, 8, 8, 384, 1, 1, 0, "zeros", False),         # 1x1, small map (32-row tiles)
+]
+
+
+@pytest.mark.parametrize("case", X3_CASES)
+def test_bf16x3_math_is_as_accurate_as_the_fp32_mfma(dev, case):
+    """`bf16x3` computes fp32 convolutions on the bf16 matrix pipe: x = h + m + l exactly (three bf16 pieces), six of
+    the nine partial products, fp32 accumulation.  What it drops is below 2^-24 of a product -- far below the
+    rounding of the fp32 accumulation both modes share -- so against an fp64 evaluation its error must equal the
+    native fp32 MFMA's (bound: 1.25x + 2e-8), forward, data gradient and weight gradient.  Inputs carry full 24-bit
+    significands; activations are ReLU-like (half zeros) and weights small, like the networks'."""
+    from conftest import note
+    ops = _ops()
+    N, Cin, H, W, Cout, k, s, p, pm, up = case
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(N, Cin, H, W, generator=g).clamp_min(-0.25)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    xt, wt = x.double().requires_grad_(), w.double().requires_grad_()
+    xin = torch.nn.functional.interpolate(xt, scale_factor=2, mode="nearest") if up else xt
+    if pm == "reflect":
+        yt = torch.nn.functional.conv2d(torch.nn.functional.pad(xin, (p, p, p, p), mode="reflect"), wt, None, s, 0)
+    else:
+        yt = torch.nn.functional.conv2d(xin, wt, None, s, p)
+    gy = torch.randn(yt.shape, generator=g)
+    yt.backward(gy.double())
+    errs = {}
+    prev = ops.get_conv_math()
+    for math in ("fp32", "bf16x3"):
+        ops.set_conv_math(math)
+        try:
+            xd, wd = x.to(dev).requires_grad_(), w.to(dev).requires_grad_()
+            yd = ops.conv2d(xd, wd, None, s, p, pm, up, None)
+            yd.backward(gy.to(dev))
+            torch.cuda.synchronize()
+        finally:
+            ops.set_conv_math(prev)
+        errs[math] = (rel_l2(yd, yt), rel_l2(xd.grad, xt.grad), rel_l2(wd.grad, wt.grad))
+    note("bf16x3 vs fp32 MFMA, error against fp64 (fwd, dgrad, wgrad) %s" % (case,),
+         "fp32 %.3e %.3e %.3e | bf16x3 %.3e %.3e %.3e" % (errs["fp32"] + errs["bf16x3"]))
+    for e32, ex3, what in zip(errs["fp32"], errs["bf16x3"], ("fwd", "dgrad", "wgrad")):
+        assert e32 < 2e-6, (what, e32)
+        assert ex3 <= 1.25 * e32 + 2e-8, (what, "fp32", e32, "bf16x3", ex3)
 
 
 def test_conv_never_consumes_memory_past_the_input_tensor(dev):
@@ -719,14 +781,15 @@ def test_conv_never_consumes_memory_past_the_input_tensor(dev):
         xc = torch.randn(N, C, H, W, generator=g)
         x.copy_(xc)
         w = torch.randn(Cout, C, k, k, generator=g) / (C * k * k) ** 0.5
-        for math in ("fp32", "bf16"):
+        prev = ops.get_conv_math()
+        for math in ("fp32", "bf16", "bf16x3"):
             ops.set_conv_math(math)
             try:
                 y = ops.conv2d(x, w.to(dev), None, 1, k // 2)
             finally:
-                ops.set_conv_math("fp32")
+                ops.set_conv_math(prev)
             assert torch.isfinite(y).all(), (math, N, C)
-            if math == "fp32":
+            if math != "bf16":
                 assert rel_l2(y, tr.conv2d(xc, w, None, 1, k // 2)) < TOL
         # weight gradient reads x too (dy behind a NaN guard as well)
         OH = H

@@ -3,7 +3,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 tools/conv_bench.cpp -Iinclude -L obj-gan_amd/objgan_hip -lobjgan_hip \
 //         -Wl,-rpath,'$ORIGIN/../obj-gan_amd/objgan_hip' -o tools/conv_bench
-//   tools/conv_bench [filter] [iters] [math: 0 fp32 | 1 bf16 inputs]
+//   tools/conv_bench [filter] [iters] [math: 0 fp32 | 1 bf16 inputs | 2 bf16x3]
 //
 // For every shape: forward, data gradient and weight gradient are timed with hipEvents and
 // reported as algorithmic TFLOP/s (2*N*OH*OW*Cout*Cin*k*k); a sample of output elements is
@@ -44,8 +44,9 @@ static const Shape SHAPES[] = {
 };
 
 static unsigned g_seed = 12345u;
-static int g_math = 0;      // 0 fp32, 1 bf16 inputs (argv[3])
-static float frand() { g_seed = g_seed * 1664525u + 1013904223u; return ((g_seed >> 8) & 0xffff) / 32768.0f - 1.0f; }
+static int g_math = 0;      // 0 fp32, 1 bf16 inputs, 2 bf16x3 (fp32 split three ways on the bf16 MFMA) (argv[3])
+// full 24-bit significands: the l pieces of the bf16x3 split must not be zero
+static float frand() { g_seed = g_seed * 1664525u + 1013904223u; return ((g_seed >> 8) & 0xffffff) / 8388608.0f - 1.0f; }
 
 static int reflect(int i, int L) { if (i < 0) i = -i; if (i >= L) i = 2 * (L - 1) - i; return i; }
 
@@ -142,8 +143,8 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(hy.data(), dy, ny * 4, hipMemcpyDeviceToHost));
         std::vector<float> hgw(nw);
         CK(hipMemcpy(hgw.data(), dgw, nw * 4, hipMemcpyDeviceToHost));
-        double maxerr_f = 0, maxref_f = 0;
-        for (int smp = 0; smp < 64; ++smp) {
+        double maxerr_f = 0, maxref_f = 0, se_f = 0, sr_f = 0;
+        for (int smp = 0; smp < 256; ++smp) {
             g_seed = g_seed * 1664525u + 1013904223u; const int n = (g_seed >> 8) % sh.N;
             g_seed = g_seed * 1664525u + 1013904223u; const int co = (g_seed >> 8) % sh.Cout;
             g_seed = g_seed * 1664525u + 1013904223u; int oh = (g_seed >> 8) % OH;
@@ -159,9 +160,10 @@ int main(int argc, char** argv) {
             }
             const double got = hy[(((size_t)n * sh.Cout + co) * OH + oh) * OW + ow];
             maxerr_f = fmax(maxerr_f, fabs(got - acc)); maxref_f = fmax(maxref_f, fabs(acc));
+            se_f += (got - acc) * (got - acc); sr_f += acc * acc;
         }
-        double maxerr_w = 0, maxref_w = 0;
-        for (int smp = 0; smp < 6; ++smp) {
+        double maxerr_w = 0, maxref_w = 0, se_w = 0, sr_w = 0;
+        for (int smp = 0; smp < 12; ++smp) {
             g_seed = g_seed * 1664525u + 1013904223u; const int co = (g_seed >> 8) % sh.Cout;
             g_seed = g_seed * 1664525u + 1013904223u; const int ci = (g_seed >> 8) % sh.Cin;
             g_seed = g_seed * 1664525u + 1013904223u; const int t = (g_seed >> 8) % T;
@@ -176,12 +178,13 @@ int main(int argc, char** argv) {
             }
             const double got = hgw[((size_t)co * sh.Cin + ci) * T + t];
             maxerr_w = fmax(maxerr_w, fabs(got - acc)); maxref_w = fmax(maxref_w, fabs(acc));
+            se_w += (got - acc) * (got - acc); sr_w += acc * acc;
         }
-        double maxerr_d = 0, maxref_d = 0;
+        double maxerr_d = 0, maxref_d = 0, se_d = 0, sr_d = 0;
         {
             std::vector<float> hgx(ngx);
             CK(hipMemcpy(hgx.data(), dgx, ngx * 4, hipMemcpyDeviceToHost));
-            for (int smp = 0; smp < 24; ++smp) {
+            for (int smp = 0; smp < 128; ++smp) {
                 g_seed = g_seed * 1664525u + 1013904223u; const int n = (g_seed >> 8) % sh.N;
                 g_seed = g_seed * 1664525u + 1013904223u; const int ci = (g_seed >> 8) % sh.Cin;
                 g_seed = g_seed * 1664525u + 1013904223u; int ih = (g_seed >> 8) % TH;
@@ -199,11 +202,14 @@ int main(int argc, char** argv) {
                 }
                 const double got = hgx[(((size_t)n * sh.Cin + ci) * TH + ih) * TW + iw];
                 maxerr_d = fmax(maxerr_d, fabs(got - acc)); maxref_d = fmax(maxref_d, fabs(acc));
+                se_d += (got - acc) * (got - acc); sr_d += acc * acc;
             }
         }
-        printf("%-32s fwd %7.3f ms %6.1f TF | dgrad %7.3f ms %6.1f TF | wgrad %7.3f ms %6.1f TF | err f %.1e d %.1e w %.1e\n",
+        // err: max |got - fp64| / max |fp64| over the samples; l2: sqrt(sum (got - fp64)^2 / sum fp64^2)
+        printf("%-32s fwd %7.3f ms %6.1f TF | dgrad %7.3f ms %6.1f TF | wgrad %7.3f ms %6.1f TF | err f %.1e d %.1e w %.1e | l2 f %.2e d %.2e w %.2e\n",
                sh.name, tf, flops / tf / 1e9, td, flops / td / 1e9, tw, flops / tw / 1e9,
-               maxerr_f / (maxref_f + 1e-30), maxerr_d / (maxref_d + 1e-30), maxerr_w / (maxref_w + 1e-30));
+               maxerr_f / (maxref_f + 1e-30), maxerr_d / (maxref_d + 1e-30), maxerr_w / (maxref_w + 1e-30),
+               sqrt(se_f / (sr_f + 1e-300)), sqrt(se_d / (sr_d + 1e-300)), sqrt(se_w / (sr_w + 1e-300)));
         fflush(stdout);
         hipFree(dx); hipFree(dw); hipFree(dy); hipFree(dg); hipFree(dgx); hipFree(dgw); hipFree(wt);
     }
