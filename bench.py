@@ -295,7 +295,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="stage3_obj",
                     help="stage3_obj: the configuration BASELINE's metric is quoted on (default); stage3 / stage1: "
                          "BASELINE configs 3 and 2 (parity-test cases; their lines are side records, not the metric)")
-    ap.add_argument("--math", choices=("fp32", "bf16x3", "bf16"), default="fp32",
+    ap.add_argument("--math", choices=("fp32", "bf16x3", "bf16"), default="bf16x3",
                     help="fp32: fp32 operands on the fp32 MFMA; bf16x3: fp32 operands split exactly three ways on the "
                          "bf16 MFMA, six partial products, fp32 accumulation (fp32 results); bf16: mixed precision of "
                          "BASELINE config 5 (bf16 matrix-core inputs, fp32 accumulation / storage / norms / optimizer)")
@@ -365,13 +365,17 @@ def main():
             "value": round(n_img / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "fp32", "bf16x3": "fp32 (operands split 3-way on the bf16 MFMA, fp32 accumulate)",
-                      "bf16": "bf16-in/fp32-acc (mixed precision, config 5)"}[args.math],
+            "dtype": "fp32" if args.math != "bf16" else "bf16-in/fp32-acc (mixed precision, config 5)",
             "data": "synthetic",
             "config": {"workload": workload_name + ("" if args.no_is_monitor else "+IS-monitor"),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": "dp%d" % world + (" (RCCL path forced)" if args.force_ddp and world == 1 else ""),
-                       "fresh_batch_every_step": True},
+                       "fresh_batch_every_step": True,
+                       "conv_math": {"fp32": "fp32 operands on the fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+                                     "bf16x3": "fp32 operands split exactly into 3 bf16 pieces each, 6 partial products "
+                                               "on v_mfma_f32_32x32x16_bf16, fp32 accumulation: fp32 results (error vs "
+                                               "fp64 <= the fp32 MFMA's, profiles/r03_parity.txt)",
+                                     "bf16": "operands rounded to bf16, fp32 accumulation"}[args.math]},
         }
         if timing:
             ms = (ctypes.c_double * 32)()

@@ -22,6 +22,21 @@ static inline int og_launch_status() {
     return e == hipSuccess ? OG_OK : -(int)e;
 }
 
+// Development switches.  The shipped library reads no environment: OG_KNOB(fn, "NAME", default) defines fn() as
+// the constant.  A development build (OBJGAN_DEV=1 python -m objgan_hip.build, i.e. -DOG_DEV) reads the integer
+// from the environment once instead, for A/B runs of tools/conv_bench and bench.py on the GPU box.
+#ifdef OG_DEV
+#include <stdlib.h>
+static inline int og_env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && e[0]) ? atoi(e) : dflt;
+}
+#define OG_KNOB(fn, name, dflt) \
+    static int fn() { static int v = -0x7fffffff; if (v == -0x7fffffff) v = og_env_int(name, dflt); return v; }
+#else
+#define OG_KNOB(fn, name, dflt) static inline int fn() { return dflt; }
+#endif
+
 static inline int og_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Grid for HBM-bound grid-stride kernels: enough workgroups to fill 256 CUs

@@ -75,7 +75,17 @@ struct IgemmArgs {
                          // (top row, bottom row, left column, right column) for objgan_reflect_ring_fold to add
                          // back -- instead of writing the padded tensor and folding it in a second full pass.
     int tap[OG_MAX_TAPS];   // (dw << 16) | (dh & 0xffff): one scalar load per (uniform) tap
+#ifdef OG_DEV
+    int ablate;             // development builds: main-loop ablation of the bf16x3 kernel (timing only, wrong results):
+                            // 1 no m/l products, 2 no pixel gathers after the prologue, 4 no row-tile loads after the
+                            // prologue, 8 no barriers, 16 no LDS stores, 32 no split VALU
+#endif
 };
+#ifdef OG_DEV
+#define OG_ABL(bit) (a.ablate & (bit))
+#else
+#define OG_ABL(bit) false
+#endif
 
 __device__ __forceinline__ float og_act(float v, int act) {
     if (act == OG_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
@@ -1161,8 +1171,11 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
 // barriers at all: waves are independent and latency is hidden by occupancy.
 // (A chunk-major K order -- all taps of a 16-channel chunk back to back, hoping for L1 hits between the
 // shifted windows -- was measured in round 2 and lost on every shape: profiles/r02_ab_convbench_variants.txt.)
-template <int TM, bool ADIRECT = false, int MATH = 0>
-__global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
+template <int TM, bool ADIRECT = false, int MATH = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a) {
+    // NW: waves per workgroup = 32-pixel column groups sharing one row tile (4: 128 pixels; 8: 256 pixels -- the
+    // bf16x3 kernels run against the L2 -> L1 fill rate, and the row tile is 2/3 of a workgroup's fills)
+    constexpr int NT = 64 * NW;
     // MATH 0: fp32 MFMA; 1 (BF): bf16-rounded operands; 2 (SP): fp32 operands split three ways on the bf16 MFMA
     // (og_split8).  SP: one iteration = one 16-deep K step like fp32; the bank holds the PRE-SPLIT filter rows,
     // [M][Kpad/16][h,m,l][16] bf16 = 96 bytes per row and step, LDS row pitch 112 bytes (an odd multiple of 16:
@@ -1170,13 +1183,13 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
     // registers (~44 VALU instructions per step next to 6 * TM MFMAs).
     constexpr bool BF = MATH == 1, SP = MATH == 2;
     constexpr int BM = 32 * TM;
-    constexpr int BN = 128;
+    constexpr int BN = 32 * NW;
     constexpr int BK = 16;
     constexpr int LD = SP ? 28 : BK + 4;              // floats per LDS row
     constexpr int PIECES = SP ? 6 : 4;                // 16-byte pieces of a bank row per iteration
     constexpr int ABYTES = PIECES * 16;
     constexpr int NA4 = BM * PIECES;
-    constexpr int NA_PER = (NA4 + 255) / 256;
+    constexpr int NA_PER = (NA4 + NT - 1) / NT;
     constexpr int TILE = BM * LD;
     constexpr int NAD = SP ? 3 : 2;                   // direct row fragments per lane (TM = 1 LDS-free form)
     constexpr bool ALDS = !(ADIRECT && TM == 1);      // row operand through LDS (shared by 4 waves)
@@ -1273,11 +1286,11 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
     if (ALDS) {
 #pragma unroll
         for (int i = 0; i < NA_PER; ++i) {
-            const int idx = tid + 256 * i;
+            const int idx = tid + NT * i;
             const int row = idx / PIECES, q = idx - row * PIECES;
-            const bool on = (NA4 % 256 == 0 || idx < NA4) && (m0 + row) < a.m_end;
+            const bool on = (NA4 % NT == 0 || idx < NA4) && (m0 + row) < a.m_end;
             avoff[i] = on ? (unsigned)(m0 + row) * (unsigned)a.Krow * (unsigned)ESZ + q * 16u : OG_OOB;
-            alds[i] = (NA4 % 256 == 0 || idx < NA4) ? row * LD + q * 4 : -1;
+            alds[i] = (NA4 % NT == 0 || idx < NA4) ? row * LD + q * 4 : -1;
         }
     }
     const unsigned adir = (m0 + lcol) < a.m_end
@@ -1295,7 +1308,7 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
         float* As = lds + buf * TILE;
 #pragma unroll
         for (int i = 0; i < NA_PER; ++i)
-            if (NA4 % 256 == 0 || alds[i] >= 0) *reinterpret_cast<f32x4*>(As + alds[i]) = ra[i];
+            if (NA4 % NT == 0 || alds[i] >= 0) *reinterpret_cast<f32x4*>(As + alds[i]) = ra[i];
     };
 
     const int nk_all = BF ? a.Krow / 32 : a.Kpad / BK;
@@ -1355,12 +1368,13 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
                 mid();
                 __builtin_amdgcn_sched_barrier(0);
             }
-            og_split8_ml(rb, bh, bm, bl);
+            if (OG_ABL(32)) { bm = bh; bl = bh; } else og_split8_ml(rb, bh, bm, bl);
 #pragma unroll
             for (int i = 0; i < TM; ++i) OG_MFMA_BF(am[i], bh, acc[i]);
 #pragma unroll
             for (int i = 0; i < TM; ++i) OG_MFMA_BF(ah[i], bh, acc[i]);
             if (ALDS) og_interleave<2 * TM, (40 + 2 * TM - 1) / (2 * TM)>();
+            if (OG_ABL(1)) return;
 #pragma unroll
             for (int i = 0; i < TM; ++i) OG_MFMA_BF(am[i], bm, acc[i]);
 #pragma unroll
@@ -1480,6 +1494,20 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
         // offsets of the row loads: waterfall loops around each buffer_load).
         float rb2[NB];
         int ks = kt0;
+#ifdef OG_DEV
+        if (a.ablate & 0x3e) {          // ablation form of the main loop (development builds only)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) rb2[j] = rb0[j];
+            for (; ks + 2 < nk; ks += 3) {
+                mma(rb0, ad0, 0, [&]() { if (!OG_ABL(16)) store_a(1); if (!OG_ABL(4)) load_a(ks + 2); if (!OG_ABL(2)) load_b(rb2); });
+                if (!OG_ABL(8)) __syncthreads();
+                mma(rb1, ad0, 1, [&]() { if (!OG_ABL(16)) store_a(2); if (!OG_ABL(4)) load_a(ks + 3); if (!OG_ABL(2)) load_b(rb0); });
+                if (!OG_ABL(8)) __syncthreads();
+                mma(rb2, ad0, 2, [&]() { if (!OG_ABL(16)) store_a(0); if (!OG_ABL(4)) load_a(ks + 4); if (!OG_ABL(2)) load_b(rb1); });
+                if (!OG_ABL(8)) __syncthreads();
+            }
+        } else
+#endif
         if (ks + 2 < nk) {
             do {
                 mma(rb0, ad0, 0, [&]() { store_a(1); load_a(ks + 2); load_b(rb2); });
@@ -1567,18 +1595,19 @@ __global__ __launch_bounds__(256) void conv_igemm3_kernel(const IgemmArgs a) {
 // B128: on the stride-1 interior fast path the eight consecutive pixels of a lane are fetched as two
 // 16-byte loads (4-byte aligned) instead of eight dwords -- the lanes of a wave sit on different
 // (channel, tap) planes, so every gather instruction touches ~20 cache lines.
-template <int TM, int MATH = 0, bool B128 = false, int XR = 0>
-__global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, const int KS) {
+template <int TM, int MATH = 0, bool B128 = false, int XR = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void conv_wgrad3_kernel(const WgradArgs a, const int KS) {
+    constexpr int NT = 64 * NW;                     // NW waves = NW 32-column groups sharing one dy row tile
     // MATH as in conv_igemm3_kernel.  SP (bf16x3): the dy rows are split by their loader thread on the way into
     // LDS (row image [h 16 | m 16 | l 16] bf16, 112-byte pitch), the gathered x fragment in registers; the gather
     // runs two steps ahead (three fragment sets), see conv_igemm3_kernel.
     constexpr bool BF = MATH == 1, SP = MATH == 2;
     constexpr int BM = 32 * TM;
-    constexpr int BN = 128;
+    constexpr int BN = 32 * NW;
     constexpr int BK = 16;
     constexpr int LD = SP ? 28 : BK + 4;
     constexpr int NA4 = BM * 4;
-    constexpr int NA_PER = (NA4 + 255) / 256;
+    constexpr int NA_PER = (NA4 + NT - 1) / NT;
     constexpr int TILE = (BM + XR) * LD;
     constexpr bool ALDS = TM > 1;
     static_assert(XR == 0 || (MATH == 0 && TM > 1), "extra rows: fp32 LDS form only");
@@ -1690,11 +1719,11 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, con
     if (ALDS) {
 #pragma unroll
         for (int i = 0; i < NA_PER; ++i) {
-            const int idx = tid + 256 * i;
+            const int idx = tid + NT * i;
             const int row = idx >> 2, q = idx & 3;
-            const bool on = (NA4 % 256 == 0 || idx < NA4) && (m0 + row) < a.m_end;
+            const bool on = (NA4 % NT == 0 || idx < NA4) && (m0 + row) < a.m_end;
             avoff[i] = on ? ((unsigned)(m0 + row) * (unsigned)OHW + q * 4u) * 4u : OG_OOB;
-            alds[i] = (NA4 % 256 == 0 || idx < NA4) ? row * LD + q * (SP ? 2 : 4) : -1;
+            alds[i] = (NA4 % NT == 0 || idx < NA4) ? row * LD + q * (SP ? 2 : 4) : -1;
         }
     }
     const unsigned adir = (m0 + lcol) < a.m_end ? ((unsigned)(m0 + lcol) * (unsigned)OHW + lrow * 8u) * 4u : OG_OOB;
@@ -1727,7 +1756,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, con
             for (int i = 0; i < NA_PER; ++i) {
                 bf16x4 h, m, l;
                 og_split4(ra[i], h, m, l);
-                if (NA4 % 256 == 0 || alds[i] >= 0) {
+                if (NA4 % NT == 0 || alds[i] >= 0) {
                     *reinterpret_cast<bf16x4*>(As + alds[i]) = h;
                     *reinterpret_cast<bf16x4*>(As + alds[i] + 8) = m;
                     *reinterpret_cast<bf16x4*>(As + alds[i] + 16) = l;
@@ -1737,7 +1766,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WgradArgs a, con
         }
 #pragma unroll
         for (int i = 0; i < NA_PER; ++i)
-            if (NA4 % 256 == 0 || alds[i] >= 0) *reinterpret_cast<f32x4*>(As + alds[i]) = ra[i];
+            if (NA4 % NT == 0 || alds[i] >= 0) *reinterpret_cast<f32x4*>(As + alds[i]) = ra[i];
         if (XR > 0 && x_loader) *reinterpret_cast<f32x4*>(As + (BM + (tid >> 2)) * LD + (tid & 3) * 4) = rax;
     };
     auto load_adir = [&](f32x4 (&ad)[2]) {
@@ -2004,6 +2033,21 @@ static inline void prof_meta(ProfRec* r, int kind, int tm, int M, int C, int T, 
 }
 static inline void prof_end(ProfRec* r, hipStream_t s) { if (r) (void)hipEventRecord(r->b, s); }
 
+// ---- development switches (OG_KNOB: common.h -- constants in the shipped library) -----------------
+OG_KNOB(og_igemm_v1, "OG_IGEMM_V1", 0)             // 1: first-generation kernels everywhere
+OG_KNOB(og_igemm_tmmax_raw, "OG_IGEMM_TMMAX", 8)   // tallest forward / data-gradient tile
+OG_KNOB(og_nothin, "OG_NO_THIN", 0)                // 1: no direct VALU kernels for thin outputs
+OG_KNOB(og_trace, "OG_TRACE", 0)                   // 1: print every launch plan to stderr
+OG_KNOB(og_wgrad3_maxtm, "OG_WGRAD3_MAXTM", 2)     // register-fragment weight-gradient form up to this tile height
+OG_KNOB(og_wgrad_oldsplit, "OG_WGRAD_OLDSPLIT", 0)
+OG_KNOB(og_wgrad_nob128, "OG_WGRAD_NOB128", 0)     // 1: dword gathers on wide stride-1 maps
+OG_KNOB(og_split_target, "OG_SPLIT_TARGET", 1024)
+OG_KNOB(og_no_xrows, "OG_NO_XROWS", 0)
+OG_KNOB(og_nw8_min, "OG_NW8_MIN", 512)             // bf16x3: 8-wave workgroups from this many workgroups on (0: never)
+OG_KNOB(og_ablate, "OG_ABLATE", 0)                 // development builds: IgemmArgs::ablate
+OG_KNOB(og_x3_wgrad3_maxtm, "OG_X3_WGRAD3_MAXTM", 2)   // bf16x3: register-fragment weight gradient up to this tile height
+static int og_igemm_tmmax() { const int v = og_igemm_tmmax_raw(); return (v < 1 || v > 8) ? 8 : v; }
+
 // ---- host side ---------------------------------------------------------------------------
 static inline int igemm_tiles(const IgemmArgs& a, int cfg) {
     const int Npix = a.N * a.PH * a.PW;
@@ -2082,16 +2126,6 @@ static int run_igemm(IgemmArgs a, hipStream_t s, int y_prezeroed) {
 }
 
 // ---- v2 launch plan: block rows of TM 32-row groups (TM <= 8) ---------------------------------
-static int og_igemm_v1() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("OG_IGEMM_V1"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v;
-}
-static int og_igemm_tmmax() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("OG_IGEMM_TMMAX"); v = e ? atoi(e) : 8; if (v < 1 || v > 8) v = 8; }
-    return v;
-}
 
 // Block-row plan for M = `groups` 32-row groups over `tiles_n` column tiles: block rows of height TM
 // (<= 7: two workgroups per CU) plus one lower block row for the remainder in its own launch
@@ -2126,12 +2160,6 @@ static void og_row_plan(int groups, int tiles_n, int tall, int* TM_out, int* ful
     *TM_out = bt; *full_rows_out = groups / bt; *rest_out = groups - (groups / bt) * bt;
 }
 
-static int og_trace();
-static int og_nothin() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("OG_NO_THIN"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v;
-}
 
 static int run_thin(IgemmArgs a, int MT, hipStream_t s) {
     const long Npix = (long)a.N * a.PH * a.PW;
@@ -2175,37 +2203,23 @@ static int run_thin(IgemmArgs a, int MT, hipStream_t s) {
     return og_launch_status();
 }
 
-static int og_trace() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("OG_TRACE"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v;
-}
 
-static int og_wgrad3_maxtm() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("OG_WGRAD3_MAXTM"); v = e ? atoi(e) : 2; }
-    return v;
-}
-static int og_wgrad_oldsplit() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("OG_WGRAD_OLDSPLIT"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v;
-}
-static int og_wgrad_nob128() {      // development switch: OG_WGRAD_NOB128=1 restores the dword gathers
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("OG_WGRAD_NOB128"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v;
-}
-static int og_split_target() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("OG_SPLIT_TARGET"); v = e ? atoi(e) : 1024; }
-    return v;
-}
-
-static int launch_igemm2(const IgemmArgs& a, int TM, dim3 grid, hipStream_t s) {
+static int launch_igemm2(const IgemmArgs& a, int TM, dim3 grid, hipStream_t s, int nw = 4) {
     if (og_trace())
-        fprintf(stderr, "OGTRACE igemm TM=%d M=%d rows=%d C=%d T=%d Npix=%d grid=%u,%u,%u H=%d W=%d stride=%d\n", TM, a.M,
+        fprintf(stderr, "OGTRACE igemm TM=%d NW=%d M=%d rows=%d C=%d T=%d Npix=%d grid=%u,%u,%u H=%d W=%d stride=%d\n", TM, nw, a.M,
                 a.m_end - a.m_begin, a.C, a.T, a.N * a.PH * a.PW, grid.x, grid.y, grid.z, a.H, a.W, a.stride);
+    if (a.math == 2 && nw == 8) {          // 8-wave workgroups: 32 * TM rows x 256 pixels
+        switch (TM) {
+            case 1: hipLaunchKernelGGL((conv_igemm3_kernel<1, false, 2, 8>), grid, dim3(512), 0, s, a); break;
+            case 2: hipLaunchKernelGGL((conv_igemm3_kernel<2, false, 2, 8>), grid, dim3(512), 0, s, a); break;
+            case 3: hipLaunchKernelGGL((conv_igemm3_kernel<3, false, 2, 8>), grid, dim3(512), 0, s, a); break;
+            case 4: hipLaunchKernelGGL((conv_igemm3_kernel<4, false, 2, 8>), grid, dim3(512), 0, s, a); break;
+            case 5: hipLaunchKernelGGL((conv_igemm3_kernel<5, false, 2, 8>), grid, dim3(512), 0, s, a); break;
+            case 6: hipLaunchKernelGGL((conv_igemm3_kernel<6, false, 2, 8>), grid, dim3(512), 0, s, a); break;
+            default: hipLaunchKernelGGL((conv_igemm3_kernel<7, false, 2, 8>), grid, dim3(512), 0, s, a); break;
+        }
+        return og_launch_status();
+    }
 #define OG_IG3(MATHv)                                                                                             \
         switch (TM) {                                                                                                 \
             case 1: if (a.M <= 32) hipLaunchKernelGGL((conv_igemm3_kernel<1, true, MATHv>), grid, dim3(256), 0, s, a); \
@@ -2239,17 +2253,18 @@ static int launch_igemm2(const IgemmArgs& a, int TM, dim3 grid, hipStream_t s) {
 // Rows are covered by block rows of TM 32-row groups: `brows - 1` (or all) full-height block rows
 // in one launch, plus one launch with a smaller TM for the remaining groups (388 rows = 13 groups
 // -> 7 + 6; 194 -> 7; 768 -> 3 x 8), so that no block computes an empty row group.
-static int og_no_xrows() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("OG_NO_XROWS"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v;
-}
 
 static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed) {
     const int groups = og_cdiv(a.M, 32);
     const int Npix = a.N * a.PH * a.PW;
-    const int tiles_n = og_cdiv(Npix, 128);
     const int nph = a.nphase > 1 ? a.nphase : 1;
+    // bf16x3 runs against the L2 -> L1 fill rate (6 TB/s of fills at 190 TFLOP/s, profiles/r03_x3_pmc_objd_l3.txt),
+    // and 2/3 of a workgroup's fills are its row tile: 8-wave workgroups (256 pixels per row tile) wherever the
+    // grid still covers the chip twice
+    int nw = 4;
+    if (a.math == 2 && a.M > 32 && og_nw8_min() > 0 &&
+        (long)og_cdiv(groups, 7) * og_cdiv(Npix, 256) * nph >= og_nw8_min()) nw = 8;
+    const int tiles_n = og_cdiv(Npix, 32 * nw);
     int TM, full_rows, rest;                             // block rows of height TM + one of height rest
     // (Carrying the 2 / 4 rows that 194 / 388 channels have beyond a multiple of 32 on the VALU next to the
     // MFMA stream -- as the weight-gradient kernels do -- was measured here in round 2 and bought nothing:
@@ -2289,7 +2304,7 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed) {
         ProfRec* pr = prof_begin(OG_CAT_IGEMM2(TM),
                                  2.0 * (a.m_end - a.m_begin) * (double)a.K * (double)Npix * nph, s);
         prof_meta(pr, 0, TM, a.m_end - a.m_begin, a.C, a.T, a.N, a.PH * nph, a.PW, a.stride * (a.osh > 1 ? -1 : 1), splits);
-        rc = launch_igemm2(a, TM, dim3(full_rows * tiles_n, splits, nph), s);
+        rc = launch_igemm2(a, TM, dim3(full_rows * tiles_n, splits, nph), s, nw);
         prof_end(pr, s);
         if (rc != OG_OK) return rc;
     }
@@ -2298,7 +2313,7 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed) {
         ProfRec* pr = prof_begin(OG_CAT_IGEMM2(rest),
                                  2.0 * (a.m_end - a.m_begin) * (double)a.K * (double)Npix * nph, s);
         prof_meta(pr, 0, rest, a.m_end - a.m_begin, a.C, a.T, a.N, a.PH * nph, a.PW, a.stride * (a.osh > 1 ? -1 : 1), splits);
-        rc = launch_igemm2(a, rest, dim3(tiles_n, splits, nph), s);
+        rc = launch_igemm2(a, rest, dim3(tiles_n, splits, nph), s, nw);
         prof_end(pr, s);
         if (rc != OG_OK) return rc;
     }
@@ -2467,6 +2482,9 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
     a.ksplit_steps = 0;
     a.nphase = 0;
     a.ring = ring;
+#ifdef OG_DEV
+    a.ablate = og_ablate();
+#endif
     for (int t = 0; t < OG_MAX_TAPS; ++t) {
         const int h = t < Tg ? dh[t] : 0, w_ = t < Tg ? dw[t] : 0;
         a.tap[t] = (int)(((unsigned)w_ << 16) | ((unsigned)h & 0xffffu));
@@ -2520,6 +2538,9 @@ int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float*
     a.ksplit_steps = 0;
     a.ring = nullptr;
     a.nphase = 4;
+#ifdef OG_DEV
+    a.ablate = og_ablate();
+#endif
     for (int t = 0; t < OG_MAX_TAPS; ++t) a.tap[t] = 0;
     for (int ph = 0; ph < 4; ++ph)
         for (int t = 0; t < Tg; ++t)
@@ -2565,16 +2586,16 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
     if (v2) {
         const bool bf = math == 1, sp = math == 2;
         int groups = og_cdiv(Cout, 32);
-        const int tiles_n = og_cdiv(a.ncol, 128);
+        const int tiles_n0 = og_cdiv(a.ncol, 128);
         // 1..4 output channels beyond a multiple of 32: on the VALU of block row 0 (see WgradArgs)
         const int tail_rows = Cout & 31;
         bool xrows = !og_no_xrows() && math == 0 && tail_rows >= 1 && tail_rows <= 4 && Cout >= 64;
         int TM, full_rows, rest;
         if (xrows) {
-            og_row_plan(groups - 1, tiles_n, 1, &TM, &full_rows, &rest);
+            og_row_plan(groups - 1, tiles_n0, 1, &TM, &full_rows, &rest);
             if (TM >= 2 && full_rows >= 1) groups -= 1; else xrows = false;
         }
-        og_row_plan(groups, tiles_n, 1, &TM, &full_rows, &rest);
+        og_row_plan(groups, tiles_n0, 1, &TM, &full_rows, &rest);      // (tall tiles: independent of the column tiling)
         a.xr_begin = groups * 32;
         for (int part = 0; part < 2; ++part) {
             const int tm = part == 0 ? TM : rest;
@@ -2588,6 +2609,19 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
             // split + a fixed prologue / atomic-epilogue cost); pick the split count that minimises it
             // (r02: `slots / workgroups` left the 288-workgroup launches of the 16x16 maps at 1 split --
             // 32 CUs with two workgroups, 224 with one -- 63 TFLOP/s).  OG_WGRAD_OLDSPLIT=1: previous rule.
+            // which form (see the comment at the launch below) and how many waves per workgroup: decided here because
+            // the column-tile count of the launch depends on it
+            const bool wide_s1 = stride == 1 && !upsample && OW >= 64;
+            const bool b128 = wide_s1 && !og_wgrad_nob128() && !bf;
+            // (bf16x3: the LDS-staged form is instruction-issue bound -- 8 VALU per MFMA for per-element gather addresses
+            // plus the split of both operands, profiles/r03_x3_pmc_objd_l3.txt -- so the register-fragment form also
+            // takes the tall tiles wherever its constant-stride gather path applies: zero padding, no upsampling;
+            // r03 A/B: objd_l2 / objd_l3 155 -> 170 TFLOP/s, upsampled sources 119 -> 109)
+            const bool x3_frag = tm <= og_x3_wgrad3_maxtm() || b128 || (!upsample && !pad_mode && og_x3_wgrad3_maxtm() >= 0);
+            const bool use3 = bf ? tm <= 2 : (sp ? x3_frag : (tm <= og_wgrad3_maxtm() || b128));
+            // bf16x3, register-fragment form: 8-wave workgroups (256 columns per dy row tile), as in run_igemm2
+            const int nw = (sp && use3 && tm > 1 && og_nw8_min() > 0 && Npix >= 16384) ? 8 : 4;
+            const int tiles_n = og_cdiv(a.ncol, 32 * nw);
             int splits;
             const int max_splits = og_cdiv(Npix, 512);       // >= 32 K steps per split
             if (og_wgrad_oldsplit()) {
@@ -2598,7 +2632,7 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
             } else {
                 const long wgs = (long)rows * tiles_n;
                 const int nsteps = og_cdiv(Npix, 16);
-                const int resident = tm == 1 ? 6 : (tm <= 4 ? 3 : 2);
+                const int resident = nw == 8 ? 1 : (tm == 1 ? 6 : (tm <= 4 ? 3 : 2));
                 double best = -1;
                 splits = 1;
                 for (int sp = 1; sp <= max_splits && sp <= 1024; ++sp) {
@@ -2615,11 +2649,8 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
             a.pix_per_split = pps;
             dim3 grid(rows * tiles_n, splits);
             if (og_trace())
-                fprintf(stderr, "OGTRACE wgrad TM=%d Cout=%d Cin=%d k=%d N=%d OH=%d OW=%d stride=%d grid=%u,%u math=%d\n", tm, Cout, Cin,
-                        ksize, N, OH, OW, stride, grid.x, grid.y, math);
-            const bool wide_s1 = stride == 1 && !upsample && OW >= 64;
-            const bool b128 = wide_s1 && !og_wgrad_nob128() && !bf;
-            const bool use3 = bf ? tm <= 2 : (tm <= og_wgrad3_maxtm() || b128);   // (b128 is false in bf16 mode)
+                fprintf(stderr, "OGTRACE wgrad TM=%d NW=%d form=%d Cout=%d Cin=%d k=%d N=%d OH=%d OW=%d stride=%d grid=%u,%u math=%d\n", tm, nw,
+                        use3 ? 3 : 2, Cout, Cin, ksize, N, OH, OW, stride, grid.x, grid.y, math);
             ProfRec* pr = prof_begin(use3 ? OG_CAT_WGRAD3(tm) : OG_CAT_WGRAD2(tm),
                                      2.0 * (a.m_end - a.m_begin + a.xr_count) * (double)a.ncol * (double)Npix, s);
             prof_meta(pr, 1, tm, a.m_end - a.m_begin + a.xr_count, Cin, ksize * ksize, N, OH, OW,
@@ -2636,6 +2667,8 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
                      else hipLaunchKernelGGL((conv_wgrad2_kernel<TMv, 0, 4>), grid, dim3(256), 0, s, a, ksize);
 #define OG_WG2(TMv) if (bf && TMv <= 2) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, 1>), grid, dim3(256), 0, s, a, ksize); \
                     else if (bf) hipLaunchKernelGGL((conv_wgrad2_kernel<TMv, 1>), grid, dim3(256), 0, s, a, ksize); \
+                    else if (sp && use3 && nw == 8 && b128) hipLaunchKernelGGL((conv_wgrad3_kernel<(TMv > 1 ? TMv : 2), 2, true, 0, 8>), grid, dim3(512), 0, s, a, ksize); \
+                    else if (sp && use3 && nw == 8) hipLaunchKernelGGL((conv_wgrad3_kernel<(TMv > 1 ? TMv : 2), 2, false, 0, 8>), grid, dim3(512), 0, s, a, ksize); \
                     else if (sp && use3 && b128) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, 2, true>), grid, dim3(256), 0, s, a, ksize); \
                     else if (sp && use3) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, 2>), grid, dim3(256), 0, s, a, ksize); \
                     else if (sp) hipLaunchKernelGGL((conv_wgrad2_kernel<TMv, 2>), grid, dim3(256), 0, s, a, ksize); \

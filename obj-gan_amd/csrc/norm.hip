@@ -612,12 +612,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
 }
 
 #define OG_IN_FUSED_MAX 65536        // largest plane (elements) the one-kernel InstanceNorm takes: 256 KB, two passes
-#include <stdlib.h>
-static int og_norm_nofuse() {       // OG_NORM_NOFUSE=1: the three-kernel path everywhere (A/B, debugging)
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("OG_NORM_NOFUSE"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v;
-}
+OG_KNOB(og_norm_nofuse, "OG_NORM_NOFUSE", 0)       // development builds: 1 = the three-kernel path everywhere
 
 static inline int norm_splits(int G, long per_group) {
     // aim for >= 4 workgroups per CU overall, >= 1024 elements per workgroup

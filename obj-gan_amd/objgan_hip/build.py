@@ -16,6 +16,9 @@ LIB_PATH = os.path.join(HERE, "libobjgan_hip.so")
 OBJ_DIR = os.path.join(CSRC, "build")
 
 BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
+# OBJGAN_DEV=1: development build -- the OG_* switches of csrc/common.h (OG_KNOB) read the environment
+if os.environ.get("OBJGAN_DEV") == "1":
+    BASE_FLAGS.append("-DOG_DEV")
 # ROIAlign index math must be bit-exact with the reference C loop: no FMA contraction.
 # The Pillow-exact image resize evaluates its filter coefficients in double in Pillow's operation order.
 PER_FILE_FLAGS = {"roi_align.hip": ["-ffp-contract=off"], "resize_pil.hip": ["-ffp-contract=off"]}
@@ -32,8 +35,20 @@ def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+FLAGS_STAMP = LIB_PATH + ".flags"
+
+
+def _flags_line():
+    return " ".join(BASE_FLAGS) + " | " + " ".join("%s:%s" % (k, " ".join(v)) for k, v in sorted(PER_FILE_FLAGS.items()))
+
+
 def needs_build():
     if not os.path.exists(LIB_PATH):
+        return True
+    try:                        # a library built with other flags (e.g. a development build) is stale
+        if open(FLAGS_STAMP).read() != _flags_line():
+            return True
+    except OSError:
         return True
     lib_m = os.path.getmtime(LIB_PATH)
     for f in os.listdir(CSRC):
@@ -46,6 +61,10 @@ def needs_build():
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB_PATH
+    try:
+        force = force or open(FLAGS_STAMP).read() != _flags_line()
+    except OSError:
+        force = True
     hipcc = _hipcc()
     os.makedirs(OBJ_DIR, exist_ok=True)
     objs = []
@@ -73,6 +92,8 @@ def build(force=False, verbose=True):
         print("[objgan_hip.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd="/tmp" if os.path.isdir("/tmp") else None)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    with open(FLAGS_STAMP, "w") as f:
+        f.write(_flags_line())
     return LIB_PATH
 
 

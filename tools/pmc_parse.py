@@ -1,6 +1,6 @@
 import csv, glob, collections, sys
 tag = sys.argv[1]
-for i in (1, 2, 3, 4):
+for i in (1, 2, 3, 4, 5):
     fs = glob.glob('gpurun_out/%s_pmc%d/*counter_collection.csv' % (tag, i))
     if not fs:
         print(i, 'no file'); continue
