@@ -77,7 +77,16 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
                       int Tg, const int* dh, const int* dw, const int* src_tap,
                       int PH, int PW, int stride,
                       int OHf, int OWf, int osh, int osw, int ooh, int oow,
-                      int act, int y_prezeroed, int wt_packed, int math, float* ring, void* stream);
+                      int act, int y_prezeroed, int wt_packed, int math, float* ring,
+                      float* ws, long ws_floats, void* stream);
+/* ws: split-K workspace.  Small-grid / long-K launches are split along K: every split stores its partial output into
+ * its own slot of ws and a second kernel sums the slots in split order (+ bias, activation) -- bit-reproducible, no
+ * zero-fill of y, no atomics.  objgan_conv_igemm_ws_floats (host-only, same geometry arguments; ring != 0 when a ring
+ * buffer is passed) says how many floats a call needs (0 for most); a call that needs them and gets fewer returns 0. */
+long objgan_conv_igemm_ws_floats(int N, int C, int H, int W, int upsample, int pad_mode,
+                                 int Cout, int Cin, int Torig, int transpose, int Tg,
+                                 int PH, int PW, int stride, int OHf, int OWf, int osh, int osw,
+                                 int act, int y_prezeroed, int math, int ring);
 /* ring (may be NULL): data gradient of a ReflectionPad2d(1) convolution without the padded intermediate -- the
  * GEMM runs over the padded pixel grid (PH = OHf + 2, PW = OWf + 2, y is the UNPADDED gradient), interior
  * pixels are stored into y, the one-pixel border into ring [N*M][2*PW + 2*PH]; objgan_reflect_ring_fold then
@@ -91,10 +100,15 @@ int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float*
                                 int N, int Cout, int OH, int OW, int Cin, int Torig,
                                 int Tg, const int* dh, const int* dw, const int* src_tap,
                                 int PH, int PW, int wt_packed, int math, void* stream);
-/* dw[co][ci][kh][kw] += sum dy * x (dw zero-filled / accumulated by the caller); ksize in {1,3,4} */
+/* dw[co][ci][kh][kw] = (accumulate ? dw : 0) + sum dy * x; ksize in {1,3,4}.  The reduction over pixels is split
+ * across workgroups; the partial tiles go through ws (objgan_conv_wgrad_ws_floats floats, host-only query) and are
+ * summed in split order: the weight gradient is bit-reproducible and dw needs no zero-fill. */
+long objgan_conv_wgrad_ws_floats(int N, int Cin, int H, int W, int upsample, int pad_mode,
+                                 int Cout, int OH, int OW, int ksize, int stride, int pad, int math);
 int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
                       int N, int Cin, int H, int W, int upsample, int pad_mode,
-                      int Cout, int OH, int OW, int ksize, int stride, int pad, int math, void* stream);
+                      int Cout, int OH, int OW, int ksize, int stride, int pad, int math,
+                      int accumulate, float* ws, long ws_floats, void* stream);
 
 /* ---- frozen text encoder (reference model.py:85-179 RNN_ENCODER: Embedding + bidirectional LSTM on
  * a packed sequence).  table [ntoken][I]; captions [B][L] int64; lens [B] int32; wt_ih [2][I][4H] and

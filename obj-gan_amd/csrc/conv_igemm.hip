@@ -66,7 +66,12 @@ struct IgemmArgs {
     int pad_mode;        // 0 = zeros outside [0,LH)x[0,LW), 1 = reflect
     int upsample;        // 1 = source index = logical index >> 1
     int act;
-    int ksplit_steps;    // > 0: split-K -- blockIdx.y owns this many BK steps, epilogue = atomicAdd
+    int ksplit_steps;    // > 0: split-K -- blockIdx.y owns this many BK steps; epilogue: its partial tile goes to
+                         // ws[blockIdx.y][...] (conv_igemm3_kernel; summed in split order by splitk_combine_kernel,
+                         // which also applies bias / activation: bit-reproducible, no zero-fill) or, ws == nullptr, is
+                         // added to a zeroed y with fp32 atomics (partial-coverage launches, first-generation kernel)
+    float* ws;           // split-K partials [splits][ws_stride]: y-shaped, then (ring mode) ring-shaped
+    long ws_stride;
     int nphase;          // > 1 (v2 kernel only): blockIdx.z = output phase p with its own tap table
                          // tap[p*8 ..], packed bank wt + p*M*Kpad and output offset (ooh, oow) = (p>>1, p&1)
     float* ring;         // != nullptr (conv_igemm3_kernel only): data gradient of a ReflectionPad2d(1) convolution.
@@ -78,7 +83,7 @@ struct IgemmArgs {
 #ifdef OG_DEV
     int ablate;             // development builds: main-loop ablation of the bf16x3 kernel (timing only, wrong results):
                             // 1 no m/l products, 2 no pixel gathers after the prologue, 4 no row-tile loads after the
-                            // prologue, 8 no barriers, 16 no LDS stores, 32 no split VALU
+                            // prologue, 8 no barriers, 16 no LDS stores, 32 no split VALU, 64 no LDS fragment reads
 #endif
 };
 #ifdef OG_DEV
@@ -694,6 +699,37 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackArg
     }
 }
 
+// out[e] = act(bias[(e / HW) % M] + sum_{s < splits} ws[s * ws_stride + seg_off + e]): the second level of split-K
+// (conv_igemm3_kernel writes the partial tiles), splits summed in order.
+__global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __restrict__ ws, int splits, long ws_stride,
+                                                             long seg_off, float* __restrict__ out, long total,
+                                                             const float* __restrict__ bias, int M, int HW, int act) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const float* p = ws + seg_off + e;
+        float v = p[0];
+        for (int k = 1; k < splits; ++k) v += p[(size_t)k * ws_stride];
+        if (bias) v += bias[(e / HW) % M];
+        out[e] = og_act(v, act);
+    }
+}
+
+// dw rows <- sum over the splits of a weight-gradient launch (WgradArgs::ws): local row r of the slot is dw row
+// m_begin + r for r < main_rows, extra row xr_begin + (r - main_rows) behind them.
+__global__ __launch_bounds__(256) void wgrad_combine_kernel(const float* __restrict__ ws, int splits, long ws_stride,
+                                                            float* __restrict__ dw, int ncol, int m_begin, int main_rows,
+                                                            int xr_begin, long total, int accumulate) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const float* p = ws + e;
+        float v = p[0];
+        for (int k = 1; k < splits; ++k) v += p[(size_t)k * ws_stride];
+        const long r = e / ncol;
+        const int col = (int)(e - r * ncol);
+        const long row = r < main_rows ? m_begin + r : xr_begin + (r - main_rows);
+        float* o = dw + row * ncol + col;
+        *o = accumulate ? *o + v : v;
+    }
+}
+
 // y[n, m, i] = act(y[n, m, i] + bias[m]) -- epilogue of the split-K path
 __global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias,
                                                        long total, int M, int HW, int act) {
@@ -720,13 +756,38 @@ struct WgradArgs {
     int m_begin, m_end;
     int ncol;
     int pix_per_split;
-    int math;          // 0 fp32, 1 bf16 inputs
+    int math;          // 0 fp32, 1 bf16 inputs, 2 bf16x3
+    // Where a workgroup's tile goes.  One split (gridDim.y == 1): straight into dw -- stored, or added to what is there
+    // when `accumulate` -- every element by exactly one thread.  Several splits: the partial tile of split s goes to
+    // ws[s * ws_stride + (m - m_begin) * ncol + col] (extra rows behind the block rows); wgrad_combine_kernel sums the
+    // splits in order.  No atomics, no zero-fill: the weight gradient is bit-reproducible.
+    float* ws;
+    long ws_stride;
+    int accumulate;
     int xr_begin, xr_count;   // XR kernels: dy rows [xr_begin, xr_begin + xr_count) (<= 4) are carried by block row 0 on
                               // the fp32 VALU instead of costing a 32-row MFMA group (194 = 6*32 + 2, 388 = 12*32 + 4):
                               // the lane's eight gathered values (its MFMA operand) meet the extra rows' dy values read
                               // as LDS broadcasts; the two pixel halves of a column meet in one shuffle in the epilogue.
                               // r02: -8 % on the 194 / 388-channel weight gradients at 128^2, -20 % at 32^2.
 };
+
+__device__ __forceinline__ void og_wgrad_store(const WgradArgs& a, int m, int col, float v) {
+    if (a.ws) {
+        a.ws[(size_t)blockIdx.y * a.ws_stride + (size_t)(m - a.m_begin) * a.ncol + col] = v;
+    } else {
+        float* p = a.dw + (size_t)m * a.ncol + col;
+        *p = a.accumulate ? *p + v : v;
+    }
+}
+// extra row j of the XR kernels: local row (m_end - m_begin) + j of the workspace slot
+__device__ __forceinline__ void og_wgrad_store_xr(const WgradArgs& a, int j, int col, float v) {
+    if (a.ws) {
+        a.ws[(size_t)blockIdx.y * a.ws_stride + (size_t)(a.m_end - a.m_begin + j) * a.ncol + col] = v;
+    } else {
+        float* p = a.dw + (size_t)(a.xr_begin + j) * a.ncol + col;
+        *p = a.accumulate ? *p + v : v;
+    }
+}
 
 template <int KS, int WM, int TM>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
@@ -867,7 +928,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-                if (m < a.m_end) atomicAdd(a.dw + (size_t)m * a.ncol + col, acc[i][j][r]);
+                if (m < a.m_end) og_wgrad_store(a, m, col, acc[i][j][r]);
             }
         }
     }
@@ -1151,13 +1212,13 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-            if (m < a.m_end) atomicAdd(a.dw + (size_t)m * a.ncol + ocol, acc[i][r]);
+            if (m < a.m_end) og_wgrad_store(a, m, ocol, acc[i][r]);
         }
     }
     if (XR > 0 && has_x && lrow == 0) {
 #pragma unroll
         for (int j = 0; j < XR; ++j)
-            if (j < a.xr_count) atomicAdd(a.dw + (size_t)(a.xr_begin + j) * a.ncol + ocol, accx[j]);
+            if (j < a.xr_count) og_wgrad_store_xr(a, j, ocol, accx[j]);
     }
 }
 
@@ -1340,6 +1401,15 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
     // row-tile load).  Issue is in order, so work placed in FRONT of a step's MFMAs is exposed every step;
     // in the fp32 LDS form it goes behind the first TM MFMAs and runs in the shadow of the rest (r02:
     // weight-gradient kernel 110 -> 119 TFLOP/s with the same move).
+    bf16x8 ah[SP ? TM : 1], am[SP ? TM : 1], al[SP ? TM : 1];     // SP: row fragments of the current step
+#ifdef OG_DEV
+    if (SP) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { ah[i][j] = (__bf16)(0.001f * (lane + j)); am[i][j] = ah[i][j]; al[i][j] = ah[i][j]; }
+    }
+#endif
     auto mma = [&](const float (&rb)[NB], const f32x4 (&ad)[NAD], int cur, auto&& mid) {
         if (BF || !ALDS) mid();       // (SP with LDS: behind its first TM MFMAs, below)
         if (SP) {
@@ -1347,8 +1417,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
             // refill behind the first TM of them, the m / l pieces (~40 VALU) pinned between the next 2 TM MFMAs.
             bf16x8 bh, bm, bl;
             og_split8_h(rb, bh);
-            bf16x8 ah[TM], am[TM], al[TM];
-            if (ALDS) {
+            if (ALDS && !OG_ABL(64)) {
                 const char* T = reinterpret_cast<const char*>(lds + cur * TILE) + lcol * (LD * 4) + lrow * 16;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
@@ -1356,7 +1425,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
                     am[i] = *reinterpret_cast<const bf16x8*>(T + i * 32 * LD * 4 + 32);
                     ah[i] = *reinterpret_cast<const bf16x8*>(T + i * 32 * LD * 4);
                 }
-            } else {
+            } else if (!ALDS) {
                 ah[0] = __builtin_bit_cast(bf16x8, ad[0]);
                 am[0] = __builtin_bit_cast(bf16x8, ad[1]);
                 al[0] = __builtin_bit_cast(bf16x8, ad[NAD - 1]);
@@ -1495,7 +1564,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
         float rb2[NB];
         int ks = kt0;
 #ifdef OG_DEV
-        if (a.ablate & 0x3e) {          // ablation form of the main loop (development builds only)
+        if (a.ablate & 0x7e) {          // ablation form of the main loop (development builds only)
 #pragma unroll
             for (int j = 0; j < NB; ++j) rb2[j] = rb0[j];
             for (; ks + 2 < nk; ks += 3) {
@@ -1557,8 +1626,10 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
     const int ow = pb * a.osw + (a.nphase > 1 ? (phase & 1) : a.oow);
     size_t plane = (size_t)a.OHf * a.OWf;
     float* yb = a.y + (size_t)n * a.M * plane + (size_t)oh * a.OWf + ow;
+    bool in_ring = false;
     if (a.ring) {        // padded grid -> unpadded y (interior) or the ring buffer (see IgemmArgs::ring)
         const bool inner = pa >= 1 && pa <= a.PH - 2 && pb >= 1 && pb <= a.PW - 2;
+        in_ring = !inner;
         if (inner) {
             yb = a.y + (size_t)n * a.M * plane + (size_t)(pa - 1) * a.OWf + (pb - 1);
         } else {
@@ -1570,6 +1641,11 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
     }
     const bool split = a.ksplit_steps > 0;
     const bool lrelu = a.act == OG_ACT_LRELU, relu = a.act == OG_ACT_RELU;
+    if (split && a.ws) {      // partial tile of this K range -> workspace slot of this split (same element offsets as y / ring)
+        const size_t off = in_ring ? (size_t)a.N * a.M * a.OHf * a.OWf + (size_t)(yb - a.ring) : (size_t)(yb - a.y);
+        yb = a.ws + (size_t)blockIdx.y * a.ws_stride + off;
+    }
+    const bool to_ws = split && a.ws;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -1577,7 +1653,9 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
             const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
             if (m < a.m_end) {
                 float v = acc[i][r];
-                if (split) {
+                if (to_ws) {
+                    yb[(size_t)m * plane] = v;
+                } else if (split) {
                     atomicAdd(&yb[(size_t)m * plane], v);
                 } else {
                     if (a.bias) v += a.bias[m];
@@ -1955,13 +2033,13 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad3_kernel(const WgradArgs a,
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-            if (m < a.m_end) atomicAdd(a.dw + (size_t)m * a.ncol + col, acc[i][r]);
+            if (m < a.m_end) og_wgrad_store(a, m, col, acc[i][r]);
         }
     }
     if (XR > 0 && has_x && lrow == 0) {
 #pragma unroll
         for (int j = 0; j < XR; ++j)
-            if (j < a.xr_count) atomicAdd(a.dw + (size_t)(a.xr_begin + j) * a.ncol + col, accx[j]);
+            if (j < a.xr_count) og_wgrad_store_xr(a, j, col, accx[j]);
     }
 }
 
@@ -2254,46 +2332,81 @@ static int launch_igemm2(const IgemmArgs& a, int TM, dim3 grid, hipStream_t s, i
 // in one launch, plus one launch with a smaller TM for the remaining groups (388 rows = 13 groups
 // -> 7 + 6; 194 -> 7; 768 -> 3 x 8), so that no block computes an empty row group.
 
-static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed) {
+struct Igemm2Plan { int nw, TM, full_rows, rest, tiles_n, splits, ksplit_steps, full_cover; };
+
+// Launch plan of run_igemm2 (also behind objgan_conv_igemm_ws_floats: the caller sizes the split-K workspace from it).
+static Igemm2Plan igemm2_plan(const IgemmArgs& a, int y_prezeroed) {
+    Igemm2Plan p;
     const int groups = og_cdiv(a.M, 32);
     const int Npix = a.N * a.PH * a.PW;
     const int nph = a.nphase > 1 ? a.nphase : 1;
     // bf16x3 runs against the L2 -> L1 fill rate (6 TB/s of fills at 190 TFLOP/s, profiles/r03_x3_pmc_objd_l3.txt),
     // and 2/3 of a workgroup's fills are its row tile: 8-wave workgroups (256 pixels per row tile) wherever the
     // grid still covers the chip twice
-    int nw = 4;
-    if (a.math == 2 && a.M > 32 && og_nw8_min() > 0 &&
-        (long)og_cdiv(groups, 7) * og_cdiv(Npix, 256) * nph >= og_nw8_min()) nw = 8;
-    const int tiles_n = og_cdiv(Npix, 32 * nw);
-    int TM, full_rows, rest;                             // block rows of height TM + one of height rest
+    // (tall tiles only: at TM <= 3 a 4-wave workgroup leaves room for three per CU and wins -- r03 A/B, 96-row
+    // layers 179 vs 158 TFLOP/s; with 8 waves the block rows are as tall as the row count allows)
+    p.nw = 4;
+    const int tm_tall = og_cdiv(groups, og_cdiv(groups, 7));
+    if (a.math == 2 && tm_tall >= 4 && og_nw8_min() > 0 &&
+        (long)og_cdiv(groups, 7) * og_cdiv(Npix, 256) * nph >= og_nw8_min()) p.nw = 8;
+    p.tiles_n = og_cdiv(Npix, 32 * p.nw);
     // (Carrying the 2 / 4 rows that 194 / 388 channels have beyond a multiple of 32 on the VALU next to the
     // MFMA stream -- as the weight-gradient kernels do -- was measured here in round 2 and bought nothing:
     // 106.0 vs 107.8 TFLOP/s on res1_128; interleaving the FMAs with the MFMAs cost 20 %.)
-    og_row_plan(groups, tiles_n * nph, 0, &TM, &full_rows, &rest);
-    const int tiles = (full_rows + (rest ? 1 : 0)) * tiles_n;
+    og_row_plan(groups, p.tiles_n * nph, p.nw == 8, &p.TM, &p.full_rows, &p.rest);
+    const int tiles = (p.full_rows + (p.rest ? 1 : 0)) * p.tiles_n;
     const int nk = a.math == 1 ? a.Krow / 32 : a.Kpad / 16;      // loop iterations of the kernel
-    const bool full_cover = (a.osh == 1 && a.osw == 1 && a.PH == a.OHf && a.PW == a.OWf) || a.ring != nullptr;
+    p.full_cover = ((a.osh == 1 && a.osw == 1 && a.PH == a.OHf && a.PW == a.OWf) || a.ring != nullptr) ? 1 : 0;
     int splits = 1;
-    if (tiles < 128 && nk >= 16 && (full_cover || y_prezeroed) && nph == 1) {
+    if (tiles < 128 && nk >= 16 && (p.full_cover || y_prezeroed) && nph == 1) {
         splits = og_cdiv(512, tiles);
         if (splits > nk / 4) splits = nk / 4;
-    } else if (og_split_target() > 0 && TM == 1 && rest == 0 && tiles < og_split_target() && nk >= 16 &&
-               (full_cover || y_prezeroed) && nph == 1) {
+    } else if (og_split_target() > 0 && p.TM == 1 && p.rest == 0 && tiles < og_split_target() && nk >= 16 &&
+               (p.full_cover || y_prezeroed) && nph == 1) {
         splits = og_cdiv(og_split_target(), tiles);
         if (splits > nk / 8) splits = nk / 8;
         if (splits < 1) splits = 1;
     }
+    p.ksplit_steps = 0;
+    if (splits > 1) {
+        p.ksplit_steps = og_cdiv(nk, splits);
+        splits = og_cdiv(nk, p.ksplit_steps);
+    }
+    p.splits = splits;
+    return p;
+}
+
+// floats of split-K workspace run_igemm2 wants for this plan (0: one split, or a partial-coverage launch that
+// accumulates into the pre-zeroed output)
+static long igemm2_ws_floats(const IgemmArgs& a, const Igemm2Plan& p) {
+    if (p.splits <= 1 || !p.full_cover) return 0;
+    const long seg = (long)a.N * a.M * a.OHf * a.OWf + (a.ring ? (long)a.N * a.M * (2 * a.PW + 2 * a.PH) : 0);
+    return seg * p.splits;
+}
+
+static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed, float* ws, long ws_floats) {
+    const Igemm2Plan p = igemm2_plan(a, y_prezeroed);
+    const int Npix = a.N * a.PH * a.PW;
+    const int nph = a.nphase > 1 ? a.nphase : 1;
+    const int TM = p.TM, full_rows = p.full_rows, rest = p.rest, tiles_n = p.tiles_n, nw = p.nw;
+    int splits = p.splits;
+    const bool full_cover = p.full_cover != 0;
     const float* bias = a.bias;
     const int act = a.act;
     const bool act_later = (act == OG_ACT_TANH || act == OG_ACT_SIGMOID);
+    const long y_elems = (long)a.N * a.M * a.OHf * a.OWf;
+    const long ring_elems = a.ring ? (long)a.N * a.M * (2 * a.PW + 2 * a.PH) : 0;
+    a.ws = nullptr; a.ws_stride = 0;
     if (splits > 1) {
-        a.ksplit_steps = og_cdiv(nk, splits);
-        splits = og_cdiv(nk, a.ksplit_steps);
+        a.ksplit_steps = p.ksplit_steps;
         a.bias = nullptr; a.act = OG_ACT_NONE;
-        if (!y_prezeroed)
-            (void)hipMemsetAsync(a.y, 0, sizeof(float) * (size_t)a.N * a.M * a.OHf * a.OWf, s);
-        if (a.ring)
-            (void)hipMemsetAsync(a.ring, 0, sizeof(float) * (size_t)a.N * a.M * (2 * a.PW + 2 * a.PH), s);
+        const long need = igemm2_ws_floats(a, p);
+        if (need > 0) {                       // two-level reduction through the caller's workspace
+            if (!ws || ws_floats < need) return OG_BAD_ARGS;
+            a.ws = ws; a.ws_stride = y_elems + ring_elems;
+        } else if (!y_prezeroed) {            // (not reached: partial coverage splits only when y is pre-zeroed)
+            (void)hipMemsetAsync(a.y, 0, sizeof(float) * (size_t)y_elems, s);
+        }
     } else {
         a.ksplit_steps = 0;
         if (act_later) { a.bias = nullptr; a.act = OG_ACT_NONE; }
@@ -2317,8 +2430,16 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed) {
         prof_end(pr, s);
         if (rc != OG_OK) return rc;
     }
+    if (a.ws) {         // second level: sum the splits in order, + bias, activation
+        hipLaunchKernelGGL(splitk_combine_kernel, dim3(og_stream_grid(y_elems, 256)), dim3(256), 0, s, a.ws, splits,
+                           a.ws_stride, 0L, a.y, y_elems, bias, a.M, a.OHf * a.OWf, act);
+        if (ring_elems > 0)
+            hipLaunchKernelGGL(splitk_combine_kernel, dim3(og_stream_grid(ring_elems, 256)), dim3(256), 0, s, a.ws, splits,
+                               a.ws_stride, y_elems, a.ring, ring_elems, (const float*)nullptr, 1, 1, OG_ACT_NONE);
+        return og_launch_status();
+    }
     if ((splits > 1 || act_later) && (bias || act != OG_ACT_NONE) && full_cover) {
-        const long total = (long)a.N * a.M * a.OHf * a.OWf;
+        const long total = y_elems;
         hipLaunchKernelGGL(bias_act_kernel, dim3(og_stream_grid(total, 256)), dim3(256), 0, s, a.y, bias,
                            total, a.M, a.OHf * a.OWf, act);
         return og_launch_status();
@@ -2438,14 +2559,12 @@ long objgan_conv_packed_floats(int M, int C, int T) {
 //   wt       scratch of objgan_conv_packed_floats(M, C*Tg) floats (overwritten)
 //   transpose 0: M = Cout, C = Cin ; 1: M = Cin, C = Cout (data gradient)
 //   src_tap[t] index of GEMM tap t in the Torig taps of w (or -1 for a zero tap)
-int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* y, float* wt,
-                      int N, int C, int H, int W, int upsample, int pad_mode,
-                      int Cout, int Cin, int Torig, int transpose,
-                      int Tg, const int* dh, const int* dw, const int* src_tap,
-                      int PH, int PW, int stride,
-                      int OHf, int OWf, int osh, int osw, int ooh, int oow,
-                      int act, int y_prezeroed, int wt_packed, int math, float* ring, void* stream) {
-    OG_ENTRY();
+// Fills the PackArgs / IgemmArgs of objgan_conv_igemm (shared with objgan_conv_igemm_ws_floats); returns OG_OK,
+// OG_BAD_ARGS or 2 for "nothing to do".
+static int og_igemm_setup(PackArgs& p, IgemmArgs& a, int& MT, const float* x, const float* w, const float* bias, float* y,
+                          float* wt, int N, int C, int H, int W, int upsample, int pad_mode, int Cout, int Cin, int Torig,
+                          int transpose, int Tg, const int* dh, const int* dw, const int* src_tap, int PH, int PW,
+                          int stride, int OHf, int OWf, int osh, int osw, int ooh, int oow, int act, int math, float* ring) {
     if (Tg < 1 || Tg > OG_MAX_TAPS) return OG_BAD_ARGS;
     if (ring && !(osh == 1 && osw == 1 && ooh == 0 && oow == 0 && PH == OHf + 2 && PW == OWf + 2 && !bias && !act))
         return OG_BAD_ARGS;
@@ -2454,21 +2573,10 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
     const int M = transpose ? Cin : Cout;
     const int Ck = transpose ? Cout : Cin;
     if (Ck != C) return OG_BAD_ARGS;
-    if (N <= 0 || PH <= 0 || PW <= 0 || M <= 0) return OG_OK;
-    hipStream_t s = (hipStream_t)stream;
-    PackArgs p;
-    int MT = 32;
+    if (N <= 0 || PH <= 0 || PW <= 0 || M <= 0) return 2;
+    MT = 32;
     og_fill_pack(p, w, wt, N, C, H, W, Cout, Cin, Torig, transpose, Tg, src_tap, PH, PW, act, math, &MT);
-    const bool v2 = p.m_major != 0, thin = p.m_major == 2;
     const int kmath = p.m_major == 3 ? 1 : (p.m_major == 4 ? 2 : 0);       // arithmetic of the kernel that runs
-    if (!wt_packed) {       // wt_packed: the caller kept wt from an earlier call with the same
-        const long ptotal = (long)Tg * p.Cp * p.Mpad;   // filter bank, taps, math and geometry class
-        hipLaunchKernelGGL(pack_weights_kernel, dim3(og_stream_grid(ptotal, 256)), dim3(256), 0, s, p);
-        int rc = og_launch_status();
-        if (rc != OG_OK) return rc;
-    }
-
-    IgemmArgs a;
     a.x = x; a.wt = wt; a.bias = bias; a.y = y;
     a.N = N; a.C = C; a.H = H; a.W = W;
     a.LH = upsample ? 2 * H : H; a.LW = upsample ? 2 * W : W;
@@ -2482,6 +2590,7 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
     a.ksplit_steps = 0;
     a.nphase = 0;
     a.ring = ring;
+    a.ws = nullptr; a.ws_stride = 0;
 #ifdef OG_DEV
     a.ablate = og_ablate();
 #endif
@@ -2491,8 +2600,55 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
     }
     if (!(osh == 1 && osw == 1 && PH == OHf && PW == OWf) && (bias || act)) return OG_BAD_ARGS;
     if (ring && p.m_major != 1 && p.m_major != 4) return OG_BAD_ARGS;     // ring mode: conv_igemm3_kernel only (ask objgan_conv_bank_layout)
+    return OG_OK;
+}
+
+// Floats of split-K workspace objgan_conv_igemm needs for these arguments (0: none).  Small-grid / long-K launches
+// are split along K: every split stores its partial output tile into its own workspace slot and a second kernel sums
+// the slots in split order (+ bias, activation) -- bit-reproducible, no zero-fill of y, no atomics.  Host-only.
+long objgan_conv_igemm_ws_floats(int N, int C, int H, int W, int upsample, int pad_mode,
+                                 int Cout, int Cin, int Torig, int transpose, int Tg,
+                                 int PH, int PW, int stride, int OHf, int OWf, int osh, int osw,
+                                 int act, int y_prezeroed, int math, int ring) {
+    PackArgs p;
+    IgemmArgs a;
+    int MT = 32;
+    int zeros[OG_MAX_TAPS] = {0};
+    float dummy = 0.f;
+    memset(&p, 0, sizeof(p));
+    const int rc = og_igemm_setup(p, a, MT, nullptr, nullptr, nullptr, nullptr, nullptr, N, C, H, W, upsample, pad_mode, Cout, Cin,
+                                  Torig, transpose, Tg, zeros, zeros, zeros, PH, PW, stride, OHf, OWf, osh, osw, 0, 0, act,
+                                  math, ring ? &dummy : nullptr);
+    if (rc != OG_OK || p.m_major == 0 || p.m_major == 2) return 0;
+    return igemm2_ws_floats(a, igemm2_plan(a, y_prezeroed));
+}
+
+int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* y, float* wt,
+                      int N, int C, int H, int W, int upsample, int pad_mode,
+                      int Cout, int Cin, int Torig, int transpose,
+                      int Tg, const int* dh, const int* dw, const int* src_tap,
+                      int PH, int PW, int stride,
+                      int OHf, int OWf, int osh, int osw, int ooh, int oow,
+                      int act, int y_prezeroed, int wt_packed, int math, float* ring,
+                      float* ws, long ws_floats, void* stream) {
+    OG_ENTRY();
+    PackArgs p;
+    IgemmArgs a;
+    int MT = 32;
+    const int rc0 = og_igemm_setup(p, a, MT, x, w, bias, y, wt, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, transpose,
+                                   Tg, dh, dw, src_tap, PH, PW, stride, OHf, OWf, osh, osw, ooh, oow, act, math, ring);
+    if (rc0 == 2) return OG_OK;
+    if (rc0 != OG_OK) return rc0;
+    hipStream_t s = (hipStream_t)stream;
+    const bool v2 = p.m_major != 0, thin = p.m_major == 2;
+    if (!wt_packed) {       // wt_packed: the caller kept wt from an earlier call with the same
+        const long ptotal = (long)Tg * p.Cp * p.Mpad;   // filter bank, taps, math and geometry class
+        hipLaunchKernelGGL(pack_weights_kernel, dim3(og_stream_grid(ptotal, 256)), dim3(256), 0, s, p);
+        int rc = og_launch_status();
+        if (rc != OG_OK) return rc;
+    }
     if (thin) return run_thin(a, MT, s);
-    return v2 ? run_igemm2(a, s, y_prezeroed) : run_igemm(a, s, y_prezeroed);
+    return v2 ? run_igemm2(a, s, y_prezeroed, ws, ws_floats) : run_igemm(a, s, y_prezeroed);
 }
 
 // Data gradient of a stride-2 convolution whose four output parity phases have the same tap count
@@ -2537,6 +2693,7 @@ int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float*
     a.stride = 1; a.pad_mode = 0; a.upsample = 0; a.act = OG_ACT_NONE;
     a.ksplit_steps = 0;
     a.ring = nullptr;
+    a.ws = nullptr; a.ws_stride = 0;
     a.nphase = 4;
 #ifdef OG_DEV
     a.ablate = og_ablate();
@@ -2545,7 +2702,7 @@ int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float*
     for (int ph = 0; ph < 4; ++ph)
         for (int t = 0; t < Tg; ++t)
             a.tap[ph * 8 + t] = (int)(((unsigned)dw[ph * Tg + t] << 16) | ((unsigned)dh[ph * Tg + t] & 0xffffu));
-    return run_igemm2(a, s, 0);
+    return run_igemm2(a, s, 0, nullptr, 0);     // (four phases in one launch: never split along K)
 }
 
 // y [planes, H, W] += mirror of ring [planes, 2*(W+2) + 2*(H+2)] (written by objgan_conv_igemm in ring mode).
@@ -2559,17 +2716,23 @@ int objgan_reflect_ring_fold(const float* ring, float* y, long planes, int H, in
     return og_launch_status();
 }
 
-// dw must be zero-initialised by the caller (or hold a gradient to accumulate into).
-int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
-                      int N, int Cin, int H, int W, int upsample, int pad_mode,
-                      int Cout, int OH, int OW, int ksize, int stride, int pad,
-                      int math, void* stream) {
-    OG_ENTRY();
+}  // extern "C"
+
+// Plan and (unless ws_need != nullptr: plan only) run the weight gradient.  The reduction over pixels is split across
+// gridDim.y; each split writes its partial tile into its own workspace slot and wgrad_combine_kernel sums the slots
+// in split order into dw (stored, or added when `accumulate`): bit-reproducible, dw needs no zero-fill.
+static int og_wgrad(const float* x, const float* dy, float* dw,
+                    int N, int Cin, int H, int W, int upsample, int pad_mode,
+                    int Cout, int OH, int OW, int ksize, int stride, int pad,
+                    int math, int accumulate, float* ws, long ws_floats, long* ws_need, hipStream_t s) {
+    const bool plan_only = ws_need != nullptr;
+    long ws_used = 0;
+    if (plan_only) *ws_need = 0;
     if (ksize != 1 && ksize != 3 && ksize != 4) return OG_BAD_ARGS;
     if (math < 0 || math > 2) return OG_BAD_ARGS;
     if (N <= 0 || Cout <= 0 || Cin <= 0) return OG_OK;
-    hipStream_t s = (hipStream_t)stream;
     WgradArgs a;
+    a.ws = nullptr; a.ws_stride = 0; a.accumulate = accumulate;
     a.x = x; a.dy = dy; a.dw = dw;
     a.N = N; a.Cin = Cin; a.H = H; a.W = W;
     a.LH = upsample ? 2 * H : H; a.LW = upsample ? 2 * W : W;
@@ -2620,7 +2783,7 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
             const bool x3_frag = tm <= og_x3_wgrad3_maxtm() || b128 || (!upsample && !pad_mode && og_x3_wgrad3_maxtm() >= 0);
             const bool use3 = bf ? tm <= 2 : (sp ? x3_frag : (tm <= og_wgrad3_maxtm() || b128));
             // bf16x3, register-fragment form: 8-wave workgroups (256 columns per dy row tile), as in run_igemm2
-            const int nw = (sp && use3 && tm > 1 && og_nw8_min() > 0 && Npix >= 16384) ? 8 : 4;
+            const int nw = (sp && use3 && tm >= 4 && og_nw8_min() > 0 && Npix >= 16384) ? 8 : 4;
             const int tiles_n = og_cdiv(a.ncol, 32 * nw);
             int splits;
             const int max_splits = og_cdiv(Npix, 512);       // >= 32 K steps per split
@@ -2647,6 +2810,16 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
             pps = (pps + 15) / 16 * 16;
             splits = og_cdiv(Npix, pps);
             a.pix_per_split = pps;
+            {
+                const long slot = (long)(a.m_end - a.m_begin + a.xr_count) * a.ncol;
+                const long need = splits > 1 ? slot * splits : 0;
+                if (plan_only) { *ws_need += need; continue; }
+                a.ws = nullptr; a.ws_stride = 0;
+                if (splits > 1) {
+                    if (!ws || ws_used + need > ws_floats) return OG_BAD_ARGS;
+                    a.ws = ws + ws_used; a.ws_stride = slot; ws_used += need;
+                }
+            }
             dim3 grid(rows * tiles_n, splits);
             if (og_trace())
                 fprintf(stderr, "OGTRACE wgrad TM=%d NW=%d form=%d Cout=%d Cin=%d k=%d N=%d OH=%d OW=%d stride=%d grid=%u,%u math=%d\n", tm, nw,
@@ -2700,6 +2873,13 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
             prof_end(pr, s);
             int rc = og_launch_status();
             if (rc != OG_OK) return rc;
+            if (a.ws) {
+                const long slot = a.ws_stride;
+                hipLaunchKernelGGL(wgrad_combine_kernel, dim3(og_stream_grid(slot, 256)), dim3(256), 0, s, a.ws, splits, slot,
+                                   dw, a.ncol, a.m_begin, a.m_end - a.m_begin, a.xr_begin, slot, accumulate);
+                rc = og_launch_status();
+                if (rc != OG_OK) return rc;
+            }
         }
         return OG_OK;
     }
@@ -2723,6 +2903,16 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
         pps = (pps + 31) / 32 * 32;
         splits = og_cdiv(Npix, pps);
         a.pix_per_split = pps;
+        {
+            const long slot = (long)(a.m_end - a.m_begin) * a.ncol;
+            const long need = splits > 1 ? slot * splits : 0;
+            if (plan_only) { *ws_need += need; continue; }
+            a.ws = nullptr; a.ws_stride = 0;
+            if (splits > 1) {
+                if (!ws || ws_used + need > ws_floats) return OG_BAD_ARGS;
+                a.ws = ws + ws_used; a.ws_stride = slot; ws_used += need;
+            }
+        }
         dim3 grid(tiles, splits);
 #define OG_WG(KS)                                                                              \
         if (cfg == 0) hipLaunchKernelGGL((conv_wgrad_kernel<KS, 2, 2>), grid, dim3(256), 0, s, a);       \
@@ -2736,8 +2926,36 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
 #undef OG_WG
         int rc = og_launch_status();
         if (rc != OG_OK) return rc;
+        if (a.ws) {
+            const long slot = a.ws_stride;
+            hipLaunchKernelGGL(wgrad_combine_kernel, dim3(og_stream_grid(slot, 256)), dim3(256), 0, s, a.ws, splits, slot,
+                               dw, a.ncol, a.m_begin, a.m_end - a.m_begin, 0, slot, accumulate);
+            rc = og_launch_status();
+            if (rc != OG_OK) return rc;
+        }
     }
     return OG_OK;
+}
+
+extern "C" {
+
+// Floats of workspace objgan_conv_wgrad needs for these arguments (0: every launch runs as one split).  Host-only.
+long objgan_conv_wgrad_ws_floats(int N, int Cin, int H, int W, int upsample, int pad_mode,
+                                 int Cout, int OH, int OW, int ksize, int stride, int pad, int math) {
+    long need = 0;
+    (void)og_wgrad(nullptr, nullptr, nullptr, N, Cin, H, W, upsample, pad_mode, Cout, OH, OW, ksize, stride, pad, math, 0,
+                   nullptr, 0, &need, nullptr);
+    return need;
+}
+
+// dw [Cout][Cin][k][k] = (accumulate ? dw : 0) + sum dy * x.  ws: objgan_conv_wgrad_ws_floats(...) floats of scratch.
+int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
+                      int N, int Cin, int H, int W, int upsample, int pad_mode,
+                      int Cout, int OH, int OW, int ksize, int stride, int pad,
+                      int math, int accumulate, float* ws, long ws_floats, void* stream) {
+    OG_ENTRY();
+    return og_wgrad(x, dy, dw, N, Cin, H, W, upsample, pad_mode, Cout, OH, OW, ksize, stride, pad, math, accumulate ? 1 : 0,
+                    ws, ws_floats, nullptr, (hipStream_t)stream);
 }
 
 // ---- profiling control (see the note above the host section) ---------------------------------

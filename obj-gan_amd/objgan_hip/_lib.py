@@ -28,12 +28,12 @@ SIGNATURES = {
                           _c_int, _ptr, _ptr, _ptr,
                           _c_int, _c_int, _c_int,
                           _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                          _c_int, _c_int, _c_int, _c_int, _ptr, _ptr],
+                          _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _c_long, _ptr],
     "objgan_reflect_ring_fold": [_ptr, _ptr, _c_long, _c_int, _c_int, _ptr],
     "objgan_conv_dgrad_s2_phases": [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                     _c_int, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_conv_wgrad": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                          _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr],
+                          _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _c_long, _ptr],
     "objgan_lstm_bidir_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                                   _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_norm_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
@@ -80,7 +80,9 @@ SIGNATURES = {
     "objgan_prof_collect": [_ptr, _ptr, _ptr],
     "objgan_prof_dump": [_ptr, _ptr, _ptr, _c_int, _ptr],
 }
-LONG_RETURN = {"objgan_conv_packed_floats": [_c_int, _c_int, _c_int]}
+LONG_RETURN = {"objgan_conv_packed_floats": [_c_int, _c_int, _c_int],
+               "objgan_conv_igemm_ws_floats": [_c_int] * 22,
+               "objgan_conv_wgrad_ws_floats": [_c_int] * 13}
 
 _LIB = None
 

@@ -179,10 +179,16 @@ def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, tran
         _bank_mark(ent)
     else:
         wt, packed = torch.empty(nfl, dtype=_F32, device=x.device), 0
+    # split-K launches (small grids, long reductions) go through a workspace: partial tiles, then an ordered sum
+    nws = _lib.load().objgan_conv_igemm_ws_floats(N, C, H, W, int(upsample), int(pad_mode), Cout, Cin, Torig,
+                                                   int(transpose), Tg, PH, PW, stride, OHf, OWf, osh, osw, act,
+                                                   int(y_prezeroed), _MATH["mode"], 0 if ring is None else 1)
+    ws = torch.empty(nws, dtype=_F32, device=x.device) if nws > 0 else None
     _lib.call("objgan_conv_igemm", _p(x), _p(w), _p(bias), _p(y), _p(wt),
               N, C, H, W, int(upsample), int(pad_mode), Cout, Cin, Torig, int(transpose),
               Tg, _iarr(dh), _iarr(dw), _iarr(src_tap), PH, PW, stride,
-              OHf, OWf, osh, osw, ooh, oow, act, int(y_prezeroed), packed, _MATH["mode"], _p(ring), _stream())
+              OHf, OWf, osh, osw, ooh, oow, act, int(y_prezeroed), packed, _MATH["mode"], _p(ring),
+              _p(ws), nws, _stream())
 
 
 def _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad_h, pad_w, LH, LW, cacheable=True):
@@ -309,9 +315,11 @@ def _conv_wgrad(x, g, Cout, k, stride, pad, refl, upsample):
     (Accumulating straight into the optimizer arena's gradient view instead of a fresh zeroed buffer --
     360 fewer fill / add launches per step -- was measured in round 2: 274.2 vs 273.2 ms, no gain.)"""
     N, Cin, H, W = x.shape
-    dw_ = torch.zeros((Cout, Cin, k, k), dtype=_F32, device=x.device)
-    _lib.call("objgan_conv_wgrad", _p(x), _p(g), _p(dw_), N, Cin, H, W, int(upsample), refl,
-              Cout, g.shape[2], g.shape[3], k, stride, pad, _MATH["mode"], _stream())
+    dw_ = torch.empty((Cout, Cin, k, k), dtype=_F32, device=x.device)      # fully written: no zero-fill
+    geo = (N, Cin, H, W, int(upsample), refl, Cout, g.shape[2], g.shape[3], k, stride, pad, _MATH["mode"])
+    nws = _lib.load().objgan_conv_wgrad_ws_floats(*geo)
+    ws = torch.empty(nws, dtype=_F32, device=x.device) if nws > 0 else None
+    _lib.call("objgan_conv_wgrad", _p(x), _p(g), _p(dw_), *geo, 0, _p(ws), nws, _stream())
     return dw_
 
 

@@ -767,6 +767,57 @@ def test_bf16x3_math_is_as_accurate_as_the_fp32_mfma(dev, case):
         assert ex3 <= 1.25 * e32 + 2e-8, (what, "fp32", e32, "bf16x3", ex3)
 
 
+def test_conv_reductions_are_bit_reproducible(dev, fp32_math):
+    """Split reductions go through a workspace and are summed in split order (no fp32 atomics): the weight gradient
+    (pixels split across workgroups) and split-K outputs (small grids, long K) are bit-identical from run to run, the
+    output buffers need no zero-fill (NaN-filled here), and `accumulate` adds onto what the buffer holds."""
+    import ctypes
+    from objgan_hip import _lib
+    ops, tr = _ops(), _tref()
+    g = torch.Generator().manual_seed(77)
+    # (N, Cin, H, W, Cout, k, stride, pad): many pixel splits / split-K head (4x4 map, K = 9216) / narrow map (v1 kernel)
+    for (N, Cin, H, W, Cout, k, s, p) in ((4, 96, 64, 64, 192, 4, 2, 1), (16, 1024, 4, 4, 768, 3, 1, 1),
+                                           (3, 200, 4, 4, 65, 4, 2, 0), (2, 194, 32, 32, 388, 3, 1, 1)):
+        x = torch.randn(N, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+        b = torch.randn(Cout, generator=g)
+        runs = []
+        for _ in range(3):
+            xd, wd, bd = x.to(dev).requires_grad_(), w.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+            yd = ops.conv2d(xd, wd, bd, s, p, "zeros", False, "lrelu")
+            yd.backward(torch.ones_like(yd))
+            torch.cuda.synchronize()
+            runs.append((yd.detach().clone(), xd.grad.clone(), wd.grad.clone()))
+        for a_, b_ in zip(runs[0], runs[1]):
+            assert torch.equal(a_, b_)
+        for a_, b_ in zip(runs[0], runs[2]):
+            assert torch.equal(a_, b_)
+        xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+        yr = tr.conv2d(xr, wr, br, s, p, "zeros", False, "lrelu")
+        yr.backward(torch.ones_like(yr))
+        assert rel_l2(runs[0][0], yr) < TOL and rel_l2(runs[0][1], xr.grad) < TOL and rel_l2(runs[0][2], wr.grad) < TOL
+        # raw entry point: NaN-filled destination, then accumulate = 1 on top of a known tensor
+        OH, OW = yr.shape[2], yr.shape[3]
+        xd, gy = x.to(dev), torch.ones_like(yr).to(dev)
+        gact = torch.where(yr > 0, torch.ones_like(yr), torch.full_like(yr, 0.2)).to(dev).contiguous()
+        geo = (N, Cin, H, W, 0, 0, Cout, OH, OW, k, s, p, ops._MATH["mode"])
+        nws = _lib.load().objgan_conv_wgrad_ws_floats(*geo)
+        ws = torch.full((max(nws, 1),), float("nan"), device=dev)
+        dw = torch.full((Cout, Cin, k, k), float("nan"), device=dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        P = lambda t: ctypes.c_void_p(t.data_ptr())       # noqa: E731
+        _lib.call("objgan_conv_wgrad", P(xd), P(gact), P(dw), *geo, 0, P(ws), nws, st)
+        assert torch.equal(dw, runs[0][2])
+        base = torch.randn(Cout, Cin, k, k, generator=g).to(dev)
+        dw2 = base.clone()
+        _lib.call("objgan_conv_wgrad", P(xd), P(gact), P(dw2), *geo, 1, P(ws), nws, st)
+        torch.cuda.synchronize()
+        assert rel_l2(dw2 - base, runs[0][2]) < 1e-5
+        if nws > 0:                 # a call that needs the workspace and does not get it is refused
+            with pytest.raises(_lib.ObjganHipError):
+                _lib.call("objgan_conv_wgrad", P(xd), P(gact), P(dw2), *geo, 0, None, 0, st)
+
+
 def test_conv_never_consumes_memory_past_the_input_tensor(dev):
     """The gather of the last 16-channel chunk addresses channels past C (their filter entries are
     zero): inside the tensor that hits the next image, past the last image it must be cut off by the

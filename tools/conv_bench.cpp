@@ -76,6 +76,10 @@ int main(int argc, char** argv) {
         if (nwt < (long)(sh.Cout + 1) * 256) nwt = (long)(sh.Cout + 1) * 256;
         CK(hipMalloc(&dx, nx * 4)); CK(hipMalloc(&dw, nw * 4)); CK(hipMalloc(&dy, ny * 4)); CK(hipMalloc(&dg, ny * 4));
         CK(hipMalloc(&dgx, ngx * 4)); CK(hipMalloc(&dgw, nw * 4)); CK(hipMalloc(&wt, nwt * 4));
+        // one scratch buffer large enough for every split-K / weight-gradient workspace of this shape
+        float* wsb;
+        const long nwsb = 96L << 20;      // 384 MB of floats
+        CK(hipMalloc(&wsb, nwsb * 4));
         CK(hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(dw, hw.data(), nw * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(dg, hg.data(), ny * 4, hipMemcpyHostToDevice));
@@ -87,7 +91,7 @@ int main(int argc, char** argv) {
         }
         auto fwd = [&]() {
             int rc = objgan_conv_igemm(dx, dw, nullptr, dy, wt, sh.N, sh.Cin, sh.H, sh.W, sh.up, sh.refl, sh.Cout, sh.Cin, T, 0,
-                                       T, dh.data(), dwv.data(), stp.data(), OH, OW, sh.s, OH, OW, 1, 1, 0, 0, 0, 0, 0, g_math, nullptr, st);
+                                       T, dh.data(), dwv.data(), stp.data(), OH, OW, sh.s, OH, OW, 1, 1, 0, 0, 0, 0, 0, g_math, nullptr, wsb, nwsb, st);
             if (rc != 1) { fprintf(stderr, "fwd rc=%d\n", rc); exit(1); }
         };
         auto dgrad = [&]() {
@@ -96,7 +100,7 @@ int main(int argc, char** argv) {
                 std::vector<int> h2(T), w2(T);
                 for (int kh = 0; kh < sh.k; ++kh) for (int kw = 0; kw < sh.k; ++kw) { h2[kh * sh.k + kw] = pe - kh; w2[kh * sh.k + kw] = pe - kw; }
                 int rc = objgan_conv_igemm(dg, dw, nullptr, dgx, wt, sh.N, sh.Cout, OH, OW, 0, 0, sh.Cout, sh.Cin, T, 1,
-                                           T, h2.data(), w2.data(), stp.data(), TH, TW, 1, TH, TW, 1, 1, 0, 0, 0, 0, 0, g_math, nullptr, st);
+                                           T, h2.data(), w2.data(), stp.data(), TH, TW, 1, TH, TW, 1, 1, 0, 0, 0, 0, 0, g_math, nullptr, wsb, nwsb, st);
                 if (rc != 1) { fprintf(stderr, "dgrad rc=%d\n", rc); exit(1); }
             } else if (sh.k % 2 == 0 && LH % 2 == 0 && sh.Cin > 32) {
                 std::vector<int> h2, w2, s2;
@@ -118,14 +122,14 @@ int main(int argc, char** argv) {
                         }
                     const int PHg = (LH - ph + 1) / 2, PWg = (LW - pw + 1) / 2;
                     int rc = objgan_conv_igemm(dg, dw, nullptr, dgx, wt, sh.N, sh.Cout, OH, OW, 0, 0, sh.Cout, sh.Cin, T, 1,
-                                               (int)h2.size(), h2.data(), w2.data(), s2.data(), PHg, PWg, 1, LH, LW, 2, 2, ph, pw, 0, 1, 0, g_math, nullptr, st);
+                                               (int)h2.size(), h2.data(), w2.data(), s2.data(), PHg, PWg, 1, LH, LW, 2, 2, ph, pw, 0, 1, 0, g_math, nullptr, wsb, nwsb, st);
                     if (rc != 1) { fprintf(stderr, "dgrad2 rc=%d\n", rc); exit(1); }
                 }
             }
         };
         auto wgrad = [&]() {
-            CK(hipMemsetAsync(dgw, 0, nw * 4, st));
-            int rc = objgan_conv_wgrad(dx, dg, dgw, sh.N, sh.Cin, sh.H, sh.W, sh.up, sh.refl, sh.Cout, OH, OW, sh.k, sh.s, sh.p, g_math, st);
+            int rc = objgan_conv_wgrad(dx, dg, dgw, sh.N, sh.Cin, sh.H, sh.W, sh.up, sh.refl, sh.Cout, OH, OW, sh.k, sh.s, sh.p, g_math,
+                                       0, wsb, nwsb, st);
             if (rc != 1) { fprintf(stderr, "wgrad rc=%d\n", rc); exit(1); }
         };
         auto timeit = [&](auto&& fn) {
@@ -211,7 +215,7 @@ int main(int argc, char** argv) {
                maxerr_f / (maxref_f + 1e-30), maxerr_d / (maxref_d + 1e-30), maxerr_w / (maxref_w + 1e-30),
                sqrt(se_f / (sr_f + 1e-300)), sqrt(se_d / (sr_d + 1e-300)), sqrt(se_w / (sr_w + 1e-300)));
         fflush(stdout);
-        hipFree(dx); hipFree(dw); hipFree(dy); hipFree(dg); hipFree(dgx); hipFree(dgw); hipFree(wt);
+        hipFree(dx); hipFree(dw); hipFree(dy); hipFree(dg); hipFree(dgx); hipFree(dgw); hipFree(wt); hipFree(wsb);
     }
     return 0;
 }
