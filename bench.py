@@ -20,8 +20,13 @@ One JSON line is printed by rank 0: the contract fields plus
                 that the headline carries no event overhead), against the fp32 MFMA peak;
                 traffic = HBM bytes per launch from the rocprofv3 --pmc passes kept in profiles/
   cpu_baseline  the CPU oracle (oracle/torch_model.py, a port of the reference path) timed on this host's
-                physical cores at the BASELINE batch (one step at batch 16, ~90 s; `--cpu-baseline-steps K`
-                adds K warmed steps; child process with a hard time limit, batch-8 fallback)
+                physical cores at the BASELINE batch: 1 warm-up + `--cpu-baseline-steps` (default 1) timed steps at
+                batch 16 (~90 s each; child process with a hard time limit, batch-8 fallback).  The unmodified
+                reference cannot run on the GPU box (no /root/reference there): `reference_vs_port` carries the
+                reference-vs-port timing measured in the build container (tools/cpu_ref_vs_port.py)
+  comm          (data-parallel runs) what the gradient exchange moved and what it cost: bytes all-reduced per step,
+                collectives per step, time the compute stream stood still waiting for them, stand-alone all-reduce
+                times of the arena sizes, RCCL version
 """
 import argparse
 import ctypes
@@ -162,15 +167,17 @@ def _cpu_baseline_worker(sample_batch, threads, timed_steps, seed=1234):
     report(dt, "1 warm-up (%.1f s) + %d timed step(s) of %.1f s each" % (warm, timed_steps, dt))
 
 
-def cpu_baseline(sample_batch=16, timed_steps=0, timeout_s=300):
+REF_VS_PORT_JSON = os.path.join(ROOT, "profiles", "r03_cpu_reference_vs_port.json")
+
+
+def cpu_baseline(sample_batch=16, timed_steps=1, timeout_s=410):
     """The oracle timed on the host's physical cores at the BASELINE batch (1 warm-up + timed
     steps), in a child process with a hard time limit so that the default bench run always finishes; if
     the full-batch run does not fit the limit a batch-8 sample is reported instead.  One thread per
     PHYSICAL core: with all 256 hardware threads of the GPU box's two EPYC 9575F the same step did not
     finish in 420 s (fork-join cost of the many small operators), with 128 it takes about 90 s.  Default
-    sample: ONE step at batch 16 (timed_steps = 0: the first, un-warmed step -- a warmed step was measured at
-    88.2 s against 93.2 s for the first, profiles/r02_bench_n1.json -- so that the default bench run stays
-    within a few minutes; `--cpu-baseline-steps K` adds K timed steps after it)."""
+    sample: one warm-up step + ONE timed step at batch 16 (the first step runs ~5 % slower than a warmed one;
+    should the timed step not fit the limit, the un-warmed one is reported and says so)."""
     import subprocess
     threads = max(1, min(128, (os.cpu_count() or 2) // 2))
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads),
@@ -193,6 +200,10 @@ def cpu_baseline(sample_batch=16, timed_steps=0, timeout_s=300):
         if last is not None:          # the timed result when it got that far, else the un-warmed first step
             if note:
                 last["sample"] += " (" + note.strip() + ")"
+            try:                      # reference-vs-port timing from the build container (the reference is not here)
+                last["reference_vs_port"] = json.load(open(REF_VS_PORT_JSON))
+            except (OSError, ValueError):
+                last["reference_vs_port"] = None
             return last
         note += "batch %d: no step finished; " % batch
     return {"value": None, "unit": "images/sec", "cores": threads, "kind": "port", "cpu": _cpu_model(),
@@ -246,12 +257,35 @@ def _rank_device(local_rank):
     return torch.device("cuda", local_rank)
 
 
+def standalone_allreduce(tr, device, barrier, reps=3):
+    """Every rank: stand-alone all-reduce of each network's gradient arena (the sizes the step exchanges), timed on
+    the host between barriers -> {"standalone_allreduce_ms": {network: ms}, "arena_bytes": {network: bytes}}.
+    Next to `exposed_wait_ms_per_step` this says how much of the exchange the step hides."""
+    arenas = [("PatD%d" % i, o.arena) for i, o in enumerate(tr.optimizersPatD)] + \
+             [("ShpD%d" % i, o.arena) for i, o in enumerate(tr.optimizersShpD)]
+    if tr.use_obj:
+        arenas += [("ObjSSD", tr.optimizerObjSSD.arena), ("ObjLSD", tr.optimizerObjLSD.arena)]
+    arenas.append(("G", tr.optimizerG.arena))
+    ms, nbytes = {}, {}
+    for name, arena in arenas:
+        buf = torch.zeros_like(arena.grad)
+        dist.all_reduce(buf)                      # warm-up (connection set-up)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dist.all_reduce(buf)
+        barrier()
+        ms[name] = round(1000.0 * (time.perf_counter() - t0) / reps, 3)
+        nbytes[name] = buf.numel() * buf.element_size()
+    return {"standalone_allreduce_ms": ms, "arena_bytes": nbytes}
+
+
 def timed_passes(step, barrier, max_over_ranks, steps, warmup, prof_steps, prof_begin=None, prof_end=None):
     """The measurement protocol, on EVERY rank alike (a step holds collectives under data parallelism, so no
     pass may run on a subset of the ranks): `warmup` untimed steps; exactly `steps` steps bracketed by
     barrier + device synchronize on both sides, the MAX over ranks of that time; then a second, UNTIMED pass
-    of `prof_steps` steps during which rank 0 brackets every conv launch with hipEvents on its stream
-    (`prof_begin` / `prof_end` are None on the other ranks) -- the headline carries no event overhead.
+    of `prof_steps` steps during which rank 0 brackets every conv launch with hipEvents on its stream and every
+    rank books its collectives (`prof_begin` / `prof_end`) -- the headline carries no event overhead.
     -> (seconds of the timed pass, seconds per step of the profiling pass or None)"""
     for _ in range(warmup):
         step()
@@ -284,8 +318,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 16; 32 with --math bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-steps", type=int, default=0,
-                    help="timed CPU steps after the first one (default 0: report the first step)")
+    ap.add_argument("--cpu-baseline-steps", type=int, default=1,
+                    help="timed CPU steps after the warm-up step (default 1; 0: report the un-warmed first step)")
     ap.add_argument("--no-is-monitor", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--force-ddp", action="store_true",
@@ -350,9 +384,34 @@ def main():
     lib = _lib.load()
     timing = (rank == 0) and not args.no_kernel_timing
     prof_steps = 0 if args.no_kernel_timing else max(1, min(args.steps, 10))
+    def prof_begin():
+        if use_dist:
+            tr.enable_comm_stats(True)              # every rank: the bookkeeping must not change what ranks execute
+        if timing:
+            lib.objgan_prof_enable(1)
+
+    def prof_end():
+        if timing:
+            lib.objgan_prof_enable(0)
     dt, prof_dt = timed_passes(step, barrier, max_over_ranks, args.steps, args.warmup, prof_steps,
-                               (lambda: lib.objgan_prof_enable(1)) if timing else None,
-                               (lambda: lib.objgan_prof_enable(0)) if timing else None)
+                               prof_begin if (timing or use_dist) else None,
+                               prof_end if (timing or use_dist) else None)
+    # host-side cost of a step: with the queue empty, the time the host needs to ISSUE one step (it does not wait for
+    # the device) and the time the device still needs afterwards.  host_issue close to ms_per_step = launch-bound.
+    host = None
+    if not args.no_kernel_timing:
+        barrier()
+        t0 = time.perf_counter()
+        step()
+        t1 = time.perf_counter()
+        barrier()
+        t2 = time.perf_counter()
+        host = {"issue_ms": round(1000.0 * (t1 - t0), 2), "device_drain_ms": round(1000.0 * (t2 - t1), 2)}
+    comm = None
+    if use_dist and prof_steps > 0:
+        comm = tr.comm_summary(prof_steps)
+        tr.enable_comm_stats(False)
+        comm.update(standalone_allreduce(tr, device, barrier))
     if timing and args.shape_table:
         _write_shape_table(lib, args.shape_table, prof_steps)
     if use_dist:
@@ -419,6 +478,16 @@ def main():
                 res["conv_total"] = {"ms_per_step": round(conv_ms, 2), "tflop_per_step": round(conv_fl / 1e12, 3),
                                      "tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
                                      "frac_of_peak": round(conv_fl / (conv_ms * 1e-3) / 1e12 / peak, 4)}
+        if host is not None:
+            res["host_step"] = host
+        if comm is not None:
+            comm["world_size"] = dist.get_world_size()
+            comm["backend"] = dist.get_backend()
+            try:
+                comm["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:                                   # noqa: BLE001 (CPU build / gloo)
+                comm["rccl_version"] = None
+            res["comm"] = comm
         if world == 1 and not args.no_cpu_baseline and args.workload == "stage3_obj":
             res["cpu_baseline"] = cpu_baseline(timed_steps=args.cpu_baseline_steps,
                                                timeout_s=300 + 110 * args.cpu_baseline_steps)

@@ -7,7 +7,8 @@ with nn.DataParallel:
 
 Under a launcher (WORLD_SIZE in the environment) every rank takes GPU LOCAL_RANK, joins the RCCL
 process group and reads its own shard of every epoch (trainDataset.build_loader); `--BATCH_SIZE` is the
-per-GPU batch.  Without `--FLAG` the sampling path runs (evaluator.condGANEvaluator).
+per-GPU batch.  Without `--FLAG` main() stops with a pointer to evaluator.condGANEvaluator.sampling(): the
+reference's test-set loader and its FID / R-precision bookkeeping are outside the hot path.
 """
 from __future__ import print_function
 
@@ -93,11 +94,23 @@ def apply_args(args):
     return cfg
 
 
-def seed_everything(args, rank=0):
+def agree_on_seed(seed, world=1, device=None):
+    """One seed for all ranks: the value rank 0 holds (a seed drawn independently per process would give every rank
+    its own DistributedSampler permutation -- overlapping / missing samples in every epoch)."""
+    if world <= 1 or not dist.is_initialized():
+        return int(seed)
+    dev = device if (device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
+    t = torch.tensor([int(seed)], dtype=torch.int64, device=dev)
+    dist.broadcast(t, src=0)
+    return int(t.item())
+
+
+def seed_everything(args, rank=0, world=1, device=None):
     if not cfg.TRAIN.FLAG:
         args.manualSeed = 100
     elif args.manualSeed is None:
         args.manualSeed = random.randint(1, 10000)
+    args.manualSeed = agree_on_seed(args.manualSeed, world, device)
     # data order / caption sampling / permute_seg differ per rank, the weights do not (rank 0's are broadcast)
     random.seed(args.manualSeed + rank)
     np.random.seed(args.manualSeed + rank)
@@ -143,7 +156,7 @@ def main(argv=None):
     args = parse_args(argv)
     apply_args(args)
     rank, world, device = init_distributed()
-    seed_everything(args, rank)
+    seed_everything(args, rank, world, device)
     if rank == 0:
         print('Using config:')
         pprint.pprint(cfg)
@@ -153,8 +166,6 @@ def main(argv=None):
         algo.train()
         split_dir = 'train'
     else:
-        from evaluator import condGANEvaluator
-        split_dir = 'test'
         raise SystemExit("the evaluation data pipeline (testDataset, FID / R-precision) is outside the hot path: "
                          "use evaluator.condGANEvaluator.sampling() on prepared tensors")
     if rank == 0:

@@ -392,7 +392,40 @@ class condGANTrainer(object):
         if not self.ddp:
             return None
         opt.arena.sync_grads()
+        self._comm_note(opt.arena.grad)
         return dist.all_reduce(opt.arena.grad, op=dist.ReduceOp.SUM, async_op=True)
+
+    # Optional bookkeeping of the gradient exchange (bench.py's `comm` object; off by default): bytes handed to
+    # all-reduce, number of collectives, and -- on the GPU -- events around every stream-side wait for a collective, i.e.
+    # the time the COMPUTE stream stood still for communication.
+    comm = None
+
+    def enable_comm_stats(self, on=True):
+        self.comm = {"bytes": 0, "collectives": 0, "waits": []} if on else None
+
+    def _comm_note(self, t):
+        if self.comm is not None:
+            self.comm["bytes"] += t.numel() * t.element_size()
+            self.comm["collectives"] += 1
+
+    def _wait(self, handle):
+        """handle.wait() = the current stream waits for the collective (the host runs on)."""
+        if self.comm is None or not torch.cuda.is_available() or self.device.type != "cuda":
+            handle.wait()
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        handle.wait()
+        e1.record()
+        self.comm["waits"].append((e0, e1))
+
+    def comm_summary(self, steps):
+        """-> dict (call after a device synchronize): per-step bytes / collectives / exposed wait on the compute stream"""
+        c = self.comm or {"bytes": 0, "collectives": 0, "waits": []}
+        steps = max(1, steps)
+        return {"allreduce_bytes_per_step": c["bytes"] // steps, "collectives_per_step": c["collectives"] / steps,
+                "exposed_wait_ms_per_step": (round(sum(a.elapsed_time(b) for a, b in c["waits"]) / steps, 3)
+                                             if c["waits"] else None)}
 
     # ---- one iteration (reference trainer.py:357-472) -----------------------------------------------
     def train_step(self, batch, noise=None, want_logs=False):
@@ -474,7 +507,7 @@ class condGANTrainer(object):
         # the flag slot was summed by the all-reduce and gates the update on the device (no host read).
         for opt, handle, active in pending:
             if handle is not None:
-                handle.wait()                        # stream-side wait, the host runs on
+                self._wait(handle)                   # stream-side wait, the host runs on
                 opt.step(grad_scale=inv_world, gated=True)
             elif active:
                 opt.step(grad_scale=inv_world)
@@ -497,18 +530,20 @@ class condGANTrainer(object):
         # completes them (stage 3 first), not in one piece after it
         g_arena, handles = self.optimizerG.arena, []
         if self.ddp:
-            g_arena.arm(lambda s0, e0: handles.append(
-                dist.all_reduce(g_arena.grad[s0:e0], op=dist.ReduceOp.SUM, async_op=True)))
+            def reduce_range(s0, e0):
+                self._comm_note(g_arena.grad[s0:e0])
+                handles.append(dist.all_reduce(g_arena.grad[s0:e0], op=dist.ReduceOp.SUM, async_op=True))
+            g_arena.arm(reduce_range)
         errG_total.backward()
         for opt in d_opts:
             opt.arena.set_requires_grad(True)
         if self.ddp:
             during = len(handles)
             for s0, e0 in g_arena.disarm():
-                handles.append(dist.all_reduce(g_arena.grad[s0:e0], op=dist.ReduceOp.SUM, async_op=True))
+                reduce_range(s0, e0)
             self.g_buckets = (during, len(handles) - during)     # issued inside backward / after it
             for h in handles:
-                h.wait()
+                self._wait(h)
         self.optimizerG.step(grad_scale=inv_world)
         ops.ema_update_(self.avg_param_G, self.optimizerG.arena.flat, 0.999)
         out["errG"] = errG_total.detach()

@@ -337,3 +337,53 @@ def test_bench_main_on_two_ranks_prints_one_whole_job_line():
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["config"]["parallelism"] == "dp2"
     assert line["scaling"] == "weak" and "cpu_baseline" not in line
     assert abs(line["value"] - 4 * 1000.0 / line["ms_per_step"]) < 0.05 * line["value"]
+    # the `comm` object of a data-parallel run: what was exchanged per step (stage 1: PatD64 + ShpD64 + G arenas, each
+    # with its flag slot, the generator in buckets), measured in the profiling pass on every rank
+    comm = line["comm"]
+    assert comm["world_size"] == 2 and comm["backend"] == "gloo"
+    nb = comm["arena_bytes"]
+    assert set(nb) == {"PatD0", "ShpD0", "G"} and set(comm["standalone_allreduce_ms"]) == set(nb)
+    assert comm["allreduce_bytes_per_step"] == sum(nb.values()) - 4        # the G buckets leave the flag slot out
+    assert comm["collectives_per_step"] >= 3 and comm["exposed_wait_ms_per_step"] is None    # (no device events on CPU)
+
+
+def _seed_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import argparse
+    import random
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "obj-gan_amd")]
+    import main as cli
+    from miscc.config import cfg
+    from torch.utils.data.distributed import DistributedSampler
+    cfg.TRAIN.FLAG = True
+    random.seed(1000 + 17 * rank)                        # every process would draw its own seed
+    args = argparse.Namespace(manualSeed=None)
+    seed = cli.seed_everything(args, rank, world, None)
+    order = list(DistributedSampler(range(64), num_replicas=world, rank=rank, shuffle=True, seed=seed))
+    q.put((rank, seed, order, random.random()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_without_manual_seed_agree_on_one_seed_and_read_disjoint_shards():
+    """`main.py` without --manualSeed: the seed is drawn on rank 0 and broadcast, so the DistributedSampler of every
+    rank shuffles the SAME permutation and the shards are disjoint and complete; the python / numpy generators still
+    differ per rank (seed + rank: caption sampling, permute_seg)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_seed_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, s0, o0, r0), (_, s1, o1, r1) = res
+    assert s0 == s1
+    assert not (set(o0) & set(o1)) and sorted(o0 + o1) == list(range(64))
+    assert r0 != r1

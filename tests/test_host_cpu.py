@@ -352,7 +352,8 @@ def test_bench_main_end_to_end_on_the_cpu_shim(monkeypatch, capsys):
         cfg.TREE.BRANCH_NUM = saved
     line = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")][-1]
     res = json.loads(line)
-    assert len(steps) == 1 + 1 + 1 and fake.enabled == [1, 0]            # warm-up, timed, profiling pass
+    assert len(steps) == 1 + 1 + 1 + 1 and fake.enabled == [1, 0]        # warm-up, timed, profiling pass, host-issue probe
+    assert res["host_step"]["issue_ms"] > 0
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config"):
         assert k in res
