@@ -396,6 +396,11 @@ def main():
     dt, prof_dt = timed_passes(step, barrier, max_over_ranks, args.steps, args.warmup, prof_steps,
                                prof_begin if (timing or use_dist) else None,
                                prof_end if (timing or use_dist) else None)
+    comm = None
+    if use_dist and prof_steps > 0:
+        comm = tr.comm_summary(prof_steps)
+        tr.enable_comm_stats(False)
+        comm.update(standalone_allreduce(tr, device, barrier))
     # host-side cost of a step: with the queue empty, the time the host needs to ISSUE one step (it does not wait for
     # the device) and the time the device still needs afterwards.  host_issue close to ms_per_step = launch-bound.
     host = None
@@ -407,11 +412,6 @@ def main():
         barrier()
         t2 = time.perf_counter()
         host = {"issue_ms": round(1000.0 * (t1 - t0), 2), "device_drain_ms": round(1000.0 * (t2 - t1), 2)}
-    comm = None
-    if use_dist and prof_steps > 0:
-        comm = tr.comm_summary(prof_steps)
-        tr.enable_comm_stats(False)
-        comm.update(standalone_allreduce(tr, device, barrier))
     if timing and args.shape_table:
         _write_shape_table(lib, args.shape_table, prof_steps)
     if use_dist:
