@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from miscc.config import cfg
-from miscc.utils import permute_seg, permuted_valid_seg, feat_select, take_rows  # noqa: F401
+from miscc.utils import permute_seg, permuted_valid_seg, feat_select, take_rows, h2d  # noqa: F401
 from GlobalAttention import func_attention  # noqa: F401  (API parity)
 from objgan_hip import ops
 
@@ -36,7 +36,7 @@ def _class_mask(class_ids, batch_size, device):
     ids = np.asarray(class_ids)
     m = (ids.reshape(-1, 1) == ids.reshape(1, -1))
     np.fill_diagonal(m, False)
-    return torch.from_numpy(m[:batch_size, :batch_size]).to(device)
+    return h2d(np.ascontiguousarray(m[:batch_size, :batch_size]), device)
 
 
 # ################## Loss for matching text-image ###################
@@ -158,7 +158,7 @@ def shpD_loss(netShpD, real_imgs, fake_imgs, seg_conditions, rois, num_rois):
     errD = _bce(net.UNCOND_DNET(real_features), 1)
     fake_err = _bce(net.UNCOND_DNET(fake_features), 0)
     if len(valid) > 0:
-        wrong_features = netShpD(real_imgs[valid], wrong_seg)
+        wrong_features = netShpD(take_rows(real_imgs, valid), wrong_seg)
         wrong_err = _bce(net.UNCOND_DNET(wrong_features), 0)
         return errD + (fake_err + wrong_err) / 2.
     return errD + fake_err
@@ -168,7 +168,7 @@ def _obj_conditions(class_table, classes, bt_c_codes, count=None):
     """[class embedding | bottom-up context] per selected box."""
     idx = getattr(classes, "_og_dev", None)          # device copy made by feat_select (one upload for all indices)
     if idx is None:
-        idx = classes.to(class_table.device)
+        idx = h2d(classes, class_table.device)
     if count is not None:
         idx = idx[:count]
     emb = class_table[idx]
@@ -189,7 +189,7 @@ def objD_loss(netObjD, real_imgs, fake_imgs, seg_conditions, raw_conditions, raw
     classes2 = []
     if len(valid) > 0:
         rois_v, num_v = take_rows(fm_rois, valid), take_rows(num_rois, valid)      # host copies stay attached
-        pooled2 = netObjD(real_imgs[valid], wrong_seg, rois_v, num_v)
+        pooled2 = netObjD(take_rows(real_imgs, valid), wrong_seg, rois_v, num_v)
         fake_features2, classes2, bt_c_codes2 = feat_select(pooled2, raw_bt_c_codes, rois_v,
                                                             num_v,
                                                             is_large_scale=is_large_scale)

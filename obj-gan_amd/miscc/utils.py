@@ -31,9 +31,28 @@ def attach_host(t_dev, t_cpu):
     return t_dev
 
 
+def h2d(t, device):
+    """Host array / tensor -> device WITHOUT stalling the enqueueing thread.  A plain `.to(device)` of pageable host
+    memory returns only when the copy has executed, i.e. after everything queued in front of it on the stream: every
+    small index upload was a full host-device synchronisation (64 per step, r03 host profile: the host could never
+    run ahead of the GPU).  Staged through a pinned buffer of torch's caching host allocator, the copy is just
+    another stream operation."""
+    if isinstance(t, np.ndarray):
+        t = torch.from_numpy(t)
+    elif not torch.is_tensor(t):
+        t = torch.as_tensor(t)
+    device = torch.device(device)
+    if device.type != "cuda" or t.is_cuda:
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def take_rows(t, rows):
     """t[rows] (rows: python list of sample indices) that keeps the host copy attached."""
-    out = t[rows]
+    if torch.is_tensor(t) and t.is_cuda:         # (indexing with a python list uploads it synchronously)
+        out = t.index_select(0, h2d(np.asarray(rows, np.int64), t.device))
+    else:
+        out = t[rows]
     h = getattr(t, "_og_host", None)
     if h is not None and torch.is_tensor(out) and out.is_cuda:
         out._og_host = h[rows]
@@ -117,7 +136,7 @@ def permute_seg(seg_conditions, rois, num_rois):
     perm, valid_mask = _class_permutations(C, rois, num_rois)
     dev = seg_conditions.device
     rows = torch.arange(B, device=dev).unsqueeze(1)
-    new_seg = seg_conditions[rows, torch.from_numpy(perm).to(dev)]
+    new_seg = seg_conditions[rows, h2d(perm, dev)]
     return new_seg, valid_mask
 
 
@@ -129,8 +148,9 @@ def permuted_valid_seg(seg_conditions, rois, num_rois):
     if not valid_mask:
         return None, valid_mask
     dev = seg_conditions.device
-    rows = torch.as_tensor(valid_mask, dtype=torch.long).unsqueeze(1).to(dev)
-    return seg_conditions[rows, torch.from_numpy(perm[valid_mask]).to(dev)], valid_mask
+    # one upload: [row index | channel map] per changed sample
+    both = h2d(np.concatenate([np.asarray(valid_mask, np.int64)[:, None], perm[valid_mask]], axis=1), dev)
+    return seg_conditions[both[:, :1], both[:, 1:]], valid_mask
 
 
 def feat_select(pooled_feat, raw_bt_c_codes, fm_rois, num_rois, is_large_scale=False):
@@ -161,12 +181,15 @@ def feat_select(pooled_feat, raw_bt_c_codes, fm_rois, num_rois, is_large_scale=F
     dev = pooled_feat.device
     cls = np.concatenate(classes).astype(np.int64)
     # one upload for the three index vectors (every small host->device copy stalls the enqueueing thread)
-    idx = torch.from_numpy(np.stack([np.asarray(sel_b, np.int64), np.asarray(sel_r, np.int64), cls])).to(dev)
+    idx = h2d(np.stack([np.asarray(sel_b, np.int64), np.asarray(sel_r, np.int64), cls]), dev)
     ib, ir = idx[0], idx[1]
     x_code_rois = pooled_feat[ib, ir]
     # NB reference quirk (SURVEY.md trap 6): raw_bt_c_codes is indexed with the batch index of the
     # tensors passed in, also when those are a `valid_mask` subset of the batch.
-    bt_c_codes = raw_bt_c_codes[ib.to(raw_bt_c_codes.device), ir.to(raw_bt_c_codes.device)]
+    if raw_bt_c_codes.device == dev:
+        bt_c_codes = raw_bt_c_codes[ib, ir]
+    else:
+        bt_c_codes = raw_bt_c_codes[ib.to(raw_bt_c_codes.device), ir.to(raw_bt_c_codes.device)]
     classes = torch.from_numpy(cls)
     if dev.type != "cpu":
         classes._og_dev = idx[2]
@@ -185,7 +208,7 @@ def form_clabels_feat(clabels_emb, rois, num_rois):
         n = int(nr[i])
         if n:
             idx[i, :n] = rois_np[i, :n, 4].astype(np.int64)
-    idx_dev = torch.from_numpy(idx).to(clabels_emb.device)
+    idx_dev = h2d(idx, clabels_emb.device)
     feat = clabels_emb[idx_dev.clamp(min=0)] * (idx_dev >= 0).unsqueeze(2).to(clabels_emb.dtype)
     return feat.transpose(1, 2).unsqueeze(3)
 

@@ -498,7 +498,7 @@ class condGANTrainer(object):
             active = torch.is_tensor(err)
             if active:
                 err.backward()
-                opt.arena.grad[-1] = 1.0             # "this rank has a gradient" flag
+                opt.arena.grad[-1:].fill_(1.0)       # "this rank has a gradient" flag
                 out[name] = err.detach()
             pending.append((opt, self._reduce_async(opt), active))
 
