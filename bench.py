@@ -329,6 +329,8 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="stage3_obj",
                     help="stage3_obj: the configuration BASELINE's metric is quoted on (default); stage3 / stage1: "
                          "BASELINE configs 3 and 2 (parity-test cases; their lines are side records, not the metric)")
+    ap.add_argument("--d-streams", type=int, default=None,
+                    help="HIP streams the eight discriminator updates are spread over (default: the trainer's)")
     ap.add_argument("--math", choices=("fp32", "bf16x3", "bf16"), default="bf16x3",
                     help="fp32: fp32 operands on the fp32 MFMA; bf16x3: fp32 operands split exactly three ways on the "
                          "bf16 MFMA, six partial products, fp32 accumulation (fp32 results); bf16: mixed precision of "
@@ -356,6 +358,8 @@ def main():
     ops.set_conv_math(args.math)
     tr = build_trainer(device, args.batch, seed=1234, with_is_monitor=not args.no_is_monitor,
                        workload=args.workload)
+    if args.d_streams is not None:
+        tr.d_streams = args.d_streams
     branch_num, _, workload_name = WORKLOADS[args.workload]
     side = 64 << (branch_num - 1)
     # a new minibatch every step, like training: four distinct per-rank batches in rotation (the trainer
@@ -429,7 +433,7 @@ def main():
             "config": {"workload": workload_name + ("" if args.no_is_monitor else "+IS-monitor"),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": "dp%d" % world + (" (RCCL path forced)" if args.force_ddp and world == 1 else ""),
-                       "fresh_batch_every_step": True,
+                       "fresh_batch_every_step": True, "d_streams": int(tr.d_streams),
                        "conv_math": {"fp32": "fp32 operands on the fp32 MFMA (v_mfma_f32_32x32x2_f32)",
                                      "bf16x3": "fp32 operands split exactly into 3 bf16 pieces each, 6 partial products "
                                                "on v_mfma_f32_32x32x16_bf16, fp32 accumulation: fp32 results (error vs "
