@@ -55,10 +55,12 @@ def cat_names(math):
     """rocprofv3's names of the kernel instances behind the library's timing categories (leading template
     arguments: tile height, LDS-free form / arithmetic)."""
     m = MATH_IDS[math]
-    return (["conv_igemm3_kernel<%d, false, %d>" % (tm, m) for tm in range(1, 8)] +
+    return (["conv_igemm3_kernel<%d, false, %d, 4>" % (tm, m) for tm in range(1, 8)] +
             ["conv_wgrad2_kernel<%d, %d" % (tm, m) for tm in range(1, 8)] +
             ["conv_thin_kernel", "conv_thin3x3_kernel", "conv_igemm_kernel", "conv_wgrad_kernel",
-             "conv_igemm3_kernel<1, true, %d>" % m] + ["conv_wgrad3_kernel<%d, %d" % (tm, m) for tm in range(1, 8)])
+             "conv_igemm3_kernel<1, true, %d, 4>" % m] + ["conv_wgrad3_kernel<%d, %d" % (tm, m) for tm in range(1, 8)] +
+            ["conv_igemm3_kernel<%d, false, %d, 8>" % (tm, m) for tm in range(1, 8)] +
+            ["conv_wgrad3_kernel<%d, %d, *, 0, 8>" % (tm, m) for tm in range(1, 8)])
 PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
@@ -441,9 +443,9 @@ def main():
                                      "bf16": "operands rounded to bf16, fp32 accumulation"}[args.math]},
         }
         if timing:
-            ms = (ctypes.c_double * 32)()
-            fl = (ctypes.c_double * 32)()
-            cnt = (ctypes.c_long * 32)()
+            ms = (ctypes.c_double * 48)()
+            fl = (ctypes.c_double * 48)()
+            cnt = (ctypes.c_long * 48)()
             lib.objgan_prof_collect(ms, fl, cnt)
             CAT_NAMES = cat_names(args.math)
             cats = [(CAT_NAMES[i], ms[i], fl[i], cnt[i]) for i in range(len(CAT_NAMES)) if cnt[i] > 0]
@@ -455,9 +457,7 @@ def main():
                 if os.path.exists(PMC_TRAFFIC_JSON):
                     try:
                         kern = json.load(open(PMC_TRAFFIC_JSON)).get("kernels", {})
-                        # the profiler prints every template argument, the category names only the
-                        # leading ones: "conv_igemm3_kernel<6, false>" is "...<6, false, false>" (fp32)
-                        ent = kern.get(name) or kern.get(name[:-1] + ", false>" if name.endswith(">") else name)
+                        ent = kern.get(name)
                         traffic = ent["hbm_bytes_per_launch"] if ent else None
                     except (ValueError, KeyError, OSError):
                         traffic = None
@@ -465,7 +465,7 @@ def main():
                         "bf16x3": round(BF16X3_PEAK_TFLOPS, 1)}[args.math]
                 res["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2),
                                    "peak": peak, "unit": "TFLOP/s",
-                                   "frac": round(ach / peak, 4), "traffic": traffic if args.math == "fp32" else None,
+                                   "frac": round(ach / peak, 4), "traffic": traffic,
                                    "algorithmic_gflop_per_launch": round(tfl / n / 1e9, 2),
                                    "launches": int(n), "avg_launch_ms": round(tms / n, 4),
                                    "share_of_step": round(tms / prof_steps / (1000.0 * prof_dt), 4),

@@ -243,7 +243,7 @@ int objgan_resize_pil_rgb8(const unsigned char* src, const long* offs, const int
 
 /* ---- measurement aid (bench.py roofline leg): hipEvent-bracketed conv launches ------------------ */
 int objgan_prof_enable(int on);
-int objgan_prof_collect(double* ms, double* flops, long* count);   /* arrays of 32 categories */
+int objgan_prof_collect(double* ms, double* flops, long* count);   /* arrays of 48 categories */
 /* per-launch records of the current window (call before objgan_prof_collect, which resets it):
  * meta[10*i..] = {kind 0 GEMM / 1 weight gradient / 2 thin, tile height, rows, K channels, taps, images,
  * pixel-grid rows, pixel-grid columns, stride (negative: strided output phases), K splits} */

@@ -2068,7 +2068,7 @@ __global__ __launch_bounds__(256) void reflect_ring_fold_kernel(const float* __r
 // When enabled, every conv launch is bracketed by hipEvents on its own stream and tagged with a
 // category (kind, taps / ksize, tile config) and its ALGORITHMIC flops 2*M*K*Npix.  Off by default;
 // the only mutable global state of the library, touched by the host thread only.
-#define OG_PROF_CATS 32
+#define OG_PROF_CATS 48
 #define OG_PROF_MAX 65536
 // meta: {kind (0 forward / data-gradient GEMM, 1 weight gradient, 2 thin VALU), tile height TM, rows M,
 //        K channels C, taps T, images N, pixel-grid rows, pixel-grid columns, stride, grid.y splits}
@@ -2083,6 +2083,8 @@ static int g_prof_made = 0;
 //   14 conv_thin_kernel<*>   15 conv_thin3x3_kernel<*>   16 conv_igemm_kernel<*> (v1)   17 conv_wgrad_kernel<*> (v1)
 //   18 conv_igemm3_kernel<1, true> (LDS-free form for thin outputs)   19..25 conv_wgrad3_kernel<1..7>
 #define OG_CAT_IGEMM2(tm) (((tm) == 1 && a.M <= 32) ? 18 : ((tm) - 1))
+#define OG_CAT_IGEMM2_NW8(tm) (25 + (tm))          // 26..32: conv_igemm3_kernel<1..7, false, 2, 8>
+#define OG_CAT_WGRAD3_NW8(tm) (32 + (tm))          // 33..39: conv_wgrad3_kernel<1..7, 2, *, 0, 8>
 #define OG_CAT_WGRAD2(tm) (6 + (tm))
 #define OG_CAT_WGRAD3(tm) (18 + (tm))
 #define OG_CAT_THIN 14
@@ -2414,7 +2416,7 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed, float* ws, lo
     int rc = OG_OK;
     if (full_rows > 0) {
         a.m_begin = 0; a.m_end = min(a.M, full_rows * TM * 32);
-        ProfRec* pr = prof_begin(OG_CAT_IGEMM2(TM),
+        ProfRec* pr = prof_begin(nw == 8 ? OG_CAT_IGEMM2_NW8(TM) : OG_CAT_IGEMM2(TM),
                                  2.0 * (a.m_end - a.m_begin) * (double)a.K * (double)Npix * nph, s);
         prof_meta(pr, 0, TM, a.m_end - a.m_begin, a.C, a.T, a.N, a.PH * nph, a.PW, a.stride * (a.osh > 1 ? -1 : 1), splits);
         rc = launch_igemm2(a, TM, dim3(full_rows * tiles_n, splits, nph), s, nw);
@@ -2423,7 +2425,7 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed, float* ws, lo
     }
     if (rest > 0) {
         a.m_begin = full_rows * TM * 32; a.m_end = a.M;
-        ProfRec* pr = prof_begin(OG_CAT_IGEMM2(rest),
+        ProfRec* pr = prof_begin(nw == 8 ? OG_CAT_IGEMM2_NW8(rest) : OG_CAT_IGEMM2(rest),
                                  2.0 * (a.m_end - a.m_begin) * (double)a.K * (double)Npix * nph, s);
         prof_meta(pr, 0, rest, a.m_end - a.m_begin, a.C, a.T, a.N, a.PH * nph, a.PW, a.stride * (a.osh > 1 ? -1 : 1), splits);
         rc = launch_igemm2(a, rest, dim3(tiles_n, splits, nph), s, nw);
@@ -2824,7 +2826,7 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
             if (og_trace())
                 fprintf(stderr, "OGTRACE wgrad TM=%d NW=%d form=%d Cout=%d Cin=%d k=%d N=%d OH=%d OW=%d stride=%d grid=%u,%u math=%d\n", tm, nw,
                         use3 ? 3 : 2, Cout, Cin, ksize, N, OH, OW, stride, grid.x, grid.y, math);
-            ProfRec* pr = prof_begin(use3 ? OG_CAT_WGRAD3(tm) : OG_CAT_WGRAD2(tm),
+            ProfRec* pr = prof_begin(use3 ? (nw == 8 ? OG_CAT_WGRAD3_NW8(tm) : OG_CAT_WGRAD3(tm)) : OG_CAT_WGRAD2(tm),
                                      2.0 * (a.m_end - a.m_begin + a.xr_count) * (double)a.ncol * (double)Npix, s);
             prof_meta(pr, 1, tm, a.m_end - a.m_begin + a.xr_count, Cin, ksize * ksize, N, OH, OW,
                       stride * (upsample ? 10 : 1) * (pad_mode ? -1 : 1), splits);
