@@ -390,15 +390,21 @@ def main():
     lib = _lib.load()
     timing = (rank == 0) and not args.no_kernel_timing
     prof_steps = 0 if args.no_kernel_timing else max(1, min(args.steps, 10))
+    timed_streams = int(tr.d_streams)
+
     def prof_begin():
         if use_dist:
             tr.enable_comm_stats(True)              # every rank: the bookkeeping must not change what ranks execute
+        # per-kernel durations are those of a kernel ALONE on the device: the profiling pass runs on one stream
+        # (in the timed pass kernels of different streams overlap and stretch each other)
+        tr.d_streams = 1
         if timing:
             lib.objgan_prof_enable(1)
 
     def prof_end():
         if timing:
             lib.objgan_prof_enable(0)
+        tr.d_streams = timed_streams
     dt, prof_dt = timed_passes(step, barrier, max_over_ranks, args.steps, args.warmup, prof_steps,
                                prof_begin if (timing or use_dist) else None,
                                prof_end if (timing or use_dist) else None)
@@ -433,9 +439,10 @@ def main():
             "dtype": "fp32" if args.math != "bf16" else "bf16-in/fp32-acc (mixed precision, config 5)",
             "data": "synthetic",
             "config": {"workload": workload_name + ("" if args.no_is_monitor else "+IS-monitor"),
+                       "d_streams_timed_pass": timed_streams,
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": "dp%d" % world + (" (RCCL path forced)" if args.force_ddp and world == 1 else ""),
-                       "fresh_batch_every_step": True, "d_streams": int(tr.d_streams),
+                       "fresh_batch_every_step": True,
                        "conv_math": {"fp32": "fp32 operands on the fp32 MFMA (v_mfma_f32_32x32x2_f32)",
                                      "bf16x3": "fp32 operands split exactly into 3 bf16 pieces each, 6 partial products "
                                                "on v_mfma_f32_32x32x16_bf16, fp32 accumulation: fp32 results (error vs "
@@ -469,9 +476,14 @@ def main():
                                    "algorithmic_gflop_per_launch": round(tfl / n / 1e9, 2),
                                    "launches": int(n), "avg_launch_ms": round(tms / n, 4),
                                    "share_of_step": round(tms / prof_steps / (1000.0 * prof_dt), 4),
-                                   "measured_in": "second pass of %d steps with hipEvents around every conv launch "
-                                                  "(%.1f ms/step; the timed pass above runs without them)"
-                                                  % (prof_steps, 1000.0 * prof_dt)}
+                                   "measured_in": "second pass of %d steps ON ONE STREAM with hipEvents around every conv "
+                                                  "launch (%.1f ms/step; the timed pass above runs without them and "
+                                                  "on %d streams)" % (prof_steps, 1000.0 * prof_dt, timed_streams),
+                                   "peak_note": ({"bf16x3": "2500 TFLOP/s dense bf16 MFMA / 6 products per fp32 MAC; an "
+                                                            "MFMA-only ablation of this loop (no loads, no LDS, no "
+                                                            "barriers) runs at 211-229 TFLOP/s on random data: "
+                                                            "profiles/r03_ablation_bf16x3_mainloop.txt"}
+                                                 .get(args.math))}
                 res["kernel_breakdown"] = [
                     {"kernel": c[0], "ms_per_step": round(c[1] / prof_steps, 3),
                      "tflops": round(c[2] / (c[1] * 1e-3) / 1e12, 2),
