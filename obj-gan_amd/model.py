@@ -649,7 +649,8 @@ def Block3x3_leakRelu(in_planes, out_planes):
 class _Encoder(nn.Sequential):
     """[conv4x4 s2, LReLU, (conv4x4 s2, BN, LReLU) x (n-1)]: spatial size / 2^n."""
 
-    def forward(self, x):
+    def forward(self, x, x2=None):
+        """x2: second part of the input (channels behind x's): conv(cat([x, x2])) with per-part data gradients"""
         mods = list(self)
         i = 0
         while i < len(mods):
@@ -658,6 +659,10 @@ class _Encoder(nn.Sequential):
                 y = ops.conv2d(x, conv.weight, None, 2, 1, "zeros")
                 x = _bn_act(y, mods[i + 1], "lrelu")
                 i += 3
+            elif x2 is not None:
+                x = ops.conv2d_cat(x, x2, conv.weight, 2, 1, act="lrelu")
+                x2 = None
+                i += 2
             else:
                 x = ops.conv2d(x, conv.weight, None, 2, 1, "zeros", act="lrelu")
                 i += 2
@@ -752,7 +757,7 @@ class _ShpD(nn.Module):
     def forward(self, x_var, s_var, s_code=None):
         if s_code is None:
             s_code = self.shp_code(s_var)
-        return self.img_code(torch.cat([x_var, s_code], dim=1))
+        return self.img_code(x_var, s_code)
 
 
 class SHP_D_NET64(_ShpD):
@@ -818,7 +823,7 @@ class _ObjD(nn.Module):
         x_var = ops.bilinear_resize(x_var, img_size, img_size)
         if s_code is None:
             s_code = self.encode_seg(s_var, img_size)
-        x_code = self.img_code(torch.cat([x_var, s_code], dim=1))
+        x_code = self.img_code(x_var, s_code)
         batch_size = fm_rois.shape[0]
         rois = _rois_blob(fm_rois, cfg.ROI.BOXES_NUM)
         pooled = self.roi_code(self.RoIAlignAvg(x_code, rois))

@@ -163,12 +163,12 @@ def _job_blob():
 
 
 def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, transpose,
-           dh, dw, src_tap, PH, PW, stride, OHf, OWf, osh, osw, ooh, oow, act, y_prezeroed=0, ring=None):
+           dh, dw, src_tap, PH, PW, stride, OHf, OWf, osh, osw, ooh, oow, act, y_prezeroed=0, ring=None, cache=True):
     Tg = len(dh)
     M = Cin if transpose else Cout
     # the library picks the kernel -- hence the bank layout -- from sizes, taps and math: ask it
     layout = _lib.load().objgan_conv_bank_layout(N, C, H, W, M, Tg, PH, PW, act, _MATH["mode"])
-    key = _pack_key(w, transpose, src_tap, layout)
+    key = _pack_key(w, transpose, src_tap, layout) if cache else None      # (temporaries: pack per call, keep nothing)
     nfl = _lib.load().objgan_conv_packed_floats(int(M), int(C), int(Tg))
     if key is not None:
         ent, fresh = _bank_lookup(key, w, nfl, x.device)
@@ -302,7 +302,7 @@ def _conv_dgrad(g, w, N, Cin, H, W, stride, pad, refl, upsample, cacheable=True)
                 if not st:      # no tap reaches this phase: gradient is zero there
                     dh, dw, st = [0], [0], [-1]
                 _igemm(g, w, None, dxl, N, Cout, OH, OW, 0, 0, Cout, Cin, k * k, 1,
-                       dh, dw, st, PHg, PWg, 1, LH, LW, 2, 2, ph, pw, 0, y_prezeroed=1)
+                       dh, dw, st, PHg, PWg, 1, LH, LW, 2, 2, ph, pw, 0, y_prezeroed=1, cache=cacheable)
     else:
         raise _lib.ObjganHipError("conv2d backward: stride %d not supported" % stride)
     if upsample:
@@ -460,6 +460,56 @@ class _UpConv3x3Fn(torch.autograd.Function):
             A = _up_matrix(x.device)
             dw_ = torch.einsum("pk,cmpq,ql->mckl", A, dW4, A).contiguous()
         return dx, dw_
+
+
+class _Conv2dCatFn(torch.autograd.Function):
+    """conv2d(cat([x1, x2], 1), w) with per-input data gradients: the first convolution of the shape / object
+    discriminators sees [image (3) | encoded layout (12)] (reference model.py:1121-1128, 1217-1220).  A discriminator
+    step needs only the layout part's gradient, a generator step only the image part's -- each is the data gradient
+    of a slice of the filter bank (12 resp. 3 of the 15 input channels), not of the whole bank."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w, stride, pad, act):
+        _chk(x1, x2, w)
+        x = torch.cat([x1, x2], dim=1)
+        w = _c(w)
+        if w.shape[1] != x.shape[1] or w.shape[2] != w.shape[3]:
+            raise _lib.ObjganHipError("conv2d_cat: bad weight shape %s for inputs %s + %s"
+                                      % (tuple(w.shape), tuple(x1.shape), tuple(x2.shape)))
+        y = _conv_fwd(x, w, None, stride, pad, 0, False, act)
+        ctx.cfg = (stride, pad, act, w.shape[2], x1.shape[1])
+        ctx.save_for_backward(x, w, y if act not in (None, "none") else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, act, k, c1 = ctx.cfg
+        N, C, H, W = x.shape
+        dy = _c(dy)
+        _chk(dy)
+        if act not in (None, "none"):
+            g = torch.empty_like(dy)
+            _lib.call("objgan_act_backward", _p(dy), _p(y), _p(g), dy.numel(), _ACT[act], _stream())
+        else:
+            g = dy
+        n1, n2, nw = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        dx1 = dx2 = dw_ = None
+        if n1 and n2:
+            dx = _conv_dgrad(g, w, N, C, H, W, stride, pad, 0, False)
+            dx1, dx2 = dx[:, :c1], dx[:, c1:]
+        elif n1:
+            dx1 = _conv_dgrad(g, w[:, :c1].contiguous(), N, c1, H, W, stride, pad, 0, False, cacheable=False)
+        elif n2:
+            dx2 = _conv_dgrad(g, w[:, c1:].contiguous(), N, C - c1, H, W, stride, pad, 0, False, cacheable=False)
+        if nw:
+            dw_ = _conv_wgrad(x, g, w.shape[0], k, stride, pad, 0, False)
+        return dx1, dx2, dw_, None, None, None
+
+
+def conv2d_cat(x1, x2, w, stride=1, pad=0, act=None):
+    """act(conv2d(cat([x1, x2], 1), w)) (zero padding, no bias) with per-input data gradients."""
+    return _Conv2dCatFn.apply(x1, x2, w, stride, pad, act)
 
 
 def conv2d(x, w, bias=None, stride=1, pad=0, pad_mode="zeros", upsample=False, act=None):

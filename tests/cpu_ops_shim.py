@@ -29,6 +29,10 @@ def _act(y, act):
     return torch.tanh(y) if act == "tanh" else torch.sigmoid(y)
 
 
+def conv2d_cat(x1, x2, w, stride=1, pad=0, act=None):
+    return tr.conv2d(torch.cat([x1, x2], dim=1), w, None, stride, pad, "zeros", False, act)
+
+
 def conv2d_frozen(x, w, bias=None, stride=1, pad=(0, 0), act=None):
     return _act(F.conv2d(x, w, bias, stride, pad), act)
 
@@ -158,7 +162,7 @@ def get_conv_math():
     return "fp32"
 
 
-API = ("conv2d", "conv2d_frozen", "linear", "norm_act", "norm_act_eval", "attn_general", "attn_bu", "masked_max",
+API = ("conv2d", "conv2d_cat", "conv2d_frozen", "linear", "norm_act", "norm_act_eval", "attn_general", "attn_bu", "masked_max",
        "softmax_strided", "roi_align", "avgpool2s1", "bilinear_resize", "lstm_bidir_forward", "adam_step_",
        "adam_step_gated_", "ema_update_", "max_pool2d", "avg_pool2d", "lift_stem_conv", "bmm", "repack_arena", "bce_const",
        "resize_pil_bilinear")

@@ -767,6 +767,30 @@ def test_bf16x3_math_is_as_accurate_as_the_fp32_mfma(dev, case):
         assert ex3 <= 1.25 * e32 + 2e-8, (what, "fp32", e32, "bf16x3", ex3)
 
 
+@pytest.mark.parametrize("need", [(True, True), (True, False), (False, True)])
+def test_conv2d_cat_gives_per_input_gradients(dev, need):
+    """conv2d_cat(x1, x2, w) = lrelu(conv(cat([x1, x2]), w)) (first layer of the shape / object discriminators): the
+    data gradient is computed per input from a slice of the filter bank, and only for the inputs that need it."""
+    ops, tr = _ops(), _tref()
+    g = torch.Generator().manual_seed(31)
+    x1, x2 = torch.randn(2, 3, 384, 384, generator=g), torch.randn(2, 12, 384, 384, generator=g)
+    w = torch.randn(40, 15, 4, 4, generator=g) / (15 * 16) ** 0.5
+    r1, r2, rw = x1.clone().requires_grad_(need[0]), x2.clone().requires_grad_(need[1]), w.clone().requires_grad_()
+    yr = tr.conv2d(torch.cat([r1, r2], 1), rw, None, 2, 1, "zeros", False, "lrelu")
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    d1, d2, dw = x1.to(dev).requires_grad_(need[0]), x2.to(dev).requires_grad_(need[1]), w.to(dev).requires_grad_()
+    yd = ops.conv2d_cat(d1, d2, dw, 2, 1, act="lrelu")
+    yd.backward(gy.to(dev))
+    torch.cuda.synchronize()
+    assert rel_l2(yd, yr) < TOL and rel_l2(dw.grad, rw.grad) < TOL
+    for dd, rr, n in ((d1, r1, need[0]), (d2, r2, need[1])):
+        if n:
+            assert rel_l2(dd.grad, rr.grad) < TOL
+        else:
+            assert dd.grad is None
+
+
 def test_conv_reductions_are_bit_reproducible(dev, fp32_math):
     """Split reductions go through a workspace and are summed in split order (no fp32 atomics): the weight gradient
     (pixels split across workgroups) and split-K outputs (small grids, long K) are bit-identical from run to run, the
