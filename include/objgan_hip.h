@@ -22,8 +22,10 @@
  *   - the library never allocates, frees or retains memory; the caller owns every buffer,
  *     including scratch / workspace buffers named in the signatures;
  *   - all tensors are contiguous fp32, NCHW, device memory;
- *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant,
- *     and keeps no global state;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant, reads no environment
+ *     variable (development builds, -DOG_DEV, do) and keeps no global state -- with one opt-in exception: the
+ *     measurement window of objgan_prof_enable / _collect / _dump (a host-side table of hipEvents, off by default,
+ *     touched by the calling thread only);
  *   - return value: 1 = launched, 0 = argument error (the reference returns 0 when
  *     rois.size(1) != 5), < 0 = -(hipError_t) of a failed launch (the reference calls exit(-1)).
  */
