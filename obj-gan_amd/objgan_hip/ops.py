@@ -108,7 +108,7 @@ def invalidate_packed():
 
 def _pack_key(w, transpose, src_tap, big):
     ep = getattr(w, "_og_epoch", None)
-    if ep is None and w.requires_grad:
+    if (ep is None and w.requires_grad) or getattr(w, "_og_nocache", False):
         return None
     return (w.data_ptr(), tuple(w.shape), int(transpose), tuple(src_tap), big, _MATH["mode"])
 
@@ -122,6 +122,17 @@ def _bank_lookup(key, w, nfloats, device):
     """-> (_Bank, fresh): the cached bank of this key (created on first use) and whether its contents
     match the weight's current version / epoch."""
     ent = _PACK_CACHE.get(key)
+    if ent is not None and ent.w is not w:
+        # a fresh VIEW of the same arena parameter (ops.linear reshapes its weight on every call): same address, same
+        # shape (both in the key), same epoch cell -> the same bank; anything else at that address is a new tensor
+        cell = getattr(w, "_og_epoch", None)
+        if cell is not None and cell is getattr(ent.w, "_og_epoch", None):
+            ent.w = w
+        elif (cell is None and getattr(ent.w, "_og_epoch", None) is None and not w.requires_grad
+              and ent.w.untyped_storage().data_ptr() == w.untyped_storage().data_ptr()):
+            # an alias of the cached frozen weight (`.detach()`, a re-made view): the entry keeps that storage alive,
+            # so the same address is the same memory; in-place edits show in the shared version counter
+            ent.w = w
     if ent is None or ent.w is not w:
         if len(_PACK_CACHE) >= _PACK_CACHE_MAX:
             invalidate_packed()
@@ -594,8 +605,11 @@ def conv2d_frozen(x, w, bias=None, stride=1, pad=(0, 0), act=None):
 
 def linear(x, w, bias=None, act=None):
     """nn.Linear as a 1x1 convolution over a [N, C, 1, 1] view (reference model.py:462, 494)."""
-    y = conv2d(x.reshape(x.shape[0], x.shape[1], 1, 1), w.reshape(w.shape[0], w.shape[1], 1, 1),
-               bias, 1, 0, "zeros", False, act)
+    w4 = w.reshape(w.shape[0], w.shape[1], 1, 1)
+    cell = getattr(w, "_og_epoch", None)
+    if cell is not None and w4 is not w:
+        w4._og_epoch = cell                  # the view stands for the arena parameter: its packed bank stays cached
+    y = conv2d(x.reshape(x.shape[0], x.shape[1], 1, 1), w4, bias, 1, 0, "zeros", False, act)
     return y.reshape(x.shape[0], w.shape[0])
 
 
@@ -1150,8 +1164,9 @@ def lift_stem_conv(seg, w, bias, size):
     Mo, C = w.shape[0], w.shape[1]
     if w.shape[2] != 3 or w.shape[3] != 3:
         raise _lib.ObjganHipError("lift_stem_conv: 3x3 filter bank expected")
-    w9 = w.permute(2, 3, 0, 1).reshape(9 * Mo, C, 1, 1)          # row (dh*3 + dw)*Mo + co
-    z = conv2d(seg, w9.contiguous())
+    w9 = w.permute(2, 3, 0, 1).reshape(9 * Mo, C, 1, 1).contiguous()          # row (dh*3 + dw)*Mo + co
+    w9._og_nocache = True        # a per-call temporary: caching its bank would pin one dead entry per call
+    z = conv2d(seg, w9)
     return _LiftTapsFn.apply(z, bias, int(size), int(size))
 
 

@@ -1009,3 +1009,41 @@ def test_images_resized_on_the_device_equal_pillow_bit_for_bit(dev):
     assert torch.equal(ramp[0, 0], torch.arange(256, dtype=torch.float32).div(255).sub(0.5).div(0.5))
     with pytest.raises(Exception):
         ops.resize_pil_bilinear([torch.zeros(4, 4, dtype=torch.uint8)], [64], dev)
+
+
+def test_bank_cache_serves_views_and_aliases_without_repacking(dev):
+    """The packed-bank cache is keyed on the weight's address; a fresh VIEW of an arena parameter (ops.linear reshapes
+    its weight on every call) or a `.detach()` alias of a frozen weight must find the cached bank (r02: ~170 single-bank
+    re-pack launches per step), and a per-call temporary (lift_stem_conv's re-ordered bank) must not be cached at all."""
+    import trainer as T
+    ops = _ops()
+    ops.invalidate_packed()
+    g = torch.Generator().manual_seed(3)
+    lin = torch.nn.Linear(200, 96, bias=False).to(dev)
+    arena = T.ParamArena(lin)
+    x = torch.randn(4, 200, generator=g).to(dev)
+    want = x @ lin.weight.detach().t()
+    n0 = len(ops._PACK_CACHE)
+    for _ in range(3):
+        y = ops.linear(x, lin.weight)
+    assert len(ops._PACK_CACHE) == n0 + 1 and rel_l2(y, want) < TOL
+    ent = [e for e in ops._PACK_CACHE.values()][-1]
+    v0 = ent.epoch
+    arena.epoch[0] += 1                                   # an optimizer step: the bank is stale, re-packed in place
+    lin.weight.data.mul_(2.0)
+    y2 = ops.linear(x, lin.weight)
+    assert len(ops._PACK_CACHE) == n0 + 1 and ent.epoch != v0 and rel_l2(y2, 2.0 * want) < TOL
+    # frozen weight and its detached alias share one entry
+    wf = torch.randn(64, 40, 3, 3, generator=g).to(dev)
+    xf = torch.randn(2, 40, 8, 8, generator=g).to(dev)
+    n1 = len(ops._PACK_CACHE)
+    ya = ops.conv2d_frozen(xf, wf, None, 1, (1, 1))
+    yb = ops.conv2d_frozen(xf, wf.detach(), None, 1, (1, 1))
+    assert len(ops._PACK_CACHE) == n1 + 1 and torch.equal(ya, yb)
+    # lift_stem_conv with a frozen bank: nothing is added per call
+    seg = torch.rand(2, 8, 16, 16, generator=g).to(dev)
+    w3 = torch.randn(12, 8, 3, 3, generator=g).to(dev)
+    n2 = len(ops._PACK_CACHE)
+    for _ in range(3):
+        ops.lift_stem_conv(seg, w3, None, 32)
+    assert len(ops._PACK_CACHE) == n2
