@@ -122,6 +122,10 @@ int objgan_lstm_bidir_forward(const float* table, const long* captions, const in
                               void* stream);
 
 /* ---- normalisation + GLU / LeakyReLU / residual (BatchNorm train mode, InstanceNorm) -------- */
+/* `sums` (forward) / `bsums` (backward): statistics workspace of objgan_norm_ws_floats(N, C, HW, per_channel) floats
+ * (host-only query): the per-workgroup partial sums of a group are combined in slot order by the last workgroup to
+ * arrive -- bit-reproducible statistics, no fp32 atomics; the totals are the first 2G floats. */
+long objgan_norm_ws_floats(int N, int C, int HW, int per_channel);
 int objgan_norm_forward(const float* x, float* y, const float* residual,
                         const float* gamma, const float* beta,
                         float* running_mean, float* running_var,
@@ -137,14 +141,19 @@ int objgan_norm_backward(const float* x, const float* dy, const float* mean, con
                          float* dx, float* dgamma, float* dbeta,
                          int N, int C, int HW, int per_channel, int mode, void* stream);
 int objgan_act_backward(const float* dy, const float* y, float* dz, long total, int kind, void* stream);
-int objgan_channel_sum(const float* x, float* out, int N, int C, int HW, void* stream);
+/* out[c] = sum over (n, i) of x[n, c, i] (bias gradients); ws: objgan_channel_sum_ws_floats floats (ordered combine) */
+long objgan_channel_sum_ws_floats(int N, int C, int HW);
+int objgan_channel_sum(const float* x, float* out, int N, int C, int HW, float* ws, void* stream);
 
 /* ---- attention (reference GlobalAttention.py:32-181, miscc/utils.py:401-413) ---------------- */
 int objgan_attn_general_forward(const float* x, const float* src, const unsigned char* mask,
                                 float* wc, float* attn, int B, int idf, int Q, int L, void* stream);
+/* dsrc is fully written (no zero-fill): every wave stores its partial tile into ws
+ * (objgan_attn_general_backward_ws_floats floats, host-only query) and a second kernel sums the waves in order */
+long objgan_attn_general_backward_ws_floats(int B, int idf, int Q, int L);
 int objgan_attn_general_backward(const float* x, const float* src, const float* attn,
                                  const float* dwc, const float* dattn, float* dx, float* dsrc,
-                                 int B, int idf, int Q, int L, void* stream);
+                                 int B, int idf, int Q, int L, float* ws, void* stream);
 int objgan_attn_bu_forward(const float* tgt, const float* ctx1, const float* src,
                            const unsigned char* mask, float* wc, float* attn,
                            int B, int d2, int idf, int R, int L, int normalize, float eps,
@@ -153,9 +162,11 @@ int objgan_attn_bu_backward(const float* dwc, const float* attn, float* dsrc,
                             int B, int idf, int R, int L, void* stream);
 int objgan_masked_max_forward(const float* f, const float* m, float* out, int B, int num, int R,
                               int P, long m_stride_b, long m_stride_r, long m_stride_c, void* stream);
+/* df is fully written (no zero-fill); ws: objgan_masked_max_backward_ws_floats floats (ordered two-level sum) */
+long objgan_masked_max_backward_ws_floats(int B, int num, int R, int P);
 int objgan_masked_max_backward(const float* f, const float* m, const float* dout, float* df,
                                int B, int num, int R, int P, long m_stride_b, long m_stride_r,
-                               long m_stride_c, void* stream);
+                               long m_stride_c, float* ws, void* stream);
 int objgan_softmax_strided_forward(const float* x, float* y, long outer, int dim, long inner,
                                    float scale, const int* lens, int nlens,
                                    const unsigned char* rowvalid, void* stream);

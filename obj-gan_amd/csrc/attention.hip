@@ -89,14 +89,15 @@ __global__ __launch_bounds__(256) void attn_general_fwd_kernel(
 // ======================================================================================
 // A1 backward
 // ======================================================================================
-// dx [B, IDF, Q] written; dsrc [B, IDF, L] accumulated with atomics (zero on entry).
+// dx [B, IDF, Q] written; every wave stores its partial dsrc tile [IDF][16] into ws[b][wave] and
+// attn_dsrc_combine_kernel sums the waves in order into dsrc [B, IDF, L] (no atomics, no zero-fill).
 // A wave walks `chunks` groups of 64 pixels; per group: lane-local softmax backward, then
 // dsrc += [x | dwc] (IDF x 128) * [ds ; attn] (128 x L) on v_mfma_f32_16x16x4_f32.
 template <int IDF, int LMAX>
 __global__ __launch_bounds__(256) void attn_general_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ src, const float* __restrict__ attn,
     const float* __restrict__ dwc, const float* __restrict__ dattn,
-    float* __restrict__ dx, float* __restrict__ dsrc, int B, int Q, int L, int chunks) {
+    float* __restrict__ dx, float* __restrict__ ws, int B, int Q, int L, int chunks) {
     static_assert(IDF % 16 == 0 && LMAX == 16, "tile shape");
     constexpr int TM = IDF / 16;
     constexpr int KQ = 64;           // pixels per contraction pass (x*ds, then dwc*attn)
@@ -179,14 +180,28 @@ __global__ __launch_bounds__(256) void attn_general_bwd_kernel(
     }
     // C/D layout of the 16x16 MFMA: col = lane & 15 (= l), row = (lane >> 4) * 4 + r (= c in tile)
     const int l = lane & 15;
-    if (l < L) {
+    float* slot = ws + ((size_t)b * (gridDim.x * 4) + wave_global) * (IDF * LMAX);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = 16 * i + (lane >> 4) * 4 + r;
-                atomicAdd(&dsrc[((size_t)b * IDF + c) * L + l], acc[i][r]);
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * i + (lane >> 4) * 4 + r;
+            slot[c * LMAX + l] = acc[i][r];
+        }
+}
+
+// dsrc[b, c, l] = sum over the waves of attn_general_bwd_kernel, in wave order
+__global__ __launch_bounds__(256) void attn_dsrc_combine_kernel(const float* __restrict__ ws, float* __restrict__ dsrc,
+                                                                int B, int IDF, int L, int nwave) {
+    const int total = B * IDF * L;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int l = e % L;
+        const int c = (e / L) % IDF;
+        const int b = e / (L * IDF);
+        const float* p = ws + (size_t)b * nwave * IDF * 16 + c * 16 + l;
+        float v = 0.f;
+        for (int w = 0; w < nwave; ++w) v += p[(size_t)w * IDF * 16];
+        dsrc[e] = v;
     }
 }
 
@@ -295,20 +310,21 @@ __global__ __launch_bounds__(256) void masked_max_fwd_kernel(
     }
 }
 
-// df[b, c, r] += sum_p dout[b, c, p] * m[b, r, p] * [r == argmax_r' f*m]   (first max wins)
+// df[b, c, r] = sum_p dout[b, c, p] * m[b, r, p] * [r == argmax_r' f*m]   (first max wins).  Every wave owns an LDS
+// slab [NUM][R] (lane 0 adds the wave's shuffle-reduced contributions: no LDS atomics), the four slabs of a workgroup
+// are added in wave order into ws[b][block], masked_max_combine_kernel sums the blocks in order: bit-reproducible.
 __global__ __launch_bounds__(256) void masked_max_bwd_kernel(
     const float* __restrict__ f, const float* __restrict__ m, const float* __restrict__ dout,
-    float* __restrict__ df, int NUM, int R, int P, long m_stride_b, long m_stride_r,
+    float* __restrict__ ws, int NUM, int R, int P, long m_stride_b, long m_stride_r,
     long m_stride_c) {
     extern __shared__ float sm[];
     float* s_f = sm;                  // [NUM][R]
-    float* s_df = sm + NUM * R;       // [NUM][R]
+    float* s_all = sm + NUM * R;      // [4 waves][NUM][R]
     const int b = blockIdx.y;
-    for (int i = threadIdx.x; i < NUM * R; i += blockDim.x) {
-        s_f[i] = f[(size_t)b * NUM * R + i];
-        s_df[i] = 0.f;
-    }
+    for (int i = threadIdx.x; i < NUM * R; i += blockDim.x) s_f[i] = f[(size_t)b * NUM * R + i];
+    for (int i = threadIdx.x; i < 4 * NUM * R; i += blockDim.x) s_all[i] = 0.f;
     __syncthreads();
+    float* s_df = s_all + (threadIdx.x >> 6) * NUM * R;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     const bool ok = p < P;
     const float* mb = m + (size_t)b * m_stride_b + (ok ? p : 0);
@@ -330,12 +346,25 @@ __global__ __launch_bounds__(256) void masked_max_bwd_kernel(
             if (__ballot(arg == r && contrib != 0.f) == 0) continue;
             float v = (arg == r) ? contrib : 0.f;
             v = og_wave_sum(v);
-            if (lane == 0 && v != 0.f) atomicAdd(&s_df[c * R + r], v);
+            if (lane == 0) s_df[c * R + r] += v;
         }
     }
     __syncthreads();
+    float* slot = ws + ((size_t)b * gridDim.x + blockIdx.x) * NUM * R;
     for (int i = threadIdx.x; i < NUM * R; i += blockDim.x)
-        if (s_df[i] != 0.f) atomicAdd(&df[(size_t)b * NUM * R + i], s_df[i]);
+        slot[i] = ((s_all[i] + s_all[NUM * R + i]) + s_all[2 * NUM * R + i]) + s_all[3 * NUM * R + i];
+}
+
+__global__ __launch_bounds__(256) void masked_max_combine_kernel(const float* __restrict__ ws, float* __restrict__ df,
+                                                                 int B, int NR, int nblk) {
+    const int total = B * NR;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int b = e / NR, i = e - b * NR;
+        const float* p = ws + (size_t)b * nblk * NR + i;
+        float v = 0.f;
+        for (int k = 0; k < nblk; ++k) v += p[(size_t)k * NR];
+        df[e] = v;
+    }
 }
 
 // ======================================================================================
@@ -557,23 +586,37 @@ int objgan_attn_general_forward(const float* x, const float* src, const unsigned
 }
 
 // dsrc must be zero on entry (it is accumulated with atomics); dattn may be null.
-int objgan_attn_general_backward(const float* x, const float* src, const float* attn,
-                                 const float* dwc, const float* dattn, float* dx, float* dsrc,
-                                 int B, int idf, int Q, int L, void* stream) {
-    OG_ENTRY();
-    if (L < 1 || L > 16) return OG_BAD_ARGS;
-    if (B <= 0 || Q <= 0) return OG_OK;
-    // pixels per wave: enough chunks that the 576 atomics per wave are amortised, while the
-    // grid still covers the chip
+static inline int attn_bwd_chunks(int Q) {
+    // pixels per wave: enough chunks that a wave's partial tile is amortised, while the grid still covers the chip
     int chunks = Q / (64 * 4 * 16);
     if (chunks < 1) chunks = 1;
     if (chunks > 8) chunks = 8;
+    return chunks;
+}
+
+// floats of workspace objgan_attn_general_backward needs (per-wave partial dsrc tiles)
+long objgan_attn_general_backward_ws_floats(int B, int idf, int Q, int L) {
+    if (B <= 0 || Q <= 0) return 0;
+    const long nwave = 4L * og_cdiv(Q, 64 * 4 * attn_bwd_chunks(Q));
+    return (long)B * nwave * idf * 16;
+}
+
+int objgan_attn_general_backward(const float* x, const float* src, const float* attn,
+                                 const float* dwc, const float* dattn, float* dx, float* dsrc,
+                                 int B, int idf, int Q, int L, float* ws, void* stream) {
+    OG_ENTRY();
+    if (L < 1 || L > 16) return OG_BAD_ARGS;
+    if (B <= 0 || Q <= 0) return OG_OK;
+    if (!ws) return OG_BAD_ARGS;
+    const int chunks = attn_bwd_chunks(Q);
     dim3 grid(og_cdiv(Q, 64 * 4 * chunks), B);
     hipStream_t s = (hipStream_t)stream;
-    if (idf == 48) hipLaunchKernelGGL((attn_general_bwd_kernel<48, 16>), grid, dim3(256), 0, s, x, src, attn, dwc, dattn, dx, dsrc, B, Q, L, chunks);
-    else if (idf == 32) hipLaunchKernelGGL((attn_general_bwd_kernel<32, 16>), grid, dim3(256), 0, s, x, src, attn, dwc, dattn, dx, dsrc, B, Q, L, chunks);
-    else if (idf == 64) hipLaunchKernelGGL((attn_general_bwd_kernel<64, 16>), grid, dim3(256), 0, s, x, src, attn, dwc, dattn, dx, dsrc, B, Q, L, chunks);
+    if (idf == 48) hipLaunchKernelGGL((attn_general_bwd_kernel<48, 16>), grid, dim3(256), 0, s, x, src, attn, dwc, dattn, dx, ws, B, Q, L, chunks);
+    else if (idf == 32) hipLaunchKernelGGL((attn_general_bwd_kernel<32, 16>), grid, dim3(256), 0, s, x, src, attn, dwc, dattn, dx, ws, B, Q, L, chunks);
+    else if (idf == 64) hipLaunchKernelGGL((attn_general_bwd_kernel<64, 16>), grid, dim3(256), 0, s, x, src, attn, dwc, dattn, dx, ws, B, Q, L, chunks);
     else return OG_BAD_ARGS;
+    hipLaunchKernelGGL(attn_dsrc_combine_kernel, dim3(og_cdiv((long)B * idf * L, 256)), dim3(256), 0, s, ws, dsrc, B, idf, L,
+                       (int)grid.x * 4);
     return og_launch_status();
 }
 
@@ -614,18 +657,27 @@ int objgan_masked_max_forward(const float* f, const float* m, float* out, int B,
     return og_launch_status();
 }
 
-// df [B, num, R] must be zero on entry
+// floats of workspace objgan_masked_max_backward needs (per-workgroup partial df)
+long objgan_masked_max_backward_ws_floats(int B, int num, int R, int P) {
+    if (B <= 0 || num <= 0 || P <= 0) return 0;
+    return (long)B * og_cdiv(P, 256) * num * R;
+}
+
+// df [B, num, R] is fully written (no zero-fill needed)
 int objgan_masked_max_backward(const float* f, const float* m, const float* dout, float* df,
                                int B, int num, int R, int P, long m_stride_b, long m_stride_r,
-                               long m_stride_c, void* stream) {
+                               long m_stride_c, float* ws, void* stream) {
     OG_ENTRY();
     if (R < 1 || R > MM_RMAX) return OG_BAD_ARGS;
     if (B <= 0 || num <= 0 || P <= 0) return OG_OK;
-    const size_t shm = sizeof(float) * (size_t)num * R * 2;
+    if (!ws) return OG_BAD_ARGS;
+    const size_t shm = sizeof(float) * (size_t)num * R * 5;
     if (shm > 60000) return OG_BAD_ARGS;
     dim3 grid(og_cdiv(P, 256), B);
     hipLaunchKernelGGL(masked_max_bwd_kernel, grid, dim3(256), shm, (hipStream_t)stream, f, m, dout,
-                       df, num, R, P, m_stride_b, m_stride_r, m_stride_c);
+                       ws, num, R, P, m_stride_b, m_stride_r, m_stride_c);
+    hipLaunchKernelGGL(masked_max_combine_kernel, dim3(og_cdiv((long)B * num * R, 256)), dim3(256), 0, (hipStream_t)stream,
+                       ws, df, B, num * R, (int)grid.x);
     return og_launch_status();
 }
 

@@ -2043,24 +2043,39 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad3_kernel(const WgradArgs a,
     }
 }
 
-// Adds the ring of a padded-grid data gradient (IgemmArgs::ring) onto the unpadded gradient: padded index p
-// mirrors to 1 (p = 0) / H - 2 (p = H + 1), interior p to p - 1.  A few hundred atomics per plane.
+// Adds the ring of a padded-grid data gradient (IgemmArgs::ring) onto the unpadded gradient: padded index p mirrors to
+// 1 (p = 0) / H - 2 (p = H + 1), interior p to p - 1.  Gather form: one thread per DESTINATION element of rows 1 / H-2
+// and columns 1 / W-2 adds its (up to four) ring entries in a fixed order -- top row, bottom row, left column, right
+// column -- to y: single writer, no atomics, bit-reproducible.
 __global__ __launch_bounds__(256) void reflect_ring_fold_kernel(const float* __restrict__ ring, float* __restrict__ y,
                                                                 long planes, int H, int W) {
     const int PH = H + 2, PW = W + 2, R = 2 * PW + 2 * PH;
-    const long total = planes * R;
+    const int D = 2 * W + 2 * H;                      // candidate destinations per plane (segments below)
+    const long total = planes * D;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const long p = e / R;
-        const int ri = (int)(e - p * R);
-        int pa, pb;
-        if (ri < PW) { pa = 0; pb = ri; }
-        else if (ri < 2 * PW) { pa = PH - 1; pb = ri - PW; }
-        else if (ri < 2 * PW + PH) { pa = ri - 2 * PW; pb = 0; }
-        else { pa = ri - 2 * PW - PH; pb = PW - 1; }
-        if (ri >= 2 * PW && (pa == 0 || pa == PH - 1)) continue;      // corners belong to the row arrays
-        const int oh = pa == 0 ? 1 : (pa == PH - 1 ? H - 2 : pa - 1);
-        const int ow = pb == 0 ? 1 : (pb == PW - 1 ? W - 2 : pb - 1);
-        atomicAdd(&y[p * (long)H * W + (long)oh * W + ow], ring[e]);
+        const long p = e / D;
+        const int d = (int)(e - p * D);
+        int oh, ow;
+        if (d < W) { oh = 1; ow = d; }
+        else if (d < 2 * W) { oh = H - 2; ow = d - W; if (oh == 1) continue; }
+        else if (d < 2 * W + H) { oh = d - 2 * W; ow = 1; if (oh == 1 || oh == H - 2) continue; }
+        else { oh = d - 2 * W - H; ow = W - 2; if (oh == 1 || oh == H - 2 || ow == 1) continue; }
+        const float* rg = ring + p * R;
+        const float* top = rg, *bot = rg + PW, *lef = rg + 2 * PW, *rig = rg + 2 * PW + PH;
+        float v = 0.f;
+        if (oh == 1) {                                   // padded row 0: columns pb with mirror(pb) == ow
+            v += top[ow + 1];
+            if (ow == 1) v += top[0];
+            if (ow == W - 2) v += top[PW - 1];
+        }
+        if (oh == H - 2) {                               // padded row PH - 1
+            v += bot[ow + 1];
+            if (ow == 1) v += bot[0];
+            if (ow == W - 2) v += bot[PW - 1];
+        }
+        if (ow == 1) v += lef[oh + 1];                   // padded column 0 (corners belong to the row arrays)
+        if (ow == W - 2) v += rig[oh + 1];               // padded column PW - 1
+        y[p * (long)H * W + (long)oh * W + ow] += v;
     }
 }
 
@@ -2360,11 +2375,14 @@ static Igemm2Plan igemm2_plan(const IgemmArgs& a, int y_prezeroed) {
     const int nk = a.math == 1 ? a.Krow / 32 : a.Kpad / 16;      // loop iterations of the kernel
     p.full_cover = ((a.osh == 1 && a.osw == 1 && a.PH == a.OHf && a.PW == a.OWf) || a.ring != nullptr) ? 1 : 0;
     int splits = 1;
-    if (tiles < 128 && nk >= 16 && (p.full_cover || y_prezeroed) && nph == 1) {
+    // (partial-coverage launches -- strided output phases into a pre-zeroed y -- are not split: their partials would
+    // have to be accumulated with atomics; they are the two 3x3 stride-2 layers of G_HMAP, 0.1 ms per step)
+    (void)y_prezeroed;
+    if (tiles < 128 && nk >= 16 && p.full_cover && nph == 1) {
         splits = og_cdiv(512, tiles);
         if (splits > nk / 4) splits = nk / 4;
     } else if (og_split_target() > 0 && p.TM == 1 && p.rest == 0 && tiles < og_split_target() && nk >= 16 &&
-               (p.full_cover || y_prezeroed) && nph == 1) {
+               p.full_cover && nph == 1) {
         splits = og_cdiv(og_split_target(), tiles);
         if (splits > nk / 8) splits = nk / 8;
         if (splits < 1) splits = 1;
@@ -2712,7 +2730,7 @@ int objgan_reflect_ring_fold(const float* ring, float* y, long planes, int H, in
     OG_ENTRY();
     if (H < 3 || W < 3) return OG_BAD_ARGS;
     if (planes <= 0) return OG_OK;
-    const long total = planes * (2 * (W + 2) + 2 * (H + 2));
+    const long total = planes * (2 * W + 2 * H);
     hipLaunchKernelGGL(reflect_ring_fold_kernel, dim3(og_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        ring, y, planes, H, W);
     return og_launch_status();

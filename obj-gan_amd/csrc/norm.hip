@@ -27,11 +27,16 @@ struct NormGeom {
 
 __device__ __forceinline__ float og_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
 
+// Statistics workspace of one call: [2G totals][G tickets][2 * G * P partial pairs] (og_ordered_sum, common.h): the
+// per-workgroup partial sums of a group are combined in slot order by the last workgroup to arrive -- no fp32 atomics.
+struct NormWs { float* sums; int* cnt; float* part; int P; };
+
 // ---- statistics ------------------------------------------------------------------------
 // grid = (G, S).  sums[g*2 + {0,1}] must be zero on entry.
 __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict__ x,
-                                                         float* __restrict__ sums, NormGeom gm) {
+                                                         NormWs ws, NormGeom gm) {
     __shared__ float red[16];
+    __shared__ int s_flag;
     const int g = blockIdx.x;
     const int planes = gm.per_channel ? gm.N : 1;
     const size_t base = gm.per_channel ? (size_t)g * gm.HW : (size_t)g * gm.HW;
@@ -51,10 +56,8 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
     }
     s1 = og_block_sum(s1, red);
     s2 = og_block_sum(s2, red);
-    if (threadIdx.x == 0 && e0 < e1) {
-        atomicAdd(&sums[2 * g], s1);
-        atomicAdd(&sums[2 * g + 1], s2);
-    }
+    const float v[2] = {s1, s2};
+    og_ordered_sum<2>(v, ws.part, ws.cnt, ws.sums, g, blockIdx.y, ws.P, &s_flag);
 }
 
 // mean/rstd per group; optional BatchNorm running-statistics update (momentum, unbiased var)
@@ -148,8 +151,9 @@ __device__ __forceinline__ float norm_dz(const float* __restrict__ x, const floa
 __global__ __launch_bounds__(256) void norm_bwd_stats_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float* __restrict__ bsums, NormGeom gm, int mode) {
+    NormWs ws, NormGeom gm, int mode) {
     __shared__ float red[16];
+    __shared__ int s_flag;
     const int g = blockIdx.x;
     const int planes = gm.per_channel ? gm.N : 1;
     const long total = (long)planes * gm.HW;
@@ -169,10 +173,8 @@ __global__ __launch_bounds__(256) void norm_bwd_stats_kernel(
     }
     s1 = og_block_sum(s1, red);
     s2 = og_block_sum(s2, red);
-    if (threadIdx.x == 0 && e0 < e1) {
-        atomicAdd(&bsums[2 * g], s1);
-        atomicAdd(&bsums[2 * g + 1], s2);
-    }
+    const float v[2] = {s1, s2};
+    og_ordered_sum<2>(v, ws.part, ws.cnt, ws.sums, g, blockIdx.y, ws.P, &s_flag);
 }
 
 // dx = gamma * rstd * (dz - mean(dz) - xhat * mean(dz * xhat))
@@ -206,8 +208,9 @@ __device__ __forceinline__ float og_group_mean(const float* p, int g) { return p
 
 // grid = (N*C, chunks): sums[g*2 + {0,1}] += shifted sums of this plane chunk (zero on entry)
 __global__ __launch_bounds__(256) void norm_stats_plane_kernel(const float* __restrict__ x,
-                                                               float* __restrict__ sums, NormGeom gm) {
+                                                               NormWs ws, NormGeom gm) {
     __shared__ float red[16];
+    __shared__ int s_flag;
     const int plane = blockIdx.x;                       // n*C + c
     const int c = plane % gm.C;
     const int g = gm.per_channel ? c : plane;
@@ -224,10 +227,10 @@ __global__ __launch_bounds__(256) void norm_stats_plane_kernel(const float* __re
     }
     s1 = og_block_sum(s1, red);
     s2 = og_block_sum(s2, red);
-    if (threadIdx.x == 0) {
-        atomicAdd(&sums[2 * g], s1);
-        atomicAdd(&sums[2 * g + 1], s2);
-    }
+    // slot of this workgroup within its group: BatchNorm groups collect the N images x chunks, InstanceNorm the chunks
+    const int idx = gm.per_channel ? (plane / gm.C) * (int)gridDim.y + (int)blockIdx.y : (int)blockIdx.y;
+    const float v[2] = {s1, s2};
+    og_ordered_sum<2>(v, ws.part, ws.cnt, ws.sums, g, idx, ws.P, &s_flag);
 }
 
 // Statistics of group g from its shifted sums (what norm_finalize_kernel computes); when `fin.sums` is set
@@ -330,8 +333,9 @@ template <int MODE>
 __global__ __launch_bounds__(256) void norm_bwd_stats_plane_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float* __restrict__ bsums, NormGeom gm) {
+    NormWs ws, NormGeom gm) {
     __shared__ float red[16];
+    __shared__ int s_flag;
     const int Co = MODE == OG_NORM_GLU ? gm.C / 2 : gm.C;
     const int plane = blockIdx.x;
     const int n = plane / Co;
@@ -366,10 +370,12 @@ __global__ __launch_bounds__(256) void norm_bwd_stats_plane_kernel(
     a1 = og_block_sum(a1, red);
     a2 = og_block_sum(a2, red);
     if (MODE == OG_NORM_GLU) { b1 = og_block_sum(b1, red); b2 = og_block_sum(b2, red); }
-    if (threadIdx.x == 0) {
-        atomicAdd(&bsums[2 * ga], a1);
-        atomicAdd(&bsums[2 * ga + 1], a2);
-        if (MODE == OG_NORM_GLU) { atomicAdd(&bsums[2 * gb], b1); atomicAdd(&bsums[2 * gb + 1], b2); }
+    const int idx = gm.per_channel ? n * (int)gridDim.y + (int)blockIdx.y : (int)blockIdx.y;
+    const float va[2] = {a1, a2};
+    og_ordered_sum<2>(va, ws.part, ws.cnt, ws.sums, ga, idx, ws.P, &s_flag);
+    if (MODE == OG_NORM_GLU) {
+        const float vb[2] = {b1, b2};
+        og_ordered_sum<2>(vb, ws.part, ws.cnt, ws.sums, gb, idx, ws.P, &s_flag);
     }
 }
 
@@ -592,10 +598,13 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     }
 }
 
-// per-channel sum over (N, HW): out[c] = sum_n sum_i x[n, c, i]   (conv bias gradient)
+// per-channel sum over (N, HW): out[c] = sum_n sum_i x[n, c, i]   (conv bias gradient); grid (C, S), the S partial
+// sums of a channel are combined in order (og_ordered_sum): ws = [C tickets][C * S partials]
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x,
-                                                          float* __restrict__ out, int N, int C, int HW) {
+                                                          float* __restrict__ out, int N, int C, int HW,
+                                                          int* __restrict__ cnt, float* __restrict__ part) {
     __shared__ float red[16];
+    __shared__ int s_flag;
     const int c = blockIdx.x;
     const long total = (long)N * HW;
     const long chunk = (total + gridDim.y - 1) / gridDim.y;
@@ -608,7 +617,8 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
         s += x[((size_t)n * C + c) * HW + i];
     }
     s = og_block_sum(s, red);
-    if (threadIdx.x == 0 && e0 < e1) atomicAdd(&out[c], s);
+    const float v[1] = {s};
+    og_ordered_sum<1>(v, part, cnt, out, c, blockIdx.y, gridDim.y, &s_flag);
 }
 
 #define OG_IN_FUSED_MAX 65536        // largest plane (elements) the one-kernel InstanceNorm takes: 256 KB, two passes
@@ -624,9 +634,30 @@ static inline int norm_splits(int G, long per_group) {
     return (int)want;
 }
 
+// partial sums per group of the statistics kernels (plane-structured or generic launch)
+static inline bool norm_planes(int N, int C, int HW) { return (HW % 4 == 0) && HW >= 256 && (long)N * C < 2000000; }
+static inline int norm_partials(int N, int C, int HW, int per_channel) {
+    const int G = per_channel ? C : N * C;
+    if (norm_planes(N, C, HW)) return (per_channel ? N : 1) * og_cdiv(HW, OG_NORM_CHUNK);
+    return norm_splits(G, per_channel ? (long)N * HW : HW);
+}
+static inline NormWs norm_ws(float* buf, int G, int P, hipStream_t s) {
+    NormWs w{buf, reinterpret_cast<int*>(buf + 2 * (size_t)G), buf + 3 * (size_t)G, P};
+    if (P > 1) (void)hipMemsetAsync(w.cnt, 0, sizeof(int) * (size_t)G, s);       // tickets of og_ordered_sum
+    return w;
+}
+
 extern "C" {
 
-// Forward: statistics + apply.  Workspaces: sums [2G] (zeroed here), mean [G], rstd [G].
+// Floats of statistics workspace (`sums` of objgan_norm_forward, `bsums` of objgan_norm_backward) for these sizes:
+// [2G totals][G tickets][2 * G * P partial pairs], P = workgroups per group of the statistics launch.  Host-only.
+long objgan_norm_ws_floats(int N, int C, int HW, int per_channel) {
+    if (N <= 0 || C <= 0 || HW <= 0) return 0;
+    const long G = per_channel ? C : (long)N * C;
+    return 3 * G + 2 * G * norm_partials(N, C, HW, per_channel);
+}
+
+// Forward: statistics + apply.  Workspaces: sums [objgan_norm_ws_floats] (totals first), mean [G], rstd [G].
 // per_channel = 1 BatchNorm (G = C), 0 InstanceNorm (G = N*C).  gamma/beta/running_* may be
 // null.  mode: 0 none, 1 LeakyReLU(0.2), 2 GLU (y has C/2 channels).  residual may be null.
 int objgan_norm_forward(const float* x, float* y, const float* residual,
@@ -642,7 +673,7 @@ int objgan_norm_forward(const float* x, float* y, const float* residual,
     NormGeom gm{N, C, HW, per_channel};
     const int G = per_channel ? C : N * C;
     const long per_group = per_channel ? (long)N * HW : HW;
-    const bool planes = (HW % 4 == 0) && HW >= 256 && (long)N * C < 2000000;
+    const bool planes = norm_planes(N, C, HW);
     const int chunks = og_cdiv(HW, OG_NORM_CHUNK);
     const int Co = mode == OG_NORM_GLU ? C / 2 : C;
     if (planes && !per_channel && !gamma && HW <= OG_IN_FUSED_MAX && !og_norm_nofuse()) {
@@ -656,12 +687,12 @@ int objgan_norm_forward(const float* x, float* y, const float* residual,
             hipLaunchKernelGGL((in_fwd_fused_kernel<OG_NORM_NONE>), grid, dim3(256), 0, s, x, residual, y, mean, rstd, gm, eps);
         return og_launch_status();
     }
-    hipMemsetAsync(sums, 0, sizeof(float) * 2 * G, s);
+    const NormWs ws = norm_ws(sums, G, norm_partials(N, C, HW, per_channel), s);
     if (planes) {
-        hipLaunchKernelGGL(norm_stats_plane_kernel, dim3(N * C, chunks), dim3(256), 0, s, x, sums, gm);
+        hipLaunchKernelGGL(norm_stats_plane_kernel, dim3(N * C, chunks), dim3(256), 0, s, x, ws, gm);
     } else {
         dim3 grid(G, norm_splits(G, per_group));
-        hipLaunchKernelGGL(norm_stats_kernel, grid, dim3(256), 0, s, x, sums, gm);
+        hipLaunchKernelGGL(norm_stats_kernel, grid, dim3(256), 0, s, x, ws, gm);
     }
     if (planes) {
         dim3 grid(N * Co, chunks);
@@ -723,7 +754,7 @@ int objgan_norm_backward(const float* x, const float* dy, const float* mean, con
     NormGeom gm{N, C, HW, per_channel};
     const int G = per_channel ? C : N * C;
     const long per_group = per_channel ? (long)N * HW : HW;
-    const bool planes = (HW % 4 == 0) && HW >= 256 && (long)N * C < 2000000;
+    const bool planes = norm_planes(N, C, HW);
     if (planes && !per_channel && !gamma && HW <= OG_IN_FUSED_MAX && !og_norm_nofuse()) {
         const int Co = mode == OG_NORM_GLU ? C / 2 : C;
         dim3 grid(N * Co);
@@ -735,13 +766,13 @@ int objgan_norm_backward(const float* x, const float* dy, const float* mean, con
             hipLaunchKernelGGL((in_bwd_fused_kernel<OG_NORM_NONE>), grid, dim3(256), 0, s, x, dy, mean, rstd, dx, gm);
         return og_launch_status();
     }
-    hipMemsetAsync(bsums, 0, sizeof(float) * 2 * G, s);
+    const NormWs ws = norm_ws(bsums, G, norm_partials(N, C, HW, per_channel), s);
     if (planes) {
         const int Co = mode == OG_NORM_GLU ? C / 2 : C;
         dim3 grid(N * Co, og_cdiv(HW, OG_NORM_CHUNK));
 #define OG_NB(MODE)                                                                                         \
         hipLaunchKernelGGL((norm_bwd_stats_plane_kernel<MODE>), grid, dim3(256), 0, s, x, dy, mean, rstd,   \
-                           gamma, beta, bsums, gm);                                                         \
+                           gamma, beta, ws, gm);                                                            \
         hipLaunchKernelGGL((norm_bwd_apply_plane_kernel<MODE>), grid, dim3(256), 0, s, x, dy, mean, rstd,   \
                            gamma, beta, bsums, dx, gm, dgamma, dbeta);
         if (mode == OG_NORM_GLU) { OG_NB(OG_NORM_GLU) } else if (mode == OG_NORM_LRELU) { OG_NB(OG_NORM_LRELU) } else { OG_NB(OG_NORM_NONE) }
@@ -750,7 +781,7 @@ int objgan_norm_backward(const float* x, const float* dy, const float* mean, con
     } else {
         dim3 grid(G, norm_splits(G, per_group));
         hipLaunchKernelGGL(norm_bwd_stats_kernel, grid, dim3(256), 0, s, x, dy, mean, rstd, gamma, beta,
-                           bsums, gm, mode);
+                           ws, gm, mode);
         const long total = (long)N * C * HW;
         hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(og_stream_grid(total, 256)), dim3(256), 0, s, x,
                            dy, mean, rstd, gamma, beta, bsums, dx, gm, mode);
@@ -772,13 +803,22 @@ int objgan_act_backward(const float* dy, const float* y, float* dz, long total, 
 }
 
 // out [C] is zeroed here, then out[c] = sum over n, i of x[n, c, i]
-int objgan_channel_sum(const float* x, float* out, int N, int C, int HW, void* stream) {
+// floats of workspace objgan_channel_sum needs: [C tickets][C * S partial sums]
+long objgan_channel_sum_ws_floats(int N, int C, int HW) {
+    if (N <= 0 || C <= 0 || HW <= 0) return 0;
+    return (long)C * (1 + norm_splits(C, (long)N * HW));
+}
+
+int objgan_channel_sum(const float* x, float* out, int N, int C, int HW, float* ws, void* stream) {
     OG_ENTRY();
     if (N <= 0 || C <= 0 || HW <= 0) return OG_OK;
     hipStream_t s = (hipStream_t)stream;
-    hipMemsetAsync(out, 0, sizeof(float) * C, s);
-    dim3 grid(C, norm_splits(C, (long)N * HW));
-    hipLaunchKernelGGL(channel_sum_kernel, grid, dim3(256), 0, s, x, out, N, C, HW);
+    const int S = norm_splits(C, (long)N * HW);
+    if (S > 1 && !ws) return OG_BAD_ARGS;
+    if (S > 1) (void)hipMemsetAsync(ws, 0, sizeof(int) * (size_t)C, s);
+    dim3 grid(C, S);
+    hipLaunchKernelGGL(channel_sum_kernel, grid, dim3(256), 0, s, x, out, N, C, HW, reinterpret_cast<int*>(ws),
+                       ws ? ws + C : nullptr);
     return og_launch_status();
 }
 

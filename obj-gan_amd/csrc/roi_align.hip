@@ -143,51 +143,98 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(
     }
 }
 
-// Backward, privatised: one workgroup owns one (image, channel) plane, accumulates every ROI of
-// that image into an LDS copy of the plane (LDS atomics: the boxes of an image overlap heavily --
-// with the reference's spatial_scale quirk they all land in the top-left corner -- which makes
-// global atomics serialise), then adds the plane into bottom_grad with plain coalesced
-// read-modify-writes.  Same per-term arithmetic as roi_align_bwd_kernel; the summation order of
-// the four-tap scatter is unspecified in the reference kernel as well (atomicAdd).
+// Backward, privatised and ORDERED: one workgroup owns one (image, channel) plane.  The ROIs of its image are taken in
+// index order, ROI_BATCH at a time: their sample geometry and incoming gradients go to LDS, the bounding box of all
+// their taps is found (integer LDS min / max), and every pixel of the box GATHERS -- in sample order -- the taps that
+// land on it into the LDS copy of the plane (one writer per pixel).  Same per-term arithmetic as roi_align_bwd_kernel
+// (and the reference's CUDA kernel); the reference leaves the order of its atomicAdds unspecified, this kernel fixes
+// it: bit-reproducible.  r02's scatter form kept 36 of 256 threads busy (146 us per launch).
+#define ROI_BATCH 8
+#define ROI_LIST_MAX 256          // rois per image this kernel takes (the hot path has 10)
 __global__ __launch_bounds__(256) void roi_align_bwd_plane_kernel(
     const float* __restrict__ top_grad, const float* __restrict__ rois,
     float* __restrict__ bottom_grad, int num_rois,
     int C, int H, int W, int AH, int AW, float spatial_scale) {
-    extern __shared__ __attribute__((aligned(16))) float plane[];      // H*W floats, then the samples
+    extern __shared__ __attribute__((aligned(16))) float plane[];      // H*W floats, then samples, then gradients
     const int HW = H * W;
     const int S = AH * AW;
-    RoiSample* smp = reinterpret_cast<RoiSample*>(plane + HW);
+    RoiSample* smp = reinterpret_cast<RoiSample*>(plane + HW);          // [ROI_BATCH * S]
+    float* sd = reinterpret_cast<float*>(smp + ROI_BATCH * S);          // [ROI_BATCH * S]
+    __shared__ int s_list[ROI_LIST_MAX];                                // rois of this image, in index order
+    __shared__ int s_wave[4], s_box[4];                                 // box: rmin, rmax, cmin, cmax
     const int c = blockIdx.x;
     const int b = blockIdx.y;
     for (int i = threadIdx.x; i < HW; i += blockDim.x) plane[i] = 0.f;
-    bool any = false;
-    for (int r = 0; r < num_rois; ++r) {
-        const float* roi = rois + (size_t)r * 5;
-        // reference: img_start = (int)(roi_batch_ind * C * H * W) -- the plane of image roi[0]
-        const int img_start = (int)(((roi[0] * (float)C) * (float)H) * (float)W);
-        if (img_start != b * C * HW) continue;                       // wave-uniform
-        any = true;
-        __syncthreads();
-        for (int s = threadIdx.x; s < S; s += blockDim.x)
-            roi_geometry(roi, spatial_scale, H, W, AH, AW, s, smp[s]);
-        __syncthreads();
-        const float* tg = top_grad + ((size_t)r * C + c) * S;
-        for (int s = threadIdx.x; s < S; s += blockDim.x) {
-            const RoiSample g = smp[s];
-            if (!g.valid) continue;
-            const float d = tg[s];
-            float* p = plane + g.off;
-            const double omh = 1.0 - (double)g.h_ratio;
-            const float omw = 1.0f - g.w_ratio;
-            const float dh_ = d * g.h_ratio;
-            atomicAdd(p,         (float)(((double)d * omh) * (double)omw));
-            atomicAdd(p + 1,     (float)(((double)d * omh) * (double)g.w_ratio));
-            atomicAdd(p + W,     dh_ * omw);
-            atomicAdd(p + W + 1, dh_ * g.w_ratio);
+    // ordered compaction of the rois that belong to image b (ballot + prefix count per wave, waves in order)
+    int nlist = 0;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int base = 0; base < num_rois; base += 256) {
+        const int r = base + threadIdx.x;
+        bool mine = false;
+        if (r < num_rois) {
+            // reference: img_start = (int)(roi_batch_ind * C * H * W) -- the plane of image roi[0]
+            const int img_start = (int)(((rois[(size_t)r * 5] * (float)C) * (float)H) * (float)W);
+            mine = img_start == b * C * HW;
         }
+        const unsigned long long m = __ballot(mine);
+        if (lane == 0) s_wave[wid] = __popcll(m);
+        __syncthreads();
+        int pos = nlist + __popcll(m & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wid; ++w) pos += s_wave[w];
+        if (mine && pos < ROI_LIST_MAX) s_list[pos] = r;
+        nlist += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
     }
-    if (!any) return;
-    __syncthreads();
+    nlist = min(nlist, ROI_LIST_MAX);
+    if (nlist == 0) return;                            // uniform: nothing lands in this plane
+    for (int k0 = 0; k0 < nlist; k0 += ROI_BATCH) {
+        const int n = min(ROI_BATCH, nlist - k0);
+        if (threadIdx.x == 0) { s_box[0] = H; s_box[1] = -1; s_box[2] = W; s_box[3] = -1; }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n * S; i += blockDim.x) {
+            const int k = i / S, s = i - k * S;
+            const int r = s_list[k0 + k];
+            RoiSample g;
+            roi_geometry(rois + (size_t)r * 5, spatial_scale, H, W, AH, AW, s, g);
+            smp[i] = g;
+            sd[i] = top_grad[((size_t)r * C + c) * S + s];
+            if (g.valid) {
+                const int row = g.off / W, col = g.off - row * W;
+                atomicMin(&s_box[0], row); atomicMax(&s_box[1], row + 1);
+                atomicMin(&s_box[2], col); atomicMax(&s_box[3], col + 1);
+            }
+        }
+        __syncthreads();
+        const int r0 = s_box[0], r1 = min(s_box[1], H - 1), c0 = s_box[2], c1 = min(s_box[3], W - 1);
+        const int bw = c1 - c0 + 1, bh = r1 - r0 + 1;
+        if (bw > 0 && bh > 0) {
+            for (int i = threadIdx.x; i < bw * bh; i += blockDim.x) {
+                const int py = r0 + i / bw, px = c0 + i % bw;
+                const int pix = py * W + px;
+                float acc = 0.f;
+                for (int j = 0; j < n * S; ++j) {
+                    const RoiSample g = smp[j];
+                    if (!g.valid) continue;
+                    const int t = pix - g.off;          // 0, 1, W, W + 1: the four taps of the sample
+                    if (t != 0 && t != 1 && t != W && t != W + 1) continue;
+                    const float d = sd[j];
+                    // reference kernel.cu:137-140: `(1. - h_ratio)` is double, `(1 - w_ratio)` is FLOAT (int
+                    // literal); the two h_ratio terms are all-float products.
+                    const double omh = 1.0 - (double)g.h_ratio;
+                    const float omw = 1.0f - g.w_ratio;
+                    const float dh_ = d * g.h_ratio;
+                    float v;
+                    if (t == 0) v = (float)(((double)d * omh) * (double)omw);
+                    else if (t == 1) v = (float)(((double)d * omh) * (double)g.w_ratio);
+                    else if (t == W) v = dh_ * omw;
+                    else v = dh_ * g.w_ratio;
+                    acc += v;
+                }
+                plane[pix] += acc;
+            }
+        }
+        __syncthreads();
+    }
     float* dst = bottom_grad + ((size_t)b * C + c) * HW;
     for (int i = threadIdx.x; i < HW; i += blockDim.x) {
         const float v = plane[i];
@@ -266,7 +313,7 @@ int objgan_roi_align_backward(const float* top_grad, const float* rois, float* b
         return OG_BAD_ARGS;
     if (num_rois <= 0 || channels <= 0) return OG_OK;
     const int S = aligned_height * aligned_width;
-    const size_t lds = (size_t)height * width * sizeof(float) + (size_t)S * sizeof(RoiSample);
+    const size_t lds = (size_t)height * width * sizeof(float) + (size_t)ROI_BATCH * S * (sizeof(RoiSample) + sizeof(float));
     if (batch_size > 0 && lds <= 64 * 1024 && (double)batch_size * channels * height * width < 2.0e9) {
         dim3 grid(channels, batch_size);
         hipLaunchKernelGGL(roi_align_bwd_plane_kernel, grid, dim3(256), lds, (hipStream_t)stream,

@@ -42,13 +42,13 @@ SIGNATURES = {
     "objgan_norm_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                              _c_int, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_act_backward": [_ptr, _ptr, _ptr, _c_long, _c_int, _ptr],
-    "objgan_channel_sum": [_ptr, _ptr, _c_int, _c_int, _c_int, _ptr],
+    "objgan_channel_sum": [_ptr, _ptr, _c_int, _c_int, _c_int, _ptr, _ptr],
     "objgan_attn_general_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr],
-    "objgan_attn_general_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr],
+    "objgan_attn_general_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr],
     "objgan_attn_bu_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _ptr],
     "objgan_attn_bu_backward": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_masked_max_forward": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_long, _c_long, _c_long, _ptr],
-    "objgan_masked_max_backward": [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_long, _c_long, _c_long, _ptr],
+    "objgan_masked_max_backward": [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_long, _c_long, _c_long, _ptr, _ptr],
     "objgan_softmax_strided_forward": [_ptr, _ptr, _c_long, _c_int, _c_long, _c_float, _ptr, _c_int, _ptr, _ptr],
     "objgan_softmax_strided_backward": [_ptr, _ptr, _ptr, _c_long, _c_int, _c_long, _c_float, _ptr],
     "objgan_bilinear_forward": [_ptr, _ptr, _c_long, _c_int, _c_int, _c_int, _c_int, _ptr],
@@ -82,7 +82,11 @@ SIGNATURES = {
 }
 LONG_RETURN = {"objgan_conv_packed_floats": [_c_int, _c_int, _c_int],
                "objgan_conv_igemm_ws_floats": [_c_int] * 22,
-               "objgan_conv_wgrad_ws_floats": [_c_int] * 13}
+               "objgan_conv_wgrad_ws_floats": [_c_int] * 13,
+               "objgan_norm_ws_floats": [_c_int] * 4,
+               "objgan_attn_general_backward_ws_floats": [_c_int] * 4,
+               "objgan_masked_max_backward_ws_floats": [_c_int] * 4,
+               "objgan_channel_sum_ws_floats": [_c_int] * 3}
 
 _LIB = None
 

@@ -336,6 +336,13 @@ def _conv_wgrad(x, g, Cout, k, stride, pad, refl, upsample):
     return dw_
 
 
+def _channel_sum(g, out, N, C, HW):
+    """out[c] = sum over images and pixels of g[:, c] (bias gradient), partial sums combined in order"""
+    n = _lib.load().objgan_channel_sum_ws_floats(N, C, HW)
+    ws = torch.empty(n, dtype=_F32, device=g.device) if n > 0 else None
+    _lib.call("objgan_channel_sum", _p(g), _p(out), N, C, HW, _p(ws), _stream())
+
+
 class _Conv2dFn(torch.autograd.Function):
     """conv2d with the gather-side fusions of the hot path.
 
@@ -381,7 +388,7 @@ class _Conv2dFn(torch.autograd.Function):
             dw_ = _conv_wgrad(x, g, Cout, k, stride, pad, refl, upsample)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(Cout, dtype=_F32, device=x.device)
-            _lib.call("objgan_channel_sum", _p(g), _p(db), N, Cout, g.shape[2] * g.shape[3], _stream())
+            _channel_sum(g, db, N, Cout, g.shape[2] * g.shape[3])
         return dx, dw_, db, None, None, None, None, None
 
 
@@ -630,8 +637,9 @@ class _NormActFn(torch.autograd.Function):
         Co = C // 2 if mode == "glu" else C
         y = torch.empty((N, Co) + tuple(x.shape[2:]), dtype=_F32, device=x.device)
         G = C if per_channel else N * C
-        ws = torch.empty(4 * G, dtype=_F32, device=x.device)
-        sums, mean, rstd = ws[:2 * G], ws[2 * G:3 * G], ws[3 * G:]
+        nst = _lib.load().objgan_norm_ws_floats(N, C, HW, int(per_channel))     # statistics workspace (ordered combine)
+        ws = torch.empty(nst + 2 * G, dtype=_F32, device=x.device)
+        sums, mean, rstd = ws[:nst], ws[nst:nst + G], ws[nst + G:]
         residual = _c(residual) if residual is not None else None
         _lib.call("objgan_norm_forward", _p(x), _p(y), _p(residual), _p(gamma), _p(beta),
                   _p(running_mean), _p(running_var), _p(sums), _p(mean), _p(rstd),
@@ -648,7 +656,7 @@ class _NormActFn(torch.autograd.Function):
         dy = _c(dy)
         _chk(dy)
         G = C if per_channel else N * C
-        bsums = torch.empty(2 * G, dtype=_F32, device=x.device)
+        bsums = torch.empty(_lib.load().objgan_norm_ws_floats(N, C, HW, int(per_channel)), dtype=_F32, device=x.device)
         dx = torch.empty_like(x)
         dgamma = dbeta = None
         if gamma is not None:
@@ -724,9 +732,10 @@ class _AttnGeneralFn(torch.autograd.Function):
         dwc = _c(dwc)
         dattn = _c(dattn) if dattn is not None else None
         dx = torch.empty_like(x)
-        dsrc = torch.zeros_like(src)
+        dsrc = torch.empty_like(src)                  # fully written by the ordered combine
+        ws = torch.empty(_lib.load().objgan_attn_general_backward_ws_floats(B, idf, Q, L), dtype=_F32, device=x.device)
         _lib.call("objgan_attn_general_backward", _p(x), _p(src), _p(attn), _p(dwc), _p(dattn),
-                  _p(dx), _p(dsrc), B, idf, Q, L, _stream())
+                  _p(dx), _p(dsrc), B, idf, Q, L, _p(ws), _stream())
         return dx, dsrc, None
 
 
@@ -803,9 +812,10 @@ class _MaskedMaxFn(torch.autograd.Function):
         f2, m = ctx.saved_tensors
         B, num, R, P, sb, sr, sc, fshape = ctx.geom
         dout = _c(dout)
-        df = torch.zeros((B, num, R), dtype=_F32, device=f2.device)
+        df = torch.empty((B, num, R), dtype=_F32, device=f2.device)
+        ws = torch.empty(_lib.load().objgan_masked_max_backward_ws_floats(B, num, R, P), dtype=_F32, device=f2.device)
         _lib.call("objgan_masked_max_backward", _p(f2), _p(m), _p(dout), _p(df), B, num, R, P,
-                  sb, sr, sc, _stream())
+                  sb, sr, sc, _p(ws), _stream())
         return df.reshape(fshape), None, None, None
 
 
@@ -1154,7 +1164,7 @@ class _LiftTapsFn(torch.autograd.Function):
                       _p(rows[3]), _p(rows[4]), _p(rows[5]), _p(cols[3]), _p(cols[4]), _p(cols[5]), _stream())
         if ctx.has_bias and ctx.needs_input_grad[1]:
             db = torch.empty(Mo, dtype=_F32, device=dy.device)
-            _lib.call("objgan_channel_sum", _p(dy), _p(db), N, Mo, SH * SW, _stream())
+            _channel_sum(dy, db, N, Mo, SH * SW)
         return dz, db, None, None
 
 
