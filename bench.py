@@ -55,11 +55,12 @@ def cat_names(math):
     """rocprofv3's names of the kernel instances behind the library's timing categories (leading template
     arguments: tile height, LDS-free form / arithmetic)."""
     m = MATH_IDS[math]
-    return (["conv_igemm3_kernel<%d, false, %d, 4>" % (tm, m) for tm in range(1, 8)] +
+    mi = 3 if m == 1 else m          # bf16 mode: the matrix kernels read the bf16 channels-last copy (template value 3)
+    return (["conv_igemm3_kernel<%d, false, %d, 4>" % (tm, mi) for tm in range(1, 8)] +
             ["conv_wgrad2_kernel<%d, %d" % (tm, m) for tm in range(1, 8)] +
             ["conv_thin_kernel", "conv_thin3x3_kernel", "conv_igemm_kernel", "conv_wgrad_kernel",
              "conv_igemm3_kernel<1, true, %d, 4>" % m] + ["conv_wgrad3_kernel<%d, %d" % (tm, m) for tm in range(1, 8)] +
-            ["conv_igemm3_kernel<%d, false, %d, 8>" % (tm, m) for tm in range(1, 8)] +
+            ["conv_igemm3_kernel<%d, false, %d, 8>" % (tm, mi) for tm in range(1, 8)] +
             ["conv_wgrad3_kernel<%d, %d, *, 0, 8>" % (tm, m) for tm in range(1, 8)])
 PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 

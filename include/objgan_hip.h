@@ -49,6 +49,18 @@ int objgan_roi_align_backward(const float* top_grad, const float* rois, float* b
                               int batch_size, int num_rois, int roi_cols, int channels,
                               int height, int width, int aligned_height, int aligned_width,
                               float spatial_scale, void* stream);
+
+/* The same adjoint with a FIXED summation order (bit-reproducible): the taps of an image's ROI samples are sorted once
+ * by anchor pixel (stable) into a table in `ws`, and every (pixel, channel) gathers its taps in a fixed order.  The
+ * reference's kernel (and objgan_roi_align_backward) leaves the order of its atomicAdds unspecified.  ws: at least
+ * objgan_roi_align_backward_ws_floats(...) floats; shapes the query returns 0 for (more than 256 rois, maps over
+ * ~5K pixels) and ws == NULL take objgan_roi_align_backward's path. */
+long objgan_roi_align_backward_ws_floats(int batch_size, int num_rois, int channels, int height, int width,
+                                         int aligned_height, int aligned_width);
+int objgan_roi_align_backward_ordered(const float* top_grad, const float* rois, float* bottom_grad,
+                                      int batch_size, int num_rois, int roi_cols, int channels,
+                                      int height, int width, int aligned_height, int aligned_width,
+                                      float spatial_scale, float* ws, long ws_floats, void* stream);
 /* avg_pool2d(kernel_size=2, stride=1) tail of RoIAlignAvg (modules/roi_align.py:26-29). */
 int objgan_avgpool2s1_forward(const float* in, float* out, long planes, int ih, int iw, void* stream);
 int objgan_avgpool2s1_backward(const float* grad_out, float* grad_in, long planes, int ih, int iw,
@@ -69,7 +81,9 @@ int objgan_conv_bank_layout(int N, int C, int H, int W, int M, int Tg, int PH, i
  * wt_packed=1: wt still holds the packed bank written by an earlier call with the same w, taps,
  * transpose flag, math and input size class (the caller caches it while w is unchanged); 0: pack now.
  * math: 0 = fp32 MFMA (exact fp32 fmaf chains); 1 = mixed precision (BASELINE config 5): operands rounded
- * to bf16 (RNE) at the matrix-core inputs, fp32 accumulation, fp32 tensors in HBM; 2 = "bf16x3": fp32 results on
+ * to bf16 (RNE), fp32 accumulation, fp32 tensors at the boundary -- the call first writes a bf16 channels-last copy
+ * [N][H][W][ceil16(C)] of x into ws and the matrix kernel reads its pixel operand from that copy as 16-byte vectors
+ * (without ws: channel-strided fp32 gathers converted in registers, same values); 2 = "bf16x3": fp32 results on
  * the bf16 matrix pipe -- every fp32 operand is split exactly into three bf16 pieces (24 = 8 + 8 + 8 significand
  * bits) and the six largest of the nine partial products are accumulated in fp32; what is dropped is below 2^-24
  * of a product.  Outputs with <= 32 channels always run on the fp32 VALU kernels. */
@@ -81,10 +95,10 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
                       int OHf, int OWf, int osh, int osw, int ooh, int oow,
                       int act, int y_prezeroed, int wt_packed, int math, float* ring,
                       float* ws, long ws_floats, void* stream);
-/* ws: split-K workspace.  Small-grid / long-K launches are split along K: every split stores its partial output into
+/* ws: the bf16 channels-last copy of x (math 1), then the split-K workspace.  Small-grid / long-K launches are split along K: every split stores its partial output into
  * its own slot of ws and a second kernel sums the slots in split order (+ bias, activation) -- bit-reproducible, no
  * zero-fill of y, no atomics.  objgan_conv_igemm_ws_floats (host-only, same geometry arguments; ring != 0 when a ring
- * buffer is passed) says how many floats a call needs (0 for most); a call that needs them and gets fewer returns 0. */
+ * buffer is passed) says how many floats a call needs (math 0 / 2: 0 for most); a call that needs them and gets fewer returns 0. */
 long objgan_conv_igemm_ws_floats(int N, int C, int H, int W, int upsample, int pad_mode,
                                  int Cout, int Cin, int Torig, int transpose, int Tg,
                                  int PH, int PW, int stride, int OHf, int OWf, int osh, int osw,
@@ -97,11 +111,13 @@ int objgan_reflect_ring_fold(const float* ring, float* y, long planes, int H, in
 /* Data gradient of a stride-2 convolution whose four output parity phases have the same number
  * of taps (k=4, pad 1, even sizes): one launch for all phases.  x = dY [N,Cout,OH,OW],
  * y = dX [N,Cin,2*PH,2*PW], fully written (no pre-zeroing).  dh/dw/src_tap: 4 x Tg entries, phase
- * p = (row parity << 1) | column parity.  wt: 4*ceil(1.5*Cin*Tg*ceil16(Cout)) floats; wt_packed as above. */
+ * p = (row parity << 1) | column parity.  wt: 4*ceil(1.5*Cin*Tg*ceil16(Cout)) floats; wt_packed as above.
+ * ws: objgan_conv_dgrad_s2_phases_ws_floats floats (math 1: the bf16 channels-last copy of dY, see below; else 0). */
+long objgan_conv_dgrad_s2_phases_ws_floats(int N, int Cout, int OH, int OW, int math);
 int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float* wt,
                                 int N, int Cout, int OH, int OW, int Cin, int Torig,
                                 int Tg, const int* dh, const int* dw, const int* src_tap,
-                                int PH, int PW, int wt_packed, int math, void* stream);
+                                int PH, int PW, int wt_packed, int math, float* ws, long ws_floats, void* stream);
 /* dw[co][ci][kh][kw] = (accumulate ? dw : 0) + sum dy * x; ksize in {1,3,4}.  The reduction over pixels is split
  * across workgroups; the partial tiles go through ws (objgan_conv_wgrad_ws_floats floats, host-only query) and are
  * summed in split order: the weight gradient is bit-reproducible and dw needs no zero-fill. */

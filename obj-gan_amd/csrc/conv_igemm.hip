@@ -56,6 +56,8 @@ struct IgemmArgs {
     int LH, LW;          // logical source dims seen by the taps (2H x 2W when upsampling)
     int M, Mpad, K, Kpad;   // K = T*C (algorithmic), Kpad = T*Cp (padded, what the loop walks)
     int math;               // 0: fp32 MFMA, 1: bf16 inputs (RNE) on the bf16 MFMA, fp32 accumulation
+    int nhwc;               // bf16 mode: 1 = the pixel operand comes from a bf16 [N][H][W][Cp] copy of x that
+                            // run_igemm2 makes in the caller's workspace (conv_igemm3_kernel<.., 3, ..>)
     int Krow;               // row pitch of the [M][Krow] bank in elements (= Kpad; bf16 bank: Kpad rounded up to 32)
     int T, Cp;              // taps, channels rounded up to 16
     int m_begin, m_end;  // output-channel rows covered by this launch
@@ -669,6 +671,34 @@ __device__ __forceinline__ void pack_item(const PackArgs& a, long i, int Kpad, i
     else pack_element(a, (unsigned)i, Kpad);
 }
 
+// fp32 [N][C][HW] -> bf16 (RNE) channels-last [N][HW][Cp], channels C..Cp-1 zero: the pixel operand of the bf16 mode.
+// 64 channels x 64 pixels per workgroup through LDS: 256-byte rows in, 128-byte runs per pixel out.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ out,
+                                                                int C, int HW, int Cp) {
+    __shared__ float tile[64][65];
+    const int n = blockIdx.z;
+    const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const float* xn = x + (size_t)n * C * HW;
+#pragma unroll 4
+    for (int cc = ty; cc < 64; cc += 4) {
+        const int c = c0 + cc, p = p0 + tx;
+        tile[cc][tx] = (c < C && p < HW) ? xn[(size_t)c * HW + p] : 0.f;
+    }
+    __syncthreads();
+    const int cg = threadIdx.x & 7;                    // 8 channels = one 16-byte store
+    if (c0 + cg * 8 >= Cp) return;
+#pragma unroll
+    for (int pp = threadIdx.x >> 3; pp < 64; pp += 32) {
+        const int p = p0 + pp;
+        if (p >= HW) break;
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (__bf16)tile[cg * 8 + j][pp];
+        *reinterpret_cast<bf16x8*>(out + ((size_t)n * HW + p) * Cp + c0 + cg * 8) = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
     const int Kpad = a.Tg * a.Cp;
     const int Krow = a.m_major == 3 ? (Kpad + 31) / 32 * 32 : (a.m_major == 4 ? 3 * Kpad : Kpad);
@@ -1242,7 +1272,10 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
     // [M][Kpad/16][h,m,l][16] bf16 = 96 bytes per row and step, LDS row pitch 112 bytes (an odd multiple of 16:
     // the 16 lanes of a ds_read_b128 group fall on 16 different 16-byte slots); the pixel fragment is split in
     // registers (~44 VALU instructions per step next to 6 * TM MFMAs).
-    constexpr bool BF = MATH == 1, SP = MATH == 2;
+    // 3 (NH): as 1, with the pixel operand read from a bf16 channels-last copy of the source, [N][H][W][Cp]
+    // (nchw_to_nhwc_bf16_kernel): the eight consecutive k of a lane are eight consecutive channels of its pixel -- one
+    // 16-byte load, no conversion -- instead of eight channel-strided dword gathers and eight conversions.
+    constexpr bool NH = MATH == 3, BF = MATH == 1 || NH, SP = MATH == 2;
     constexpr int BM = 32 * TM;
     constexpr int BN = 32 * NW;
     constexpr int BK = 16;
@@ -1259,7 +1292,8 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
     // group); the bank is bf16 [M][Krow], so a row piece is again 64 bytes per iteration and the
     // LDS image / fragment reads keep their 80-byte pitch.
     constexpr int ESZ = (BF || SP) ? 2 : 4;
-    constexpr int NB = BF ? 16 : 8;                   // gathered pixel-operand values per lane and iteration
+    constexpr int NBC = NH ? 4 : 8;                   // registers per 16-channel chunk of the pixel operand
+    constexpr int NB = BF ? 2 * NBC : 8;              // pixel-operand registers per lane and iteration
 
     __shared__ __attribute__((aligned(16))) float lds[ALDS ? (SP ? 3 : 2) * TILE : 4];
 
@@ -1283,7 +1317,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
     const int tapbase = phase * 8;
     const int HW = a.H * a.W;
     __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.x, 0, (int)((unsigned)a.N * a.C * HW * 4u), OG_BUF_FLAGS);
+        (void*)a.x, 0, NH ? (int)((unsigned)a.N * HW * a.Cp * 2u) : (int)((unsigned)a.N * a.C * HW * 4u), OG_BUF_FLAGS);
     __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const char*)a.wt + (size_t)phase * a.M * a.Krow * ESZ), 0,
         (int)((unsigned)a.M * a.Krow * (unsigned)ESZ), OG_BUF_FLAGS);
@@ -1302,7 +1336,8 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
         const int pb = rem - pa * a.PW;
         ihb = pa * a.stride;
         iwb = pb * a.stride;
-        img_off = (unsigned)n * (unsigned)a.C * (unsigned)HW + (unsigned)(lrow * 8) * (unsigned)HW;
+        img_off = NH ? (unsigned)n * (unsigned)HW
+                     : (unsigned)n * (unsigned)a.C * (unsigned)HW + (unsigned)(lrow * 8) * (unsigned)HW;
     }
     const int us = a.upsample ? 1 : 0;
     const bool refl = a.pad_mode == 1;
@@ -1319,16 +1354,23 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
         const bool ok = pix_ok && (refl || inb);
         const int ihs = (refl ? ihr : ih) >> us;
         const int iws = (refl ? iwr : iw) >> us;
-        bvoff = ok ? (img_off + (unsigned)(ihs * a.W + iws)) * 4u : OG_OOB;
+        if (NH) bvoff = ok ? ((img_off + (unsigned)(ihs * a.W + iws)) * (unsigned)a.Cp + (unsigned)(lrow * 8)) * 2u : OG_OOB;
+        else bvoff = ok ? (img_off + (unsigned)(ihs * a.W + iws)) * 4u : OG_OOB;
     };
     int t_ld, cb_ld;
     const int spt = a.Cp / BK;
     // channels past C (padding of the last 16-channel chunk) read finite neighbouring data or the
-    // range-check zero; their filter entries are zero
+    // range-check zero; their filter entries are zero  (NH: the copy holds zeros there)
     auto load_b8 = [&](float* rb) {
+        if (NH) {
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, bvoff, cb_ld * 2, 0));
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, bvoff, (cb_ld + i) * HW * 4, 0));
+            for (int i = 0; i < 4; ++i) rb[i] = v[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, bvoff, (cb_ld + i) * HW * 4, 0));
+        }
         cb_ld += BK;
         if (cb_ld >= a.Cp) {
             cb_ld = 0;
@@ -1338,7 +1380,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
     };
     auto load_b = [&](float (&rb)[NB]) {
         load_b8(&rb[0]);
-        if (BF) load_b8(&rb[NB - 8]);      // second 16-channel chunk (past the last one: zero filter entries)
+        if (BF) load_b8(&rb[NBC]);         // second 16-channel chunk (past the last one: zero filter entries)
     };
 
     // ---- row operand (filter bank [M][Kpad])
@@ -1455,9 +1497,17 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
         if (BF) {
             bf16x8 bq[2];
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h) {
+                if (NH) {
+                    f32x4 v;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) bq[h][j] = (__bf16)rb[(NB - 8) * h + j];
+                    for (int j = 0; j < 4; ++j) v[j] = rb[NBC * h + j];
+                    bq[h] = __builtin_bit_cast(bf16x8, v);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bq[h][j] = (__bf16)rb[NBC * h + j];
+                }
+            }
             if (ALDS) {
                 const float* T = lds + cur * TILE;
 #pragma unroll
@@ -2303,6 +2353,22 @@ static int launch_igemm2(const IgemmArgs& a, int TM, dim3 grid, hipStream_t s, i
     if (og_trace())
         fprintf(stderr, "OGTRACE igemm TM=%d NW=%d M=%d rows=%d C=%d T=%d Npix=%d grid=%u,%u,%u H=%d W=%d stride=%d\n", TM, nw, a.M,
                 a.m_end - a.m_begin, a.C, a.T, a.N * a.PH * a.PW, grid.x, grid.y, grid.z, a.H, a.W, a.stride);
+    if (a.math == 1 && a.nhwc) {           // bf16, channels-last pixel operand
+#define OG_IGNH(TMv)                                                                                                  \
+        if (nw == 8) hipLaunchKernelGGL((conv_igemm3_kernel<TMv, false, 3, 8>), grid, dim3(512), 0, s, a);            \
+        else hipLaunchKernelGGL((conv_igemm3_kernel<TMv, false, 3, 4>), grid, dim3(256), 0, s, a);
+        switch (TM) {
+            case 1: OG_IGNH(1) break;
+            case 2: OG_IGNH(2) break;
+            case 3: OG_IGNH(3) break;
+            case 4: OG_IGNH(4) break;
+            case 5: OG_IGNH(5) break;
+            case 6: OG_IGNH(6) break;
+            default: OG_IGNH(7) break;
+        }
+#undef OG_IGNH
+        return og_launch_status();
+    }
     if (a.math == 2 && nw == 8) {          // 8-wave workgroups: 32 * TM rows x 256 pixels
         switch (TM) {
             case 1: hipLaunchKernelGGL((conv_igemm3_kernel<1, false, 2, 8>), grid, dim3(512), 0, s, a); break;
@@ -2364,7 +2430,7 @@ static Igemm2Plan igemm2_plan(const IgemmArgs& a, int y_prezeroed) {
     // layers 179 vs 158 TFLOP/s; with 8 waves the block rows are as tall as the row count allows)
     p.nw = 4;
     const int tm_tall = og_cdiv(groups, og_cdiv(groups, 7));
-    if (a.math == 2 && tm_tall >= 4 && og_nw8_min() > 0 &&
+    if ((a.math == 2 || (a.math == 1 && a.nhwc)) && tm_tall >= 4 && og_nw8_min() > 0 &&
         (long)og_cdiv(groups, 7) * og_cdiv(Npix, 256) * nph >= og_nw8_min()) p.nw = 8;
     p.tiles_n = og_cdiv(Npix, 32 * p.nw);
     // (Carrying the 2 / 4 rows that 194 / 388 channels have beyond a multiple of 32 on the VALU next to the
@@ -2398,14 +2464,30 @@ static Igemm2Plan igemm2_plan(const IgemmArgs& a, int y_prezeroed) {
 
 // floats of split-K workspace run_igemm2 wants for this plan (0: one split, or a partial-coverage launch that
 // accumulates into the pre-zeroed output)
+// bf16 mode: floats of workspace the channels-last bf16 copy of the source takes (0: not this mode / too large for
+// the 32-bit buffer range)
+static long igemm2_nhwc_floats(int math, int N, int H, int W, int Cp) {
+    if (math != 1 || (double)N * H * W * Cp * 2.0 >= 4.0e9) return 0;
+    return ((long)N * H * W * Cp / 2 + 3) & ~3L;
+}
 static long igemm2_ws_floats(const IgemmArgs& a, const Igemm2Plan& p) {
-    if (p.splits <= 1 || !p.full_cover) return 0;
+    const long nh = a.nhwc ? igemm2_nhwc_floats(a.math, a.N, a.H, a.W, a.Cp) : 0;
+    if (p.splits <= 1 || !p.full_cover) return nh;
     const long seg = (long)a.N * a.M * a.OHf * a.OWf + (a.ring ? (long)a.N * a.M * (2 * a.PW + 2 * a.PH) : 0);
-    return seg * p.splits;
+    return nh + seg * p.splits;
 }
 
 static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed, float* ws, long ws_floats) {
+    if (a.nhwc && !ws) a.nhwc = 0;              // no workspace: fp32 NCHW gathers (conv_igemm3_kernel<.., 1, ..>)
     const Igemm2Plan p = igemm2_plan(a, y_prezeroed);
+    if (a.nhwc) {                               // bf16 channels-last copy of the source: first part of the workspace
+        const long nh = igemm2_nhwc_floats(a.math, a.N, a.H, a.W, a.Cp);
+        if (ws_floats < igemm2_ws_floats(a, p)) return OG_BAD_ARGS;
+        hipLaunchKernelGGL(nchw_to_nhwc_bf16_kernel, dim3(og_cdiv(a.H * a.W, 64), og_cdiv(a.Cp, 64), a.N), dim3(256), 0, s,
+                           a.x, reinterpret_cast<__bf16*>(ws), a.C, a.H * a.W, a.Cp);
+        a.x = ws;
+        ws += nh; ws_floats -= nh;
+    }
     const int Npix = a.N * a.PH * a.PW;
     const int nph = a.nphase > 1 ? a.nphase : 1;
     const int TM = p.TM, full_rows = p.full_rows, rest = p.rest, tiles_n = p.tiles_n, nw = p.nw;
@@ -2420,7 +2502,7 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed, float* ws, lo
     if (splits > 1) {
         a.ksplit_steps = p.ksplit_steps;
         a.bias = nullptr; a.act = OG_ACT_NONE;
-        const long need = igemm2_ws_floats(a, p);
+        const long need = igemm2_ws_floats(a, p) - (a.nhwc ? igemm2_nhwc_floats(a.math, a.N, a.H, a.W, a.Cp) : 0);
         if (need > 0) {                       // two-level reduction through the caller's workspace
             if (!ws || ws_floats < need) return OG_BAD_ARGS;
             a.ws = ws; a.ws_stride = y_elems + ring_elems;
@@ -2602,6 +2684,7 @@ static int og_igemm_setup(PackArgs& p, IgemmArgs& a, int& MT, const float* x, co
     a.LH = upsample ? 2 * H : H; a.LW = upsample ? 2 * W : W;
     a.M = M; a.Mpad = p.Mpad; a.K = C * Tg; a.Kpad = Tg * p.Cp; a.T = Tg; a.Cp = p.Cp;
     a.math = kmath;
+    a.nhwc = igemm2_nhwc_floats(kmath, N, H, W, p.Cp) > 0 ? 1 : 0;
     a.Krow = og_krow(a.Kpad, kmath);
     a.m_begin = 0; a.m_end = M;
     a.PH = PH; a.PW = PW; a.OHf = OHf; a.OWf = OWf;
@@ -2679,7 +2762,7 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
 int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float* wt,
                                 int N, int Cout, int OH, int OW, int Cin, int Torig,
                                 int Tg, const int* dh, const int* dw, const int* src_tap,
-                                int PH, int PW, int wt_packed, int math, void* stream) {
+                                int PH, int PW, int wt_packed, int math, float* ws, long ws_floats, void* stream) {
     OG_ENTRY();
     if (Tg < 1 || Tg > 8) return OG_BAD_ARGS;
     if (math < 0 || math > 2) return OG_BAD_ARGS;
@@ -2707,6 +2790,7 @@ int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float*
     a.N = N; a.C = C; a.H = OH; a.W = OW; a.LH = OH; a.LW = OW;
     a.M = M; a.Mpad = (M + 127) / 128 * 128; a.K = C * Tg; a.Kpad = Kpad; a.T = Tg; a.Cp = Cp;
     a.math = math; a.Krow = Krow;
+    a.nhwc = igemm2_nhwc_floats(math, N, OH, OW, Cp) > 0 ? 1 : 0;
     a.m_begin = 0; a.m_end = M;
     a.PH = PH; a.PW = PW; a.OHf = 2 * PH; a.OWf = 2 * PW;
     a.osh = 2; a.osw = 2; a.ooh = 0; a.oow = 0;
@@ -2722,7 +2806,12 @@ int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float*
     for (int ph = 0; ph < 4; ++ph)
         for (int t = 0; t < Tg; ++t)
             a.tap[ph * 8 + t] = (int)(((unsigned)dw[ph * Tg + t] << 16) | ((unsigned)dh[ph * Tg + t] & 0xffffu));
-    return run_igemm2(a, s, 0, nullptr, 0);     // (four phases in one launch: never split along K)
+    return run_igemm2(a, s, 0, ws, ws_floats);  // (four phases in one launch: never split along K)
+}
+
+// floats of workspace objgan_conv_dgrad_s2_phases takes (bf16 mode: the channels-last bf16 copy of dY; else 0)
+long objgan_conv_dgrad_s2_phases_ws_floats(int N, int Cout, int OH, int OW, int math) {
+    return igemm2_nhwc_floats(math, N, OH, OW, (Cout + 15) / 16 * 16);
 }
 
 // y [planes, H, W] += mirror of ring [planes, 2*(W+2) + 2*(H+2)] (written by objgan_conv_igemm in ring mode).

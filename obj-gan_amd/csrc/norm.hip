@@ -27,16 +27,31 @@ struct NormGeom {
 
 __device__ __forceinline__ float og_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
 
-// Statistics workspace of one call: [2G totals][G tickets][2 * G * P partial pairs] (og_ordered_sum, common.h): the
-// per-workgroup partial sums of a group are combined in slot order by the last workgroup to arrive -- no fp32 atomics.
-struct NormWs { float* sums; int* cnt; float* part; int P; };
+// Statistics workspace of one call: [2G totals][2 * G * P partial pairs].  Every workgroup of a statistics launch
+// stores the partial sums of its slice into its own slot; norm_partials_sum_kernel (one thread per group, launched
+// where round 2 had the memset of the atomics' target) adds the P slots of a group in slot order: bit-reproducible
+// statistics.  (A single-launch form -- ticket + last arriver sums -- was measured first: the agent-scope release
+// fence every workgroup needs writes the XCD's L2 back, 150-200 us per launch against 25.)
+struct NormWs { float* sums; float* part; int P; };
+__device__ __forceinline__ void og_store_partial2(const NormWs& ws, int g, int idx, float s1, float s2) {
+    if (ws.P == 1) { ws.sums[2 * g] = s1; ws.sums[2 * g + 1] = s2; return; }
+    float* slot = ws.part + ((size_t)g * ws.P + idx) * 2;
+    slot[0] = s1; slot[1] = s2;
+}
+__global__ __launch_bounds__(256) void norm_partials_sum_kernel(NormWs ws, int G) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const float* p = ws.part + (size_t)g * ws.P * 2;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < ws.P; ++k) { a += p[2 * k]; b += p[2 * k + 1]; }
+    ws.sums[2 * g] = a; ws.sums[2 * g + 1] = b;
+}
 
 // ---- statistics ------------------------------------------------------------------------
 // grid = (G, S).  sums[g*2 + {0,1}] must be zero on entry.
 __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict__ x,
                                                          NormWs ws, NormGeom gm) {
     __shared__ float red[16];
-    __shared__ int s_flag;
     const int g = blockIdx.x;
     const int planes = gm.per_channel ? gm.N : 1;
     const size_t base = gm.per_channel ? (size_t)g * gm.HW : (size_t)g * gm.HW;
@@ -56,8 +71,7 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
     }
     s1 = og_block_sum(s1, red);
     s2 = og_block_sum(s2, red);
-    const float v[2] = {s1, s2};
-    og_ordered_sum<2>(v, ws.part, ws.cnt, ws.sums, g, blockIdx.y, ws.P, &s_flag);
+    if (threadIdx.x == 0) og_store_partial2(ws, g, blockIdx.y, s1, s2);
 }
 
 // mean/rstd per group; optional BatchNorm running-statistics update (momentum, unbiased var)
@@ -153,7 +167,6 @@ __global__ __launch_bounds__(256) void norm_bwd_stats_kernel(
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
     NormWs ws, NormGeom gm, int mode) {
     __shared__ float red[16];
-    __shared__ int s_flag;
     const int g = blockIdx.x;
     const int planes = gm.per_channel ? gm.N : 1;
     const long total = (long)planes * gm.HW;
@@ -173,8 +186,7 @@ __global__ __launch_bounds__(256) void norm_bwd_stats_kernel(
     }
     s1 = og_block_sum(s1, red);
     s2 = og_block_sum(s2, red);
-    const float v[2] = {s1, s2};
-    og_ordered_sum<2>(v, ws.part, ws.cnt, ws.sums, g, blockIdx.y, ws.P, &s_flag);
+    if (threadIdx.x == 0) og_store_partial2(ws, g, blockIdx.y, s1, s2);
 }
 
 // dx = gamma * rstd * (dz - mean(dz) - xhat * mean(dz * xhat))
@@ -210,7 +222,6 @@ __device__ __forceinline__ float og_group_mean(const float* p, int g) { return p
 __global__ __launch_bounds__(256) void norm_stats_plane_kernel(const float* __restrict__ x,
                                                                NormWs ws, NormGeom gm) {
     __shared__ float red[16];
-    __shared__ int s_flag;
     const int plane = blockIdx.x;                       // n*C + c
     const int c = plane % gm.C;
     const int g = gm.per_channel ? c : plane;
@@ -229,8 +240,7 @@ __global__ __launch_bounds__(256) void norm_stats_plane_kernel(const float* __re
     s2 = og_block_sum(s2, red);
     // slot of this workgroup within its group: BatchNorm groups collect the N images x chunks, InstanceNorm the chunks
     const int idx = gm.per_channel ? (plane / gm.C) * (int)gridDim.y + (int)blockIdx.y : (int)blockIdx.y;
-    const float v[2] = {s1, s2};
-    og_ordered_sum<2>(v, ws.part, ws.cnt, ws.sums, g, idx, ws.P, &s_flag);
+    if (threadIdx.x == 0) og_store_partial2(ws, g, idx, s1, s2);
 }
 
 // Statistics of group g from its shifted sums (what norm_finalize_kernel computes); when `fin.sums` is set
@@ -335,7 +345,6 @@ __global__ __launch_bounds__(256) void norm_bwd_stats_plane_kernel(
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
     NormWs ws, NormGeom gm) {
     __shared__ float red[16];
-    __shared__ int s_flag;
     const int Co = MODE == OG_NORM_GLU ? gm.C / 2 : gm.C;
     const int plane = blockIdx.x;
     const int n = plane / Co;
@@ -371,11 +380,9 @@ __global__ __launch_bounds__(256) void norm_bwd_stats_plane_kernel(
     a2 = og_block_sum(a2, red);
     if (MODE == OG_NORM_GLU) { b1 = og_block_sum(b1, red); b2 = og_block_sum(b2, red); }
     const int idx = gm.per_channel ? n * (int)gridDim.y + (int)blockIdx.y : (int)blockIdx.y;
-    const float va[2] = {a1, a2};
-    og_ordered_sum<2>(va, ws.part, ws.cnt, ws.sums, ga, idx, ws.P, &s_flag);
-    if (MODE == OG_NORM_GLU) {
-        const float vb[2] = {b1, b2};
-        og_ordered_sum<2>(vb, ws.part, ws.cnt, ws.sums, gb, idx, ws.P, &s_flag);
+    if (threadIdx.x == 0) {
+        og_store_partial2(ws, ga, idx, a1, a2);
+        if (MODE == OG_NORM_GLU) og_store_partial2(ws, gb, idx, b1, b2);
     }
 }
 
@@ -598,13 +605,12 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     }
 }
 
-// per-channel sum over (N, HW): out[c] = sum_n sum_i x[n, c, i]   (conv bias gradient); grid (C, S), the S partial
-// sums of a channel are combined in order (og_ordered_sum): ws = [C tickets][C * S partials]
+// per-channel sum over (N, HW): out[c] = sum_n sum_i x[n, c, i]   (conv bias gradient); grid (C, S): S partial sums
+// per channel into ws[c][S], added in order by channel_partials_sum_kernel
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x,
                                                           float* __restrict__ out, int N, int C, int HW,
-                                                          int* __restrict__ cnt, float* __restrict__ part) {
+                                                          float* __restrict__ part) {
     __shared__ float red[16];
-    __shared__ int s_flag;
     const int c = blockIdx.x;
     const long total = (long)N * HW;
     const long chunk = (total + gridDim.y - 1) / gridDim.y;
@@ -617,8 +623,17 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
         s += x[((size_t)n * C + c) * HW + i];
     }
     s = og_block_sum(s, red);
-    const float v[1] = {s};
-    og_ordered_sum<1>(v, part, cnt, out, c, blockIdx.y, gridDim.y, &s_flag);
+    if (threadIdx.x == 0) {
+        if (gridDim.y == 1) out[c] = s; else part[(size_t)c * gridDim.y + blockIdx.y] = s;
+    }
+}
+__global__ __launch_bounds__(256) void channel_partials_sum_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                                   int C, int S) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f;
+    for (int k = 0; k < S; ++k) a += part[(size_t)c * S + k];
+    out[c] = a;
 }
 
 #define OG_IN_FUSED_MAX 65536        // largest plane (elements) the one-kernel InstanceNorm takes: 256 KB, two passes
@@ -641,20 +656,19 @@ static inline int norm_partials(int N, int C, int HW, int per_channel) {
     if (norm_planes(N, C, HW)) return (per_channel ? N : 1) * og_cdiv(HW, OG_NORM_CHUNK);
     return norm_splits(G, per_channel ? (long)N * HW : HW);
 }
-static inline NormWs norm_ws(float* buf, int G, int P, hipStream_t s) {
-    NormWs w{buf, reinterpret_cast<int*>(buf + 2 * (size_t)G), buf + 3 * (size_t)G, P};
-    if (P > 1) (void)hipMemsetAsync(w.cnt, 0, sizeof(int) * (size_t)G, s);       // tickets of og_ordered_sum
-    return w;
+static inline NormWs norm_ws(float* buf, int G, int P) { return NormWs{buf, buf + 2 * (size_t)G, P}; }
+static inline void norm_sum_partials(const NormWs& ws, int G, hipStream_t s) {
+    if (ws.P > 1) hipLaunchKernelGGL(norm_partials_sum_kernel, dim3(og_cdiv(G, 256)), dim3(256), 0, s, ws, G);
 }
 
 extern "C" {
 
 // Floats of statistics workspace (`sums` of objgan_norm_forward, `bsums` of objgan_norm_backward) for these sizes:
-// [2G totals][G tickets][2 * G * P partial pairs], P = workgroups per group of the statistics launch.  Host-only.
+// [2G totals][2 * G * P partial pairs], P = workgroups per group of the statistics launch.  Host-only.
 long objgan_norm_ws_floats(int N, int C, int HW, int per_channel) {
     if (N <= 0 || C <= 0 || HW <= 0) return 0;
     const long G = per_channel ? C : (long)N * C;
-    return 3 * G + 2 * G * norm_partials(N, C, HW, per_channel);
+    return 2 * G + 2 * G * norm_partials(N, C, HW, per_channel);
 }
 
 // Forward: statistics + apply.  Workspaces: sums [objgan_norm_ws_floats] (totals first), mean [G], rstd [G].
@@ -687,13 +701,14 @@ int objgan_norm_forward(const float* x, float* y, const float* residual,
             hipLaunchKernelGGL((in_fwd_fused_kernel<OG_NORM_NONE>), grid, dim3(256), 0, s, x, residual, y, mean, rstd, gm, eps);
         return og_launch_status();
     }
-    const NormWs ws = norm_ws(sums, G, norm_partials(N, C, HW, per_channel), s);
+    const NormWs ws = norm_ws(sums, G, norm_partials(N, C, HW, per_channel));
     if (planes) {
         hipLaunchKernelGGL(norm_stats_plane_kernel, dim3(N * C, chunks), dim3(256), 0, s, x, ws, gm);
     } else {
         dim3 grid(G, norm_splits(G, per_group));
         hipLaunchKernelGGL(norm_stats_kernel, grid, dim3(256), 0, s, x, ws, gm);
     }
+    norm_sum_partials(ws, G, s);
     if (planes) {
         dim3 grid(N * Co, chunks);
         const NormFin fin{sums, mean, rstd, running_mean, running_var, eps, momentum};
@@ -766,13 +781,14 @@ int objgan_norm_backward(const float* x, const float* dy, const float* mean, con
             hipLaunchKernelGGL((in_bwd_fused_kernel<OG_NORM_NONE>), grid, dim3(256), 0, s, x, dy, mean, rstd, dx, gm);
         return og_launch_status();
     }
-    const NormWs ws = norm_ws(bsums, G, norm_partials(N, C, HW, per_channel), s);
+    const NormWs ws = norm_ws(bsums, G, norm_partials(N, C, HW, per_channel));
     if (planes) {
         const int Co = mode == OG_NORM_GLU ? C / 2 : C;
         dim3 grid(N * Co, og_cdiv(HW, OG_NORM_CHUNK));
 #define OG_NB(MODE)                                                                                         \
         hipLaunchKernelGGL((norm_bwd_stats_plane_kernel<MODE>), grid, dim3(256), 0, s, x, dy, mean, rstd,   \
                            gamma, beta, ws, gm);                                                            \
+        norm_sum_partials(ws, G, s);                                                                        \
         hipLaunchKernelGGL((norm_bwd_apply_plane_kernel<MODE>), grid, dim3(256), 0, s, x, dy, mean, rstd,   \
                            gamma, beta, bsums, dx, gm, dgamma, dbeta);
         if (mode == OG_NORM_GLU) { OG_NB(OG_NORM_GLU) } else if (mode == OG_NORM_LRELU) { OG_NB(OG_NORM_LRELU) } else { OG_NB(OG_NORM_NONE) }
@@ -782,6 +798,7 @@ int objgan_norm_backward(const float* x, const float* dy, const float* mean, con
         dim3 grid(G, norm_splits(G, per_group));
         hipLaunchKernelGGL(norm_bwd_stats_kernel, grid, dim3(256), 0, s, x, dy, mean, rstd, gamma, beta,
                            ws, gm, mode);
+        norm_sum_partials(ws, G, s);
         const long total = (long)N * C * HW;
         hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(og_stream_grid(total, 256)), dim3(256), 0, s, x,
                            dy, mean, rstd, gamma, beta, bsums, dx, gm, mode);
@@ -803,10 +820,11 @@ int objgan_act_backward(const float* dy, const float* y, float* dz, long total, 
 }
 
 // out [C] is zeroed here, then out[c] = sum over n, i of x[n, c, i]
-// floats of workspace objgan_channel_sum needs: [C tickets][C * S partial sums]
+// floats of workspace objgan_channel_sum needs: [C * S partial sums]
 long objgan_channel_sum_ws_floats(int N, int C, int HW) {
     if (N <= 0 || C <= 0 || HW <= 0) return 0;
-    return (long)C * (1 + norm_splits(C, (long)N * HW));
+    const int S = norm_splits(C, (long)N * HW);
+    return S > 1 ? (long)C * S : 0;
 }
 
 int objgan_channel_sum(const float* x, float* out, int N, int C, int HW, float* ws, void* stream) {
@@ -815,10 +833,9 @@ int objgan_channel_sum(const float* x, float* out, int N, int C, int HW, float* 
     hipStream_t s = (hipStream_t)stream;
     const int S = norm_splits(C, (long)N * HW);
     if (S > 1 && !ws) return OG_BAD_ARGS;
-    if (S > 1) (void)hipMemsetAsync(ws, 0, sizeof(int) * (size_t)C, s);
     dim3 grid(C, S);
-    hipLaunchKernelGGL(channel_sum_kernel, grid, dim3(256), 0, s, x, out, N, C, HW, reinterpret_cast<int*>(ws),
-                       ws ? ws + C : nullptr);
+    hipLaunchKernelGGL(channel_sum_kernel, grid, dim3(256), 0, s, x, out, N, C, HW, ws);
+    if (S > 1) hipLaunchKernelGGL(channel_partials_sum_kernel, dim3(og_cdiv(C, 256)), dim3(256), 0, s, ws, out, C, S);
     return og_launch_status();
 }
 

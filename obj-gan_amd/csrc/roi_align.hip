@@ -143,28 +143,46 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(
     }
 }
 
-// Backward, privatised and ORDERED: one workgroup owns one (image, channel) plane.  The ROIs of its image are taken in
-// index order, ROI_BATCH at a time: their sample geometry and incoming gradients go to LDS, the bounding box of all
-// their taps is found (integer LDS min / max), and every pixel of the box GATHERS -- in sample order -- the taps that
-// land on it into the LDS copy of the plane (one writer per pixel).  Same per-term arithmetic as roi_align_bwd_kernel
-// (and the reference's CUDA kernel); the reference leaves the order of its atomicAdds unspecified, this kernel fixes
-// it: bit-reproducible.  r02's scatter form kept 36 of 256 threads busy (146 us per launch).
-#define ROI_BATCH 8
-#define ROI_LIST_MAX 256          // rois per image this kernel takes (the hot path has 10)
-__global__ __launch_bounds__(256) void roi_align_bwd_plane_kernel(
-    const float* __restrict__ top_grad, const float* __restrict__ rois,
-    float* __restrict__ bottom_grad, int num_rois,
-    int C, int H, int W, int AH, int AW, float spatial_scale) {
-    extern __shared__ __attribute__((aligned(16))) float plane[];      // H*W floats, then samples, then gradients
+// Backward, ORDERED: the taps of an image's ROI samples are the same for all C channel planes, so the samples are sorted
+// ONCE per image by the pixel of their first tap (stable: roi, then sample order -- roi_tap_table_kernel, one workgroup
+// per image), and every (touched pixel, channel) then GATHERS what lands on it in a fixed order: tap 0 of the samples
+// anchored at p, tap 1 of those anchored at p - 1, tap 2 of p - W, tap 3 of p - W - 1 (roi_align_bwd_gather_kernel).
+// One writer per element, no atomics on floats, bit-reproducible.  Same per-term arithmetic as roi_align_bwd_kernel
+// (and the reference's CUDA kernel, which leaves the order of its atomicAdds unspecified).  r02's privatised scatter
+// took 146 us per launch, an ordered gather without the table 609 us.
+#define ROI_TAB_MAX 256           // rois per call the table path takes (the hot path has 160: 16 images x 10)
+struct RoiTabDims { int maxs, maxp, o_start, o_sorted, o_smp, stride; };
+static inline RoiTabDims roi_tab_dims(int num_rois, int HW, int S) {
+    RoiTabDims d;
+    d.maxs = num_rois * S;                                   // samples of one image (all rois may belong to it)
+    d.maxp = HW < 4 * d.maxs ? HW : 4 * d.maxs;              // touched pixels
+    // ints per image: [hdr 4][pix maxp][start HW + 1][sorted maxs][smp 4 x maxs], every part 16-byte aligned
+    d.o_start = 4 + ((d.maxp + 3) & ~3);
+    d.o_sorted = d.o_start + ((HW + 1 + 3) & ~3);
+    d.o_smp = d.o_sorted + ((d.maxs + 3) & ~3);
+    d.stride = d.o_smp + 4 * d.maxs;
+    return d;
+}
+
+__global__ __launch_bounds__(256) void roi_tap_table_kernel(
+    const float* __restrict__ rois, int* __restrict__ ws, int num_rois,
+    int C, int H, int W, int AH, int AW, float spatial_scale, RoiTabDims d) {
+    extern __shared__ int tab_lds[];                                    // cnt[HW], st[HW], soff[maxs]
     const int HW = H * W;
     const int S = AH * AW;
-    RoiSample* smp = reinterpret_cast<RoiSample*>(plane + HW);          // [ROI_BATCH * S]
-    float* sd = reinterpret_cast<float*>(smp + ROI_BATCH * S);          // [ROI_BATCH * S]
-    __shared__ int s_list[ROI_LIST_MAX];                                // rois of this image, in index order
-    __shared__ int s_wave[4], s_box[4];                                 // box: rmin, rmax, cmin, cmax
-    const int c = blockIdx.x;
-    const int b = blockIdx.y;
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) plane[i] = 0.f;
+    int* cnt = tab_lds;
+    int* st = tab_lds + HW;
+    int* soff = tab_lds + 2 * HW;
+    __shared__ int s_list[ROI_TAB_MAX];                                 // rois of this image, in index order
+    __shared__ int s_wave[4];
+    __shared__ int s_scan[2 * 256];
+    const int b = blockIdx.x;
+    int* hdr = ws + (size_t)b * d.stride;
+    int* pix = hdr + 4;
+    int* start = hdr + d.o_start;
+    int* sorted = hdr + d.o_sorted;
+    int* smp = hdr + d.o_smp;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) cnt[i] = 0;
     // ordered compaction of the rois that belong to image b (ballot + prefix count per wave, waves in order)
     int nlist = 0;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -181,64 +199,118 @@ __global__ __launch_bounds__(256) void roi_align_bwd_plane_kernel(
         __syncthreads();
         int pos = nlist + __popcll(m & ((1ull << lane) - 1ull));
         for (int w = 0; w < wid; ++w) pos += s_wave[w];
-        if (mine && pos < ROI_LIST_MAX) s_list[pos] = r;
+        if (mine) s_list[pos] = r;
         nlist += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
         __syncthreads();
     }
-    nlist = min(nlist, ROI_LIST_MAX);
-    if (nlist == 0) return;                            // uniform: nothing lands in this plane
-    for (int k0 = 0; k0 < nlist; k0 += ROI_BATCH) {
-        const int n = min(ROI_BATCH, nlist - k0);
-        if (threadIdx.x == 0) { s_box[0] = H; s_box[1] = -1; s_box[2] = W; s_box[3] = -1; }
-        __syncthreads();
-        for (int i = threadIdx.x; i < n * S; i += blockDim.x) {
-            const int k = i / S, s = i - k * S;
-            const int r = s_list[k0 + k];
-            RoiSample g;
-            roi_geometry(rois + (size_t)r * 5, spatial_scale, H, W, AH, AW, s, g);
-            smp[i] = g;
-            sd[i] = top_grad[((size_t)r * C + c) * S + s];
-            if (g.valid) {
-                const int row = g.off / W, col = g.off - row * W;
-                atomicMin(&s_box[0], row); atomicMax(&s_box[1], row + 1);
-                atomicMin(&s_box[2], col); atomicMax(&s_box[3], col + 1);
-            }
-        }
-        __syncthreads();
-        const int r0 = s_box[0], r1 = min(s_box[1], H - 1), c0 = s_box[2], c1 = min(s_box[3], W - 1);
-        const int bw = c1 - c0 + 1, bh = r1 - r0 + 1;
-        if (bw > 0 && bh > 0) {
-            for (int i = threadIdx.x; i < bw * bh; i += blockDim.x) {
-                const int py = r0 + i / bw, px = c0 + i % bw;
-                const int pix = py * W + px;
-                float acc = 0.f;
-                for (int j = 0; j < n * S; ++j) {
-                    const RoiSample g = smp[j];
-                    if (!g.valid) continue;
-                    const int t = pix - g.off;          // 0, 1, W, W + 1: the four taps of the sample
-                    if (t != 0 && t != 1 && t != W && t != W + 1) continue;
-                    const float d = sd[j];
-                    // reference kernel.cu:137-140: `(1. - h_ratio)` is double, `(1 - w_ratio)` is FLOAT (int
-                    // literal); the two h_ratio terms are all-float products.
-                    const double omh = 1.0 - (double)g.h_ratio;
-                    const float omw = 1.0f - g.w_ratio;
-                    const float dh_ = d * g.h_ratio;
-                    float v;
-                    if (t == 0) v = (float)(((double)d * omh) * (double)omw);
-                    else if (t == 1) v = (float)(((double)d * omh) * (double)g.w_ratio);
-                    else if (t == W) v = dh_ * omw;
-                    else v = dh_ * g.w_ratio;
-                    acc += v;
-                }
-                plane[pix] += acc;
-            }
-        }
-        __syncthreads();
+    const int n_smp = nlist * S;
+    for (int i = threadIdx.x; i < n_smp; i += blockDim.x) {
+        const int k = i / S, sidx = i - k * S;
+        const int r = s_list[k];
+        RoiSample g;
+        roi_geometry(rois + (size_t)r * 5, spatial_scale, H, W, AH, AW, sidx, g);
+        const int off = g.valid ? g.off : -1;
+        soff[i] = off;
+        smp[4 * i + 0] = off;
+        smp[4 * i + 1] = __float_as_int(g.h_ratio);
+        smp[4 * i + 2] = __float_as_int(g.w_ratio);
+        smp[4 * i + 3] = (r << 8) | sidx;
+        if (off >= 0) atomicAdd(&cnt[off], 1);       // anchors have row <= H - 2 and column <= W - 2
     }
-    float* dst = bottom_grad + ((size_t)b * C + c) * HW;
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-        const float v = plane[i];
-        if (v != 0.f) dst[i] += v;
+    __syncthreads();
+    // exclusive scans over the pixels (samples anchored before a pixel; touched pixels before it): 256 contiguous slices
+    const int per = (HW + 255) / 256;
+    const int p0 = min(HW, (int)threadIdx.x * per), p1 = min(HW, p0 + per);
+    auto touched = [&](int p) -> int {
+        return (cnt[p] | (p >= 1 ? cnt[p - 1] : 0) | (p >= W ? cnt[p - W] : 0) | (p >= W + 1 ? cnt[p - W - 1] : 0)) != 0;
+    };
+    int e_sum = 0, n_sum = 0;
+    for (int p = p0; p < p1; ++p) { e_sum += cnt[p]; n_sum += touched(p); }
+    s_scan[2 * threadIdx.x] = e_sum; s_scan[2 * threadIdx.x + 1] = n_sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int e = 0, n = 0;
+        for (int t = 0; t < 256; ++t) {
+            const int a = s_scan[2 * t], c = s_scan[2 * t + 1];
+            s_scan[2 * t] = e; s_scan[2 * t + 1] = n;
+            e += a; n += c;
+        }
+        hdr[0] = n; hdr[1] = e; hdr[2] = n_smp; hdr[3] = 0;
+        start[HW] = e;
+    }
+    __syncthreads();
+    {
+        int e = s_scan[2 * threadIdx.x], n = s_scan[2 * threadIdx.x + 1];
+        for (int p = p0; p < p1; ++p) {
+            if (touched(p)) pix[n++] = p;
+            st[p] = e; start[p] = e;
+            e += cnt[p];
+        }
+    }
+    __syncthreads();
+    // stable placement: a sample's slot = start of its anchor + the number of earlier samples with the same anchor
+    for (int i = threadIdx.x; i < n_smp; i += blockDim.x) {
+        const int off = soff[i];
+        if (off < 0) continue;
+        int rank = 0;
+        for (int j = 0; j < i; ++j) rank += soff[j] == off;
+        sorted[st[off] + rank] = i;
+    }
+}
+
+// grid (channel slabs, images): 16 lanes per (touched pixel, channel) element.  The element's tap list (the four anchor
+// ranges, concatenated) is strided over the 16 lanes and their partial sums meet in a fixed butterfly: with the 1/16
+// spatial-scale of the hot path most of an image's 360 samples share a handful of anchors, and one lane walking 300
+// dependent loads took 284 us per launch.
+#define ROI_SUB 16
+__global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
+    const float* __restrict__ top_grad, const int* __restrict__ ws, float* __restrict__ bottom_grad,
+    int C, int HW, int W, int S, RoiTabDims d, int cpb) {
+    const int b = blockIdx.y;
+    const int* hdr = ws + (size_t)b * d.stride;
+    const int* pix = hdr + 4;
+    const int* start = hdr + d.o_start;
+    const int* sorted = hdr + d.o_sorted;
+    const int4* smp = reinterpret_cast<const int4*>(hdr + d.o_smp);
+    const int n_pix = hdr[0];
+    const int c0 = blockIdx.x * cpb;
+    const int nc = min(cpb, C - c0);
+    const int sub = threadIdx.x & (ROI_SUB - 1), grp = threadIdx.x / ROI_SUB;
+    for (int i = grp; i < n_pix * nc; i += 256 / ROI_SUB) {
+        const int ci = i / n_pix, ip = i - ci * n_pix;
+        const int c = c0 + ci;
+        const int p = pix[ip];
+        int k0[4], lim[4];                                              // range starts; cumulative lengths
+        int total = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int q = p - (t & 1) - (t >> 1) * W;                   // anchor whose tap t lands on p
+            k0[t] = q >= 0 ? start[q] : 0;
+            total += q >= 0 ? start[q + 1] - k0[t] : 0;
+            lim[t] = total;
+        }
+        float acc = 0.f;
+        for (int m = sub; m < total; m += ROI_SUB) {
+            const int t = (m >= lim[0]) + (m >= lim[1]) + (m >= lim[2]);
+            const int k = t == 0 ? k0[0] + m : t == 1 ? k0[1] + m - lim[0] : t == 2 ? k0[2] + m - lim[1] : k0[3] + m - lim[2];
+            const int4 g = smp[sorted[k]];
+            const float h_ratio = __int_as_float(g.y), w_ratio = __int_as_float(g.z);
+            const float dv = top_grad[((size_t)(g.w >> 8) * C + c) * S + (g.w & 255)];
+            // reference kernel.cu:137-140: `(1. - h_ratio)` is double, `(1 - w_ratio)` is FLOAT (int
+            // literal); the two h_ratio terms are all-float products.
+            const double omh = 1.0 - (double)h_ratio;
+            const float omw = 1.0f - w_ratio;
+            const float dh_ = dv * h_ratio;
+            float v;
+            if (t == 0) v = (float)(((double)dv * omh) * (double)omw);
+            else if (t == 1) v = (float)(((double)dv * omh) * (double)w_ratio);
+            else if (t == 2) v = dh_ * omw;
+            else v = dh_ * w_ratio;
+            acc += v;
+        }
+#pragma unroll
+        for (int o = ROI_SUB / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (sub == 0) bottom_grad[((size_t)b * C + c) * HW + p] += acc;
     }
 }
 
@@ -308,24 +380,59 @@ int objgan_roi_align_backward(const float* top_grad, const float* rois, float* b
                               int height, int width, int aligned_height, int aligned_width,
                               float spatial_scale, void* stream) {
     OG_ENTRY();
+    (void)batch_size;
     if (roi_cols != 5) return OG_BAD_ARGS;
     if (aligned_height * aligned_width > ROI_MAX_SAMPLES || aligned_height < 2 || aligned_width < 2)
         return OG_BAD_ARGS;
     if (num_rois <= 0 || channels <= 0) return OG_OK;
     const int S = aligned_height * aligned_width;
-    const size_t lds = (size_t)height * width * sizeof(float) + (size_t)ROI_BATCH * S * (sizeof(RoiSample) + sizeof(float));
-    if (batch_size > 0 && lds <= 64 * 1024 && (double)batch_size * channels * height * width < 2.0e9) {
-        dim3 grid(channels, batch_size);
-        hipLaunchKernelGGL(roi_align_bwd_plane_kernel, grid, dim3(256), lds, (hipStream_t)stream,
-                           top_grad, rois, bottom_grad, num_rois, channels, height, width,
-                           aligned_height, aligned_width, spatial_scale);
-        return og_launch_status();
-    }
     const int cpb = roi_c_per_block(channels, S);
     dim3 grid(num_rois, og_cdiv(channels, cpb));
     hipLaunchKernelGGL(roi_align_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream,
                        top_grad, rois, bottom_grad, channels, height, width,
                        aligned_height, aligned_width, spatial_scale, cpb);
+    return og_launch_status();
+}
+
+// ints (4 bytes, = floats) of workspace for objgan_roi_align_backward_ordered; 0 = shape outside the table path
+long objgan_roi_align_backward_ws_floats(int batch_size, int num_rois, int channels, int height, int width,
+                                         int aligned_height, int aligned_width) {
+    const int S = aligned_height * aligned_width;
+    const long HW = (long)height * width;
+    if (batch_size <= 0 || num_rois <= 0 || num_rois > ROI_TAB_MAX || S > ROI_MAX_SAMPLES) return 0;
+    if ((2 * HW + (long)num_rois * S) * 4 > 64 * 1024) return 0;                  // table kernel's LDS
+    if ((double)batch_size * channels * (double)HW >= 2.0e9) return 0;
+    return (long)batch_size * roi_tab_dims(num_rois, (int)HW, S).stride;
+}
+
+// Same adjoint, fixed summation order (see roi_tap_table_kernel): bit-reproducible.  ws: the floats the query above
+// returns; shapes it returns 0 for (or ws == NULL) take objgan_roi_align_backward's unordered atomics.
+int objgan_roi_align_backward_ordered(const float* top_grad, const float* rois, float* bottom_grad,
+                                      int batch_size, int num_rois, int roi_cols, int channels,
+                                      int height, int width, int aligned_height, int aligned_width,
+                                      float spatial_scale, float* ws, long ws_floats, void* stream) {
+    OG_ENTRY();
+    if (roi_cols != 5) return OG_BAD_ARGS;
+    if (aligned_height * aligned_width > ROI_MAX_SAMPLES || aligned_height < 2 || aligned_width < 2)
+        return OG_BAD_ARGS;
+    if (num_rois <= 0 || channels <= 0) return OG_OK;
+    const long need = objgan_roi_align_backward_ws_floats(batch_size, num_rois, channels, height, width,
+                                                          aligned_height, aligned_width);
+    if (need == 0 || !ws)
+        return objgan_roi_align_backward(top_grad, rois, bottom_grad, batch_size, num_rois, roi_cols, channels,
+                                         height, width, aligned_height, aligned_width, spatial_scale, stream);
+    if (ws_floats < need) return OG_BAD_ARGS;
+    const int S = aligned_height * aligned_width;
+    const int HW = height * width;
+    const RoiTabDims d = roi_tab_dims(num_rois, HW, S);
+    const size_t lds = (2 * (size_t)HW + (size_t)num_rois * S) * sizeof(int);
+    hipLaunchKernelGGL(roi_tap_table_kernel, dim3(batch_size), dim3(256), lds, (hipStream_t)stream,
+                       rois, reinterpret_cast<int*>(ws), num_rois, channels, height, width,
+                       aligned_height, aligned_width, spatial_scale, d);
+    const int cpb = channels >= 64 ? 8 : 1;
+    hipLaunchKernelGGL(roi_align_bwd_gather_kernel, dim3(og_cdiv(channels, cpb), batch_size), dim3(256), 0,
+                       (hipStream_t)stream, top_grad, reinterpret_cast<const int*>(ws), bottom_grad,
+                       channels, HW, width, S, d, cpb);
     return og_launch_status();
 }
 

@@ -20,6 +20,8 @@ _ptr = ctypes.c_void_p
 SIGNATURES = {
     "objgan_roi_align_forward": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _ptr],
     "objgan_roi_align_backward": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _ptr],
+    "objgan_roi_align_backward_ordered": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                          _c_float, _ptr, _c_long, _ptr],
     "objgan_avgpool2s1_forward": [_ptr, _ptr, _c_long, _c_int, _c_int, _ptr],
     "objgan_avgpool2s1_backward": [_ptr, _ptr, _c_long, _c_int, _c_int, _ptr],
     "objgan_conv_igemm": [_ptr, _ptr, _ptr, _ptr, _ptr,
@@ -31,7 +33,7 @@ SIGNATURES = {
                           _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _c_long, _ptr],
     "objgan_reflect_ring_fold": [_ptr, _ptr, _c_long, _c_int, _c_int, _ptr],
     "objgan_conv_dgrad_s2_phases": [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                                    _c_int, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr],
+                                    _c_int, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _c_long, _ptr],
     "objgan_conv_wgrad": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                           _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _c_long, _ptr],
     "objgan_lstm_bidir_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
@@ -83,10 +85,12 @@ SIGNATURES = {
 LONG_RETURN = {"objgan_conv_packed_floats": [_c_int, _c_int, _c_int],
                "objgan_conv_igemm_ws_floats": [_c_int] * 22,
                "objgan_conv_wgrad_ws_floats": [_c_int] * 13,
+               "objgan_conv_dgrad_s2_phases_ws_floats": [_c_int] * 5,
                "objgan_norm_ws_floats": [_c_int] * 4,
                "objgan_attn_general_backward_ws_floats": [_c_int] * 4,
                "objgan_masked_max_backward_ws_floats": [_c_int] * 4,
-               "objgan_channel_sum_ws_floats": [_c_int] * 3}
+               "objgan_channel_sum_ws_floats": [_c_int] * 3,
+               "objgan_roi_align_backward_ws_floats": [_c_int] * 7}
 
 _LIB = None
 

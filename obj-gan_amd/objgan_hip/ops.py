@@ -239,8 +239,10 @@ def _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad_h, pad_w, LH, LW, cachea
         _bank_mark(ent)
     else:
         wt, packed = torch.empty(n, dtype=_F32, device=g.device), 0
+    nws = _lib.load().objgan_conv_dgrad_s2_phases_ws_floats(N, Cout, OH, OW, _MATH["mode"])
+    ws = torch.empty(nws, dtype=_F32, device=g.device) if nws > 0 else None
     _lib.call("objgan_conv_dgrad_s2_phases", _p(g), _p(w), _p(dx), _p(wt), N, Cout, OH, OW, Cin, KH * KW,
-              Tg, _iarr(dh), _iarr(dw), _iarr(st), LH // 2, LW // 2, packed, _MATH["mode"], _stream())
+              Tg, _iarr(dh), _iarr(dw), _iarr(st), LH // 2, LW // 2, packed, _MATH["mode"], _p(ws), nws, _stream())
     return dx
 
 
@@ -943,8 +945,10 @@ class RoIAlignFunction(torch.autograd.Function):
         grad_output = _c(grad_output)
         _chk(grad_output)
         grad_input = torch.zeros((B, C, H, W), dtype=_F32, device=grad_output.device)
-        _lib.call("objgan_roi_align_backward", _p(grad_output), _p(rois), _p(grad_input), B,
-                  rois.shape[0], rois.shape[1], C, H, W, ah, aw, scale, _stream())
+        need = _lib.load().objgan_roi_align_backward_ws_floats(B, rois.shape[0], C, H, W, ah, aw)
+        ws = torch.empty((max(int(need), 1),), dtype=_F32, device=grad_output.device)
+        _lib.call("objgan_roi_align_backward_ordered", _p(grad_output), _p(rois), _p(grad_input), B,
+                  rois.shape[0], rois.shape[1], C, H, W, ah, aw, scale, _p(ws), int(need), _stream())
         return grad_input, None, None, None, None
 
 

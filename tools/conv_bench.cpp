@@ -110,7 +110,7 @@ int main(int argc, char** argv) {
                             h2.push_back((ph + sh.p - kh) / 2); w2.push_back((pw + sh.p - kw) / 2); s2.push_back(kh * sh.k + kw);
                         }
                 int rc = objgan_conv_dgrad_s2_phases(dg, dw, dgx, wt, sh.N, sh.Cout, OH, OW, sh.Cin, T, (int)h2.size() / 4,
-                                                     h2.data(), w2.data(), s2.data(), LH / 2, LW / 2, 0, g_math, st);
+                                                     h2.data(), w2.data(), s2.data(), LH / 2, LW / 2, 0, g_math, wsb, nwsb, st);
                 if (rc != 1) { fprintf(stderr, "dgrad phases rc=%d\n", rc); exit(1); }
             } else {
                 CK(hipMemsetAsync(dgx, 0, ngx * 4, st));
