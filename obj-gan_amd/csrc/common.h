@@ -71,49 +71,3 @@ __device__ __forceinline__ float og_block_sum(float v, float* red) {
     r = og_wave_sum(r);
     return r;
 }
-
-// ---- ordered two-level reduction ---------------------------------------------------------------------------------
-// P workgroups contribute one partial (pair) each to a group g.  Every one stores its partial into its own slot
-// part[(g * P + idx) * NV ..], makes it visible (agent-scope fence) and takes a ticket from cnt[g]; the LAST one to
-// arrive sums the P slots in slot order -- wave 0: lane-strided partial sums, then the fixed shuffle tree -- and
-// writes the totals.  The order of arrival only decides WHO sums, never in which order: the result is bit-reproducible,
-// unlike P fp32 atomicAdds.  cnt[g] must be 0 on entry (the host memsets it).  Call from ALL threads of the block
-// with v[] valid in thread 0; `s_flag`: one int of LDS.  totals are written to out[g * NV + k].
-template <int NV>
-__device__ __forceinline__ void og_ordered_sum(const float (&v)[NV], float* __restrict__ part, int* __restrict__ cnt,
-                                               float* __restrict__ out, int g, int idx, int P, int* s_flag) {
-    if (P == 1) {
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int k = 0; k < NV; ++k) out[(size_t)g * NV + k] = v[k];
-        }
-        return;
-    }
-    if (threadIdx.x == 0) {
-        float* slot = part + ((size_t)g * P + idx) * NV;
-#pragma unroll
-        for (int k = 0; k < NV; ++k) slot[k] = v[k];
-        __threadfence();
-        *s_flag = (atomicAdd(&cnt[g], 1) == P - 1) ? 1 : 0;
-    }
-    __syncthreads();
-    if (*s_flag && threadIdx.x < 64) {
-        __threadfence();
-        float acc[NV];
-#pragma unroll
-        for (int k = 0; k < NV; ++k) acc[k] = 0.f;
-        const float* base = part + (size_t)g * P * NV;
-        for (int j = threadIdx.x; j < P; j += 64) {
-#pragma unroll
-            for (int k = 0; k < NV; ++k)
-                acc[k] += __hip_atomic_load(base + (size_t)j * NV + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-#pragma unroll
-        for (int k = 0; k < NV; ++k) acc[k] = og_wave_sum(acc[k]);
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int k = 0; k < NV; ++k) out[(size_t)g * NV + k] = acc[k];
-        }
-    }
-    __syncthreads();
-}

@@ -173,6 +173,16 @@ def _job_blob():
     return ctypes.create_string_buffer(_lib.load().objgan_conv_pack_job_bytes())
 
 
+# bf16 mode (BASELINE config 5): the matrix kernels read their pixel operand from a bf16 channels-last copy of the source
+# that the library writes into the call's workspace.  Tests switch this off to compare with the fp32-gather form of the
+# same arithmetic (bit-identical results: same values, same summation order).
+_BF16_CHANNELS_LAST = True
+
+
+def _nhwc_floats(N, C, H, W):
+    return (N * H * W * ((C + 15) // 16 * 16) // 2 + 3) & ~3
+
+
 def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, transpose,
            dh, dw, src_tap, PH, PW, stride, OHf, OWf, osh, osw, ooh, oow, act, y_prezeroed=0, ring=None, cache=True):
     Tg = len(dh)
@@ -197,6 +207,8 @@ def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, tran
                                                    int(transpose), Tg, PH, PW, stride, OHf, OWf, osh, osw, act,
                                                    int(y_prezeroed), _MATH["mode"], 0 if ring is None else 1)
     ws = torch.empty(nws, dtype=_F32, device=x.device) if nws > 0 else None
+    if not _BF16_CHANNELS_LAST and _MATH["mode"] == 1 and nws == _nhwc_floats(N, C, H, W):
+        ws, nws = None, 0                 # (tests) no workspace: the library gathers from the fp32 NCHW source instead
     _lib.call("objgan_conv_igemm", _p(x), _p(w), _p(bias), _p(y), _p(wt),
               N, C, H, W, int(upsample), int(pad_mode), Cout, Cin, Torig, int(transpose),
               Tg, _iarr(dh), _iarr(dw), _iarr(src_tap), PH, PW, stride,
@@ -240,7 +252,8 @@ def _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad_h, pad_w, LH, LW, cachea
     else:
         wt, packed = torch.empty(n, dtype=_F32, device=g.device), 0
     nws = _lib.load().objgan_conv_dgrad_s2_phases_ws_floats(N, Cout, OH, OW, _MATH["mode"])
-    ws = torch.empty(nws, dtype=_F32, device=g.device) if nws > 0 else None
+    ws = torch.empty(nws, dtype=_F32, device=g.device) if nws > 0 and _BF16_CHANNELS_LAST else None
+    nws = nws if ws is not None else 0
     _lib.call("objgan_conv_dgrad_s2_phases", _p(g), _p(w), _p(dx), _p(wt), N, Cout, OH, OW, Cin, KH * KW,
               Tg, _iarr(dh), _iarr(dw), _iarr(st), LH // 2, LW // 2, packed, _MATH["mode"], _p(ws), nws, _stream())
     return dx

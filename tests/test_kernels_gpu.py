@@ -727,6 +727,72 @@ X3_CASES = [
 ]
 
 
+@pytest.mark.parametrize("case", BF16_CASES + [
+    (4, 96, 64, 64, 192, 4, 2, 1, "zeros", False),        # large enough for unsplit launches and 8-wave workgroups
+    (2, 194, 64, 64, 194, 3, 1, 1, "reflect", False),
+    (2, 194, 32, 32, 96, 3, 1, 1, "zeros", True),
+])
+def test_bf16_channels_last_operand_equals_the_fp32_gather_form(dev, case):
+    """bf16 mode reads the pixel operand of the forward / data-gradient kernels from a bf16 channels-last copy of the
+    source (one 16-byte load per lane and K step instead of eight channel-strided dword gathers + conversions).  Same
+    rounded values, same summation order: the results are BIT-identical to the gather form of the same kernels."""
+    ops = _ops()
+    N, Cin, H, W, Cout, k, s, p, pm, up = case
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(N, Cin, H, W, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(dev)
+    prev = ops.get_conv_math()
+    ops.set_conv_math("bf16")
+    outs = []
+    try:
+        for nhwc in (True, False):
+            ops._BF16_CHANNELS_LAST = nhwc
+            xd, wd = x.clone().requires_grad_(), w.clone().requires_grad_()
+            yd = ops.conv2d(xd, wd, None, s, p, pm, up, "lrelu")
+            gy = torch.randn(yd.shape, generator=torch.Generator().manual_seed(5)).to(dev)
+            yd.backward(gy)
+            torch.cuda.synchronize()
+            outs.append((yd.detach().clone(), xd.grad.clone()))
+    finally:
+        ops._BF16_CHANNELS_LAST = True
+        ops.set_conv_math(prev)
+    assert torch.equal(outs[0][0], outs[1][0]), ("fwd", rel_l2(outs[0][0], outs[1][0]))
+    assert torch.equal(outs[0][1], outs[1][1]), ("dgrad", rel_l2(outs[0][1], outs[1][1]))
+    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+
+
+def test_roi_align_backward_is_bit_reproducible(dev):
+    """The ordered ROIAlign backward (per-image tap table + fixed-order gather) gives the same bits on every run --
+    also when most samples of an image share a few anchor pixels (the hot path's 1/16 scale on feature-scale boxes)
+    -- and agrees with the reference-style atomicAdd scatter to fp32 rounding."""
+    ops = _ops()
+    from objgan_hip import _lib
+    rng = np.random.RandomState(3)
+    for trial, (B, C, H, W, scale, per) in enumerate([(4, 96, 64, 64, 1 / 16., 10), (3, 40, 32, 32, 1.0, 7),
+                                                     (2, 8, 20, 27, 0.5, 1)]):
+        n = B * per
+        rois = np.zeros((n, 5), np.float32)
+        rois[:, 0] = np.repeat(np.arange(B), per)
+        xy = rng.uniform(-3, W / scale * 0.7, (n, 2))
+        rois[:, 1:3] = xy
+        rois[:, 3:5] = xy + rng.uniform(0, W / scale * 0.6, (n, 2))
+        rois[1, 1:] = 0
+        rd = torch.from_numpy(rois).to(dev)
+        gtop = torch.from_numpy(rng.randn(n, C, 6, 6).astype(np.float32)).to(dev)
+        grads = []
+        for rep in range(3):
+            fd = torch.zeros(B, C, H, W, device=dev).requires_grad_()
+            ops.roi_align(fd, rd, 6, 6, scale).backward(gtop)
+            torch.cuda.synchronize()
+            grads.append(fd.grad.clone())
+        assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2]), trial
+        scat = torch.zeros(B, C, H, W, device=dev)
+        _lib.call("objgan_roi_align_backward", gtop.data_ptr(), rd.data_ptr(), scat.data_ptr(), B, n, 5, C, H, W, 6, 6,
+                  float(scale), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert rel_l2(grads[0], scat) < 2e-6, (trial, rel_l2(grads[0], scat))
+
+
 @pytest.mark.parametrize("case", X3_CASES)
 def test_bf16x3_math_is_as_accurate_as_the_fp32_mfma(dev, case):
     """`bf16x3` computes fp32 convolutions on the bf16 matrix pipe: x = h + m + l exactly (three bf16 pieces), six of
