@@ -689,9 +689,10 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_bf16_kernel(const float* __r
     const int cg = threadIdx.x & 7;                    // 8 channels = one 16-byte store
     if (c0 + cg * 8 >= Cp) return;
 #pragma unroll
-    for (int pp = threadIdx.x >> 3; pp < 64; pp += 32) {
+    for (int it = 0; it < 2; ++it) {
+        const int pp = (threadIdx.x >> 3) + 32 * it;
         const int p = p0 + pp;
-        if (p >= HW) break;
+        if (p >= HW) continue;
         bf16x8 v;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (__bf16)tile[cg * 8 + j][pp];
