@@ -56,7 +56,7 @@ struct IgemmArgs {
     int LH, LW;          // logical source dims seen by the taps (2H x 2W when upsampling)
     int M, Mpad, K, Kpad;   // K = T*C (algorithmic), Kpad = T*Cp (padded, what the loop walks)
     int math;               // 0: fp32 MFMA, 1: bf16 inputs (RNE) on the bf16 MFMA, fp32 accumulation
-    int nhwc;               // bf16 mode: 1 = the pixel operand comes from a bf16 [N][H][W][Cp] copy of x that
+    int nhwc;               // bf16 mode: 1 = the pixel operand comes from a bf16 [N][Cp/16][H][W][16] copy of x that
                             // run_igemm2 makes in the caller's workspace (conv_igemm3_kernel<.., 3, ..>)
     int Krow;               // row pitch of the [M][Krow] bank in elements (= Kpad; bf16 bank: Kpad rounded up to 32)
     int T, Cp;              // taps, channels rounded up to 16
@@ -671,8 +671,9 @@ __device__ __forceinline__ void pack_item(const PackArgs& a, long i, int Kpad, i
     else pack_element(a, (unsigned)i, Kpad);
 }
 
-// fp32 [N][C][HW] -> bf16 (RNE) channels-last [N][HW][Cp], channels C..Cp-1 zero: the pixel operand of the bf16 mode.
-// 64 channels x 64 pixels per workgroup through LDS: 256-byte rows in, 128-byte runs per pixel out.
+// fp32 [N][C][HW] -> bf16 (RNE) channel-blocked [N][Cp/16][HW][16], channels C..Cp-1 zero: the pixel operand of the
+// bf16 mode (16 channels of a pixel = 32 contiguous bytes, neighbouring pixels of a chunk contiguous).
+// 64 channels x 64 pixels per workgroup through LDS: 256-byte rows in, 1 KiB runs per wave out.
 __global__ __launch_bounds__(256) void nchw_to_nhwc_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ out,
                                                                 int C, int HW, int Cp) {
     __shared__ float tile[64][65];
@@ -686,17 +687,18 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_bf16_kernel(const float* __r
         tile[cc][tx] = (c < C && p < HW) ? xn[(size_t)c * HW + p] : 0.f;
     }
     __syncthreads();
-    const int cg = threadIdx.x & 7;                    // 8 channels = one 16-byte store
+    const int cg = threadIdx.x >> 5;                   // 8 channels = one 16-byte store; a wave = one 16-channel chunk
     if (c0 + cg * 8 >= Cp) return;
+    const int chunk = (c0 + cg * 8) >> 4, half = cg & 1;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-        const int pp = (threadIdx.x >> 3) + 32 * it;
+        const int pp = (threadIdx.x & 31) + 32 * it;
         const int p = p0 + pp;
         if (p >= HW) continue;
         bf16x8 v;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (__bf16)tile[cg * 8 + j][pp];
-        *reinterpret_cast<bf16x8*>(out + ((size_t)n * HW + p) * Cp + c0 + cg * 8) = v;
+        *reinterpret_cast<bf16x8*>(out + (((size_t)n * (Cp / 16) + chunk) * HW + p) * 16 + half * 8) = v;
     }
 }
 
@@ -1273,10 +1275,16 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
     // [M][Kpad/16][h,m,l][16] bf16 = 96 bytes per row and step, LDS row pitch 112 bytes (an odd multiple of 16:
     // the 16 lanes of a ds_read_b128 group fall on 16 different 16-byte slots); the pixel fragment is split in
     // registers (~44 VALU instructions per step next to 6 * TM MFMAs).
-    // 3 (NH): as 1, with the pixel operand read from a bf16 channels-last copy of the source, [N][H][W][Cp]
+    // 3 (NH): as 1, with the pixel operand read from a bf16 channel-blocked copy of the source, [N][Cp/16][H][W][16]
     // (nchw_to_nhwc_bf16_kernel): the eight consecutive k of a lane are eight consecutive channels of its pixel -- one
-    // 16-byte load, no conversion -- instead of eight channel-strided dword gathers and eight conversions.
+    // 16-byte load, no conversion -- instead of eight channel-strided dword gathers and eight conversions; the 32
+    // pixels of a wave that are neighbours in a row read 1 KiB of contiguous memory per instruction (a plain
+    // channels-last [N][H][W][Cp] copy made every such load touch 32 cache lines: 517 -> see DESIGN.md §4).
     constexpr bool NH = MATH == 3, BF = MATH == 1 || NH, SP = MATH == 2;
+    // P3: three LDS row tiles / three pixel-fragment register sets, loads two steps ahead (see the main loop).  SP: a
+    // step is 6 TM MFMAs; NH: 2 TM MFMAs -- 0.2 us at TM = 6, far below a loaded L2 round trip, and the fragment of a
+    // step is only 8 registers.
+    constexpr bool P3 = SP || NH;
     constexpr int BM = 32 * TM;
     constexpr int BN = 32 * NW;
     constexpr int BK = 16;
@@ -1296,7 +1304,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
     constexpr int NBC = NH ? 4 : 8;                   // registers per 16-channel chunk of the pixel operand
     constexpr int NB = BF ? 2 * NBC : 8;              // pixel-operand registers per lane and iteration
 
-    __shared__ __attribute__((aligned(16))) float lds[ALDS ? (SP ? 3 : 2) * TILE : 4];
+    __shared__ __attribute__((aligned(16))) float lds[ALDS ? (P3 ? 3 : 2) * TILE : 4];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1337,7 +1345,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
         const int pb = rem - pa * a.PW;
         ihb = pa * a.stride;
         iwb = pb * a.stride;
-        img_off = NH ? (unsigned)n * (unsigned)HW
+        img_off = NH ? (unsigned)n * (unsigned)(a.Cp / 16) * (unsigned)HW
                      : (unsigned)n * (unsigned)a.C * (unsigned)HW + (unsigned)(lrow * 8) * (unsigned)HW;
     }
     const int us = a.upsample ? 1 : 0;
@@ -1355,7 +1363,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
         const bool ok = pix_ok && (refl || inb);
         const int ihs = (refl ? ihr : ih) >> us;
         const int iws = (refl ? iwr : iw) >> us;
-        if (NH) bvoff = ok ? ((img_off + (unsigned)(ihs * a.W + iws)) * (unsigned)a.Cp + (unsigned)(lrow * 8)) * 2u : OG_OOB;
+        if (NH) bvoff = ok ? (img_off + (unsigned)(ihs * a.W + iws)) * 32u + (unsigned)(lrow * 16) : OG_OOB;
         else bvoff = ok ? (img_off + (unsigned)(ihs * a.W + iws)) * 4u : OG_OOB;
     };
     int t_ld, cb_ld;
@@ -1364,7 +1372,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
     // range-check zero; their filter entries are zero  (NH: the copy holds zeros there)
     auto load_b8 = [&](float* rb) {
         if (NH) {
-            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, bvoff, cb_ld * 2, 0));
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, bvoff, (cb_ld >> 4) * HW * 32, 0));
 #pragma unroll
             for (int i = 0; i < 4; ++i) rb[i] = v[i];
         } else {
@@ -1454,7 +1462,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
     }
 #endif
     auto mma = [&](const float (&rb)[NB], const f32x4 (&ad)[NAD], int cur, auto&& mid) {
-        if (BF || !ALDS) mid();       // (SP with LDS: behind its first TM MFMAs, below)
+        if ((BF && !NH) || !ALDS) mid();       // (SP / NH with LDS: behind their first TM MFMAs, below)
         if (SP) {
             // Order: the three products that need only the h piece of the pixel fragment first (4 conversions), the
             // refill behind the first TM of them, the m / l pieces (~40 VALU) pinned between the next 2 TM MFMAs.
@@ -1517,6 +1525,11 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
                         aq[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(T + lcol * LD + h * 8 + lrow * 4 + i * 32 * LD));
+                    if (NH && h == 1) {        // the refill (LDS store of the next row tile, loads two steps ahead)
+                        __builtin_amdgcn_sched_barrier(0);
+                        mid();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
                         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[i], bq[h], acc[i], 0, 0, 0);
@@ -1566,12 +1579,12 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
     if (ALDS) {
         load_a(kt0);
         store_a(0);
-        if (SP || kt0 + 1 < nk) load_a(kt0 + 1);
+        if (P3 || kt0 + 1 < nk) load_a(kt0 + 1);
     } else {
         load_adir(ad0, kt0);
     }
     load_b(rb0);
-    if (SP && ALDS) load_b(rb1);
+    if (P3 && ALDS) load_b(rb1);
     if (ALDS) __syncthreads();
     int cur = 0;
     // Two steps per trip with the fragment registers in fixed ping-pong roles (rb0/ad0 even, rb1/ad1
@@ -1602,7 +1615,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
         if (kt + 1 < nk) mma(rb1, ad1, 0, [] {});
         kt = nk;
     }
-    if (SP && ALDS) {
+    if (P3 && ALDS) {
         // Split mode: a step is 6 * TM MFMAs of 32 cycles -- shorter than a loaded gather round trip for the
         // short tiles -- so the pixel gather runs TWO steps ahead (three fragment sets in fixed rotation, three
         // steps per trip).  Order inside the refill: LDS store of the row tile loaded one step ago, load of the
