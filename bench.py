@@ -55,7 +55,7 @@ def cat_names(math):
     """rocprofv3's names of the kernel instances behind the library's timing categories (leading template
     arguments: tile height, LDS-free form / arithmetic)."""
     m = MATH_IDS[math]
-    mi = 3 if m == 1 else m          # bf16 mode: the matrix kernels read the bf16 channels-last copy (template value 3)
+    mi = 3 if m == 1 else m          # bf16 mode: the matrix kernels read the bf16 channel-blocked copy (template value 3)
     return (["conv_igemm3_kernel<%d, false, %d, 4>" % (tm, mi) for tm in range(1, 8)] +
             ["conv_wgrad2_kernel<%d, %d" % (tm, m) for tm in range(1, 8)] +
             ["conv_thin_kernel", "conv_thin3x3_kernel", "conv_igemm_kernel", "conv_wgrad_kernel",

@@ -81,8 +81,8 @@ int objgan_conv_bank_layout(int N, int C, int H, int W, int M, int Tg, int PH, i
  * wt_packed=1: wt still holds the packed bank written by an earlier call with the same w, taps,
  * transpose flag, math and input size class (the caller caches it while w is unchanged); 0: pack now.
  * math: 0 = fp32 MFMA (exact fp32 fmaf chains); 1 = mixed precision (BASELINE config 5): operands rounded
- * to bf16 (RNE), fp32 accumulation, fp32 tensors at the boundary -- the call first writes a bf16 channels-last copy
- * [N][H][W][ceil16(C)] of x into ws and the matrix kernel reads its pixel operand from that copy as 16-byte vectors
+ * to bf16 (RNE), fp32 accumulation, fp32 tensors at the boundary -- the call first writes a bf16 channel-blocked copy
+ * [N][ceil16(C)/16][H][W][16] of x into ws and the matrix kernel reads its pixel operand from that copy as 16-byte vectors
  * (without ws: channel-strided fp32 gathers converted in registers, same values); 2 = "bf16x3": fp32 results on
  * the bf16 matrix pipe -- every fp32 operand is split exactly into three bf16 pieces (24 = 8 + 8 + 8 significand
  * bits) and the six largest of the nine partial products are accumulated in fp32; what is dropped is below 2^-24
@@ -95,7 +95,7 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
                       int OHf, int OWf, int osh, int osw, int ooh, int oow,
                       int act, int y_prezeroed, int wt_packed, int math, float* ring,
                       float* ws, long ws_floats, void* stream);
-/* ws: the bf16 channels-last copy of x (math 1), then the split-K workspace.  Small-grid / long-K launches are split along K: every split stores its partial output into
+/* ws: the bf16 channel-blocked copy of x (math 1), then the split-K workspace.  Small-grid / long-K launches are split along K: every split stores its partial output into
  * its own slot of ws and a second kernel sums the slots in split order (+ bias, activation) -- bit-reproducible, no
  * zero-fill of y, no atomics.  objgan_conv_igemm_ws_floats (host-only, same geometry arguments; ring != 0 when a ring
  * buffer is passed) says how many floats a call needs (math 0 / 2: 0 for most); a call that needs them and gets fewer returns 0. */
@@ -112,7 +112,7 @@ int objgan_reflect_ring_fold(const float* ring, float* y, long planes, int H, in
  * of taps (k=4, pad 1, even sizes): one launch for all phases.  x = dY [N,Cout,OH,OW],
  * y = dX [N,Cin,2*PH,2*PW], fully written (no pre-zeroing).  dh/dw/src_tap: 4 x Tg entries, phase
  * p = (row parity << 1) | column parity.  wt: 4*ceil(1.5*Cin*Tg*ceil16(Cout)) floats; wt_packed as above.
- * ws: objgan_conv_dgrad_s2_phases_ws_floats floats (math 1: the bf16 channels-last copy of dY, see below; else 0). */
+ * ws: objgan_conv_dgrad_s2_phases_ws_floats floats (math 1: the bf16 channel-blocked copy of dY, see objgan_conv_igemm; else 0). */
 long objgan_conv_dgrad_s2_phases_ws_floats(int N, int Cout, int OH, int OW, int math);
 int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float* wt,
                                 int N, int Cout, int OH, int OW, int Cin, int Torig,

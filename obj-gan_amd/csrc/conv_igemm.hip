@@ -1279,7 +1279,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
     // (nchw_to_nhwc_bf16_kernel): the eight consecutive k of a lane are eight consecutive channels of its pixel -- one
     // 16-byte load, no conversion -- instead of eight channel-strided dword gathers and eight conversions; the 32
     // pixels of a wave that are neighbours in a row read 1 KiB of contiguous memory per instruction (a plain
-    // channels-last [N][H][W][Cp] copy made every such load touch 32 cache lines: 517 -> see DESIGN.md §4).
+    // channels-last [N][H][W][Cp] copy made every such load touch 32 cache lines: 517 -> 603 TFLOP/s).
     constexpr bool NH = MATH == 3, BF = MATH == 1 || NH, SP = MATH == 2;
     // P3: three LDS row tiles / three pixel-fragment register sets, loads two steps ahead (see the main loop).  SP: a
     // step is 6 TM MFMAs; NH: 2 TM MFMAs -- 0.2 us at TM = 6, far below a loaded L2 round trip, and the fragment of a
@@ -2367,7 +2367,7 @@ static int launch_igemm2(const IgemmArgs& a, int TM, dim3 grid, hipStream_t s, i
     if (og_trace())
         fprintf(stderr, "OGTRACE igemm TM=%d NW=%d M=%d rows=%d C=%d T=%d Npix=%d grid=%u,%u,%u H=%d W=%d stride=%d\n", TM, nw, a.M,
                 a.m_end - a.m_begin, a.C, a.T, a.N * a.PH * a.PW, grid.x, grid.y, grid.z, a.H, a.W, a.stride);
-    if (a.math == 1 && a.nhwc) {           // bf16, channels-last pixel operand
+    if (a.math == 1 && a.nhwc) {           // bf16, channel-blocked pixel operand
 #define OG_IGNH(TMv)                                                                                                  \
         if (nw == 8) hipLaunchKernelGGL((conv_igemm3_kernel<TMv, false, 3, 8>), grid, dim3(512), 0, s, a);            \
         else hipLaunchKernelGGL((conv_igemm3_kernel<TMv, false, 3, 4>), grid, dim3(256), 0, s, a);
@@ -2478,7 +2478,7 @@ static Igemm2Plan igemm2_plan(const IgemmArgs& a, int y_prezeroed) {
 
 // floats of split-K workspace run_igemm2 wants for this plan (0: one split, or a partial-coverage launch that
 // accumulates into the pre-zeroed output)
-// bf16 mode: floats of workspace the channels-last bf16 copy of the source takes (0: not this mode / too large for
+// bf16 mode: floats of workspace the channel-blocked bf16 copy of the source takes (0: not this mode / too large for
 // the 32-bit buffer range)
 static long igemm2_nhwc_floats(int math, int N, int H, int W, int Cp) {
     if (math != 1 || (double)N * H * W * Cp * 2.0 >= 4.0e9) return 0;
@@ -2494,7 +2494,7 @@ static long igemm2_ws_floats(const IgemmArgs& a, const Igemm2Plan& p) {
 static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed, float* ws, long ws_floats) {
     if (a.nhwc && !ws) a.nhwc = 0;              // no workspace: fp32 NCHW gathers (conv_igemm3_kernel<.., 1, ..>)
     const Igemm2Plan p = igemm2_plan(a, y_prezeroed);
-    if (a.nhwc) {                               // bf16 channels-last copy of the source: first part of the workspace
+    if (a.nhwc) {                               // bf16 channel-blocked copy of the source: first part of the workspace
         const long nh = igemm2_nhwc_floats(a.math, a.N, a.H, a.W, a.Cp);
         if (ws_floats < igemm2_ws_floats(a, p)) return OG_BAD_ARGS;
         hipLaunchKernelGGL(nchw_to_nhwc_bf16_kernel, dim3(og_cdiv(a.H * a.W, 64), og_cdiv(a.Cp, 64), a.N), dim3(256), 0, s,
@@ -2823,7 +2823,7 @@ int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float*
     return run_igemm2(a, s, 0, ws, ws_floats);  // (four phases in one launch: never split along K)
 }
 
-// floats of workspace objgan_conv_dgrad_s2_phases takes (bf16 mode: the channels-last bf16 copy of dY; else 0)
+// floats of workspace objgan_conv_dgrad_s2_phases takes (bf16 mode: the channel-blocked bf16 copy of dY; else 0)
 long objgan_conv_dgrad_s2_phases_ws_floats(int N, int Cout, int OH, int OW, int math) {
     return igemm2_nhwc_floats(math, N, OH, OW, (Cout + 15) / 16 * 16);
 }

@@ -173,7 +173,7 @@ def _job_blob():
     return ctypes.create_string_buffer(_lib.load().objgan_conv_pack_job_bytes())
 
 
-# bf16 mode (BASELINE config 5): the matrix kernels read their pixel operand from a bf16 channels-last copy of the source
+# bf16 mode (BASELINE config 5): the matrix kernels read their pixel operand from a bf16 channel-blocked copy [N][C/16][H][W][16] of the source
 # that the library writes into the call's workspace.  Tests switch this off to compare with the fp32-gather form of the
 # same arithmetic (bit-identical results: same values, same summation order).
 _BF16_CHANNELS_LAST = True

@@ -732,8 +732,8 @@ X3_CASES = [
     (2, 194, 64, 64, 194, 3, 1, 1, "reflect", False),
     (2, 194, 32, 32, 96, 3, 1, 1, "zeros", True),
 ])
-def test_bf16_channels_last_operand_equals_the_fp32_gather_form(dev, case):
-    """bf16 mode reads the pixel operand of the forward / data-gradient kernels from a bf16 channels-last copy of the
+def test_bf16_blocked_operand_equals_the_fp32_gather_form(dev, case):
+    """bf16 mode reads the pixel operand of the forward / data-gradient kernels from a bf16 channel-blocked copy [N][C/16][H][W][16] of the
     source (one 16-byte load per lane and K step instead of eight channel-strided dword gathers + conversions).  Same
     rounded values, same summation order: the results are BIT-identical to the gather form of the same kernels."""
     ops = _ops()
