@@ -57,7 +57,8 @@ def cat_names(math):
     m = MATH_IDS[math]
     mi = 3 if m == 1 else m          # bf16 mode: the matrix kernels read the bf16 channel-blocked copy (template value 3)
     return (["conv_igemm3_kernel<%d, false, %d, 4>" % (tm, mi) for tm in range(1, 8)] +
-            ["conv_wgrad2_kernel<%d, %d" % (tm, m) for tm in range(1, 8)] +
+            # (bf16 mode: the bf16-operand weight-gradient kernel reports in the slots of the LDS-staged one)
+            [("conv_wgrad_bfb_kernel<%d," % tm) if m == 1 else ("conv_wgrad2_kernel<%d, %d" % (tm, m)) for tm in range(1, 8)] +
             ["conv_thin_kernel", "conv_thin3x3_kernel", "conv_igemm_kernel", "conv_wgrad_kernel",
              "conv_igemm3_kernel<1, true, %d, 4>" % m] + ["conv_wgrad3_kernel<%d, %d" % (tm, m) for tm in range(1, 8)] +
             ["conv_igemm3_kernel<%d, false, %d, 8>" % (tm, mi) for tm in range(1, 8)] +

@@ -2143,6 +2143,220 @@ __global__ __launch_bounds__(256) void reflect_ring_fold_kernel(const float* __r
     }
 }
 
+// ---- weight gradient of the bf16 mode: bf16 operands, x read from its channel-blocked copy -----------------------------
+// dW[m][c][t] = sum over output pixels p = (n, oh, ow) of dy[n][m][p] * x[n][c][p @ tap t]: GEMM rows = output channels,
+// K = pixels, columns = (tap, channel).  Both MFMA operands want eight consecutive K = pixels per lane; x arrives
+// pixel-major -- its channel-blocked bf16 copy [N][Cp/16][H*W][16] (nchw_to_nhwc_bf16_kernel) holds 16 channels of a pixel
+// as one 32-byte record -- so a wave copies the records of its 32 pixels x 32 channels (ONE tap, two chunks) into a
+// wave-private LDS image [32 pixels][2 chunks][16 channels] (lane-linear 16-byte stores) and reads them back with
+// ds_read_b64_tr_b16, the gfx950 transposing LDS read: lane (i = l & 15 of a 16-lane group) passes the address of row
+// i >> 2, columns 4 (i & 3) .. +3 and receives column i of the 4 x 16 block -- four consecutive PIXELS of one channel.
+// Two such reads are the lane's operand of one 32x32x16 MFMA (measured on the box: tools/tr_probe.hip).  No fp32
+// gathers, no conversions of x, every geometry (zero / reflect padding, stride, nearest-x2 upsampling) is just the
+// record address of the lane's pixel; records are 32 bytes, so every load is 16-byte aligned whatever the tap shift.
+// dy rows: fp32 NCHW, rounded to bf16 by the thread that stages them into LDS (80-byte pitch: conflict-free
+// ds_read_b128), shared by the NW waves of the workgroup -- NW column groups (tap, 32 channels) per row tile.
+// One iteration = 32 pixels = two MFMAs per row group.  Requires (OH * OW) % 32 == 0.
+template <int TM, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_wgrad_bfb_kernel(const WgradArgs a, const __bf16* __restrict__ xb,
+                                                                 const int KS, const int Cp) {
+    constexpr int NT = 64 * NW;
+    constexpr int BM = 32 * TM;
+    constexpr int BK = 32;
+    constexpr int ALD = 20;                          // floats per dy row in LDS: 64 bytes of bf16 + 16 (odd multiple of 16)
+    constexpr int ATILE = BM * ALD;
+    constexpr int NA4 = BM * 8;                      // 16-byte fp32 pieces (4 pixels) of a row tile per iteration
+    constexpr int NA_PER = (NA4 + NT - 1) / NT;
+    constexpr int BTILE = 512;                       // floats: 32 pixels x 64 bytes per wave and buffer
+    static_assert((2 * ATILE + 2 * NW * BTILE) * 4 <= 64 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) float ldsA[2 * ATILE];
+    __shared__ __attribute__((aligned(16))) float ldsB[2 * NW * BTILE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane >> 5;
+    const int lcol = lane & 31;
+
+    const int T = KS * KS;
+    const int Cc = Cp >> 4;                          // 16-channel chunks
+    const int CG = (Cc + 1) >> 1;                    // 32-channel column groups per tap
+    const int ngroups = T * CG;
+    const int tiles_m = (a.m_end - a.m_begin + BM - 1) / BM;
+    const int tiles_n = (ngroups + NW - 1) / NW;
+    const int nwg = tiles_m * tiles_n;
+    const int wg = og_xcd_remap(blockIdx.x, nwg);
+    const int tile_m = wg % tiles_m;
+    const int tile_n = wg / tiles_m;
+    const int m0 = a.m_begin + tile_m * BM;
+    const int group = tile_n * NW + wid;
+    const bool grp_ok = group < ngroups;
+    const int t = grp_ok ? group / CG : 0;
+    const int cg = grp_ok ? group - t * CG : 0;
+    const int kh = t / KS;
+    const int dh = kh - a.pad, dw = (t - kh * KS) - a.pad;
+
+    const int OHW = a.OH * a.OW;
+    const int HW = a.H * a.W;
+    const int Npix = a.N * OHW;
+    const int p_begin = blockIdx.y * a.pix_per_split;
+    const int p_end = min(Npix, p_begin + a.pix_per_split);
+    const int nk = (p_end - p_begin + BK - 1) / BK;
+
+    __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)xb, 0, (int)((unsigned)a.N * (unsigned)Cc * (unsigned)HW * 32u), OG_BUF_FLAGS);
+    __amdgpu_buffer_rsrc_t dyres = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.dy, 0, (int)((unsigned)a.N * a.Cout * OHW * 4u), OG_BUF_FLAGS);
+
+    // ---- x records: lane = (pixel j = l >> 2 of a 16-pixel half, chunk (l >> 1) & 1, 16-byte half l & 1)
+    const int chunk = cg * 2 + ((lane >> 1) & 1);
+    const bool rec_ok = grp_ok && chunk < Cc;
+    const unsigned rec_lane = (unsigned)chunk * (unsigned)HW;     // + n * Cc * HW + ih * W + iw, x 32 bytes + half
+    const int us = a.upsample ? 1 : 0;
+    const bool refl = a.pad_mode == 1;
+    int pn, poh, pow_;                               // output pixel of this lane in the first half of the next iteration
+    {
+        const int p = p_begin + (lane >> 2);
+        pn = p / OHW;
+        const int r = p - pn * OHW;
+        poh = r / a.OW;
+        pow_ = r - poh * a.OW;
+    }
+    auto rec_offset = [&](int n, int oh, int ow, bool in_range) -> unsigned {
+        const int ih = oh * a.stride + dh, iw = ow * a.stride + dw;
+        int ihr = ih < 0 ? -ih : ih;
+        int iwr = iw < 0 ? -iw : iw;
+        ihr = ihr >= a.LH ? 2 * (a.LH - 1) - ihr : ihr;
+        iwr = iwr >= a.LW ? 2 * (a.LW - 1) - iwr : iwr;
+        const bool inb = ((unsigned)ih < (unsigned)a.LH) && ((unsigned)iw < (unsigned)a.LW);
+        const bool ok = rec_ok && in_range && (refl || inb);
+        const int ihs = (refl ? ihr : ih) >> us, iws = (refl ? iwr : iw) >> us;
+        return ok ? (((unsigned)n * (unsigned)Cc * (unsigned)HW + rec_lane + (unsigned)(ihs * a.W + iws)) * 32u
+                     + (unsigned)((lane & 1) * 16)) : OG_OOB;
+    };
+    int p_ld = p_begin + (lane >> 2);                // pixel index of (pn, poh, pow_)
+    auto load_b = [&](f32x4 (&rb)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // second half: 16 pixels further (OW need not divide 16: carry into rows / images)
+            int n = pn, oh = poh, ow = pow_ + 16 * h;
+            while (ow >= a.OW) { ow -= a.OW; oh += 1; }
+            while (oh >= a.OH) { oh -= a.OH; n += 1; }
+            const unsigned off = rec_offset(n, oh, ow, p_ld + 16 * h < p_end);
+            rb[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 0));
+        }
+        p_ld += BK;
+        pow_ += BK;
+        while (pow_ >= a.OW) { pow_ -= a.OW; poh += 1; }
+        while (poh >= a.OH) { poh -= a.OH; pn += 1; }
+    };
+    auto store_b = [&](const f32x4 (&rb)[2], int buf) {
+        float* Bs = ldsB + (buf * NW + wid) * BTILE;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) *reinterpret_cast<f32x4*>(Bs + h * 256 + lane * 4) = rb[h];
+    };
+    // transposing read: 16-lane group g = l >> 4: chunk g & 1, pixel half-octet g >> 1; see the header comment
+    const int b_rd = ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;   // bytes
+
+    // ---- dy rows
+    unsigned avoff[NA_PER];
+    int alds[NA_PER];
+#pragma unroll
+    for (int i = 0; i < NA_PER; ++i) {
+        const int idx = tid + NT * i;
+        const int row = idx >> 3, q = idx & 7;
+        const bool on = (NA4 % NT == 0 || idx < NA4) && (m0 + row) < a.m_end;
+        avoff[i] = on ? ((unsigned)(m0 + row) * (unsigned)OHW + q * 4u) * 4u : OG_OOB;
+        alds[i] = (NA4 % NT == 0 || idx < NA4) ? row * ALD + q * 2 : -1;
+    }
+    int n_ld = p_begin / OHW;                        // scalar (image, offset) of the next dy iteration
+    int rem_ld = p_begin - n_ld * OHW;
+    f32x4 ra[NA_PER];
+    auto load_a = [&]() {
+        const int so = (n_ld * a.Cout * OHW + rem_ld) * 4;
+        rem_ld += BK;
+        if (rem_ld >= OHW) { rem_ld = 0; n_ld += 1; }
+#pragma unroll
+        for (int i = 0; i < NA_PER; ++i)
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyres, avoff[i], so, 0));
+    };
+    auto store_a = [&](int buf) {
+        float* As = ldsA + buf * ATILE;
+#pragma unroll
+        for (int i = 0; i < NA_PER; ++i) {
+            bf16x4 h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[j] = (__bf16)ra[i][j];
+            if (NA4 % NT == 0 || alds[i] >= 0) *reinterpret_cast<bf16x4*>(As + alds[i]) = h;
+        }
+    };
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4;
+    auto mma = [&](int buf, auto&& mid) {
+        const char* Bs = reinterpret_cast<const char*>(ldsB + (buf * NW + wid) * BTILE) + b_rd;
+        const float* As = ldsA + buf * ATILE + lcol * ALD + lrow * 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(Bs + h * 1024));
+            const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(Bs + h * 1024 + 256));
+            // (whole-vector casts: an element-wise short -> bf16 copy of the two halves came out of hipcc as
+            // {b0.lo, b0.lo, b1.lo, b1.lo} -- found with tools/dbg_wgrad.py)
+            const bf16x8 bq = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+            bf16x8 aq[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                aq[i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * ALD + h * 8);
+            if (h == 1) {                 // the refill behind the first TM MFMAs of the iteration
+                __builtin_amdgcn_sched_barrier(0);
+                mid();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[i], bq, acc[i], 0, 0, 0);
+        }
+    };
+
+    // prologue: iteration 0 in LDS buffer 0, iteration 1 in registers
+    f32x4 rb[2];
+    load_a(); load_b(rb);
+    store_a(0); store_b(rb, 0);
+    load_a(); load_b(rb);
+    __syncthreads();
+    // two iterations per trip (literal buffer indices); the loads of iteration k + 2 are issued in iteration k and stored to
+    // LDS in iteration k + 1 (unconditionally: past the end they hit the range check or unused records)
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        mma(0, [&]() { store_a(1); store_b(rb, 1); load_a(); load_b(rb); });
+        __syncthreads();
+        mma(1, [&]() { store_a(0); store_b(rb, 0); load_a(); load_b(rb); });
+        __syncthreads();
+    }
+    if (kt < nk) mma(0, [] {});
+
+    // ---- epilogue: column = channel ci of tap t -> dw[m][ci * T + t]
+    const int ci = cg * 32 + lcol;
+    if (!grp_ok || ci >= a.Cin) return;
+    const int ocol = ci * T + t;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+            if (m < a.m_end) og_wgrad_store(a, m, ocol, acc[i][r]);
+        }
+    }
+}
+
+
 // ---- optional per-launch timing (bench.py's roofline leg) -------------------------------------
 // When enabled, every conv launch is bracketed by hipEvents on its own stream and tagged with a
 // category (kind, taps / ksize, tile config) and its ALGORITHMIC flops 2*M*K*Npix.  Off by default;
@@ -2871,6 +3085,22 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
     a.math = math;
     if (v2) {
         const bool bf = math == 1, sp = math == 2;
+        // bf16 mode: bf16 operands, x from its channel-blocked copy in the workspace (conv_wgrad_bfb_kernel); without a
+        // workspace (or on maps of fewer than 32 pixels) the fp32-gather kernels below
+        const int Cpb = (Cin + 15) / 16 * 16;
+        bool bfb = bf && OHW % 32 == 0 && (double)N * Cpb * H * W * 2.0 < 4.0e9 && (plan_only || ws != nullptr);
+        const long xb_floats = bfb ? (((long)N * H * W * Cpb / 2 + 3) & ~3L) : 0;
+        const __bf16* xb = nullptr;
+        if (bfb) {
+            if (plan_only) { *ws_need += xb_floats; }
+            else {
+                if (ws_floats < xb_floats) return OG_BAD_ARGS;
+                hipLaunchKernelGGL(nchw_to_nhwc_bf16_kernel, dim3(og_cdiv(H * W, 64), og_cdiv(Cpb, 64), N), dim3(256), 0, s,
+                                   x, reinterpret_cast<__bf16*>(ws), Cin, H * W, Cpb);
+                xb = reinterpret_cast<const __bf16*>(ws);
+                ws_used = xb_floats;
+            }
+        }
         int groups = og_cdiv(Cout, 32);
         const int tiles_n0 = og_cdiv(a.ncol, 128);
         // 1..4 output channels beyond a multiple of 32: on the VALU of block row 0 (see WgradArgs)
@@ -2906,8 +3136,10 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
             const bool x3_frag = tm <= og_x3_wgrad3_maxtm() || b128 || (!upsample && !pad_mode && og_x3_wgrad3_maxtm() >= 0);
             const bool use3 = bf ? tm <= 2 : (sp ? x3_frag : (tm <= og_wgrad3_maxtm() || b128));
             // bf16x3, register-fragment form: 8-wave workgroups (256 columns per dy row tile), as in run_igemm2
-            const int nw = (sp && use3 && tm >= 4 && og_nw8_min() > 0 && Npix >= 16384) ? 8 : 4;
-            const int tiles_n = og_cdiv(a.ncol, 32 * nw);
+            const int nw = bfb ? ((tm <= 6 && Npix >= 16384) ? 8 : 4)
+                               : ((sp && use3 && tm >= 4 && og_nw8_min() > 0 && Npix >= 16384) ? 8 : 4);
+            // column tiles: 32 columns (ci * T + t) per wave; bfb: one (tap, 32-channel group) per wave
+            const int tiles_n = bfb ? og_cdiv(ksize * ksize * og_cdiv(Cpb, 32), nw) : og_cdiv(a.ncol, 32 * nw);
             int splits;
             const int max_splits = og_cdiv(Npix, 512);       // >= 32 K steps per split
             if (og_wgrad_oldsplit()) {
@@ -2930,7 +3162,7 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
                 }
             }
             int pps = og_cdiv(Npix, splits);
-            pps = (pps + 15) / 16 * 16;
+            pps = bfb ? (pps + 31) / 32 * 32 : (pps + 15) / 16 * 16;
             splits = og_cdiv(Npix, pps);
             a.pix_per_split = pps;
             {
@@ -2947,7 +3179,8 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
             if (og_trace())
                 fprintf(stderr, "OGTRACE wgrad TM=%d NW=%d form=%d Cout=%d Cin=%d k=%d N=%d OH=%d OW=%d stride=%d grid=%u,%u math=%d\n", tm, nw,
                         use3 ? 3 : 2, Cout, Cin, ksize, N, OH, OW, stride, grid.x, grid.y, math);
-            ProfRec* pr = prof_begin(use3 ? (nw == 8 ? OG_CAT_WGRAD3_NW8(tm) : OG_CAT_WGRAD3(tm)) : OG_CAT_WGRAD2(tm),
+            ProfRec* pr = prof_begin(bfb ? OG_CAT_WGRAD2(tm)
+                                         : (use3 ? (nw == 8 ? OG_CAT_WGRAD3_NW8(tm) : OG_CAT_WGRAD3(tm)) : OG_CAT_WGRAD2(tm)),
                                      2.0 * (a.m_end - a.m_begin + a.xr_count) * (double)a.ncol * (double)Npix, s);
             prof_meta(pr, 1, tm, a.m_end - a.m_begin + a.xr_count, Cin, ksize * ksize, N, OH, OW,
                       stride * (upsample ? 10 : 1) * (pad_mode ? -1 : 1), splits);
@@ -2971,7 +3204,20 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
                     else if (use3 && b128) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, 0, true>), grid, dim3(256), 0, s, a, ksize); \
                     else if (use3) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv>), grid, dim3(256), 0, s, a, ksize); \
                     else hipLaunchKernelGGL((conv_wgrad2_kernel<TMv>), grid, dim3(256), 0, s, a, ksize);
-            if (a.xr_count > 0) {
+            if (bfb) {
+#define OG_WGB(TMv) if (nw == 8) hipLaunchKernelGGL((conv_wgrad_bfb_kernel<(TMv <= 6 ? TMv : 6), 8>), grid, dim3(512), 0, s, a, xb, ksize, Cpb); \
+                    else hipLaunchKernelGGL((conv_wgrad_bfb_kernel<TMv, 4>), grid, dim3(256), 0, s, a, xb, ksize, Cpb);
+                switch (tm) {
+                    case 1: OG_WGB(1) break;
+                    case 2: OG_WGB(2) break;
+                    case 3: OG_WGB(3) break;
+                    case 4: OG_WGB(4) break;
+                    case 5: OG_WGB(5) break;
+                    case 6: OG_WGB(6) break;
+                    default: OG_WGB(7) break;
+                }
+#undef OG_WGB
+            } else if (a.xr_count > 0) {
                 switch (tm) {
                     case 2: OG_WG2X(2) break;
                     case 3: OG_WG2X(3) break;
