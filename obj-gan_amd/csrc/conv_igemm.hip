@@ -2156,7 +2156,12 @@ __global__ __launch_bounds__(256) void reflect_ring_fold_kernel(const float* __r
 // record address of the lane's pixel; records are 32 bytes, so every load is 16-byte aligned whatever the tap shift.
 // dy rows: fp32 NCHW, rounded to bf16 by the thread that stages them into LDS (80-byte pitch: conflict-free
 // ds_read_b128), shared by the NW waves of the workgroup -- NW column groups (tap, 32 channels) per row tile.
-// One iteration = 32 pixels = two MFMAs per row group.  Requires (OH * OW) % 32 == 0.
+// One iteration = 32 pixels = two MFMAs per row group.  Requires (OH * OW) % 32 == 0 and OH, OW <= 256.
+// The record address of a lane's pixel costs VALU work every iteration (K = pixels: nothing is constant across the
+// loop): the tap geometry -- stride, padding, reflection, upsampling, bounds -- sits in two small LDS tables per
+// workgroup (source row offset per (kh, oh), source column per (kw, ow); 0xffff = outside), so an address is two
+// 16-bit LDS reads and ~8 VALU instructions; the first version evaluated the geometry per record (~108 VALU per wave and
+// iteration next to 12 MFMAs: VALU bound, 344 TFLOP/s).
 template <int TM, int NW>
 __global__ __launch_bounds__(64 * NW) void conv_wgrad_bfb_kernel(const WgradArgs a, const __bf16* __restrict__ xb,
                                                                  const int KS, const int Cp) {
@@ -2167,10 +2172,14 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bfb_kernel(const WgradArgs
     constexpr int ATILE = BM * ALD;
     constexpr int NA4 = BM * 8;                      // 16-byte fp32 pieces (4 pixels) of a row tile per iteration
     constexpr int NA_PER = (NA4 + NT - 1) / NT;
-    constexpr int BTILE = 512;                       // floats: 32 pixels x 64 bytes per wave and buffer
-    static_assert((2 * ATILE + 2 * NW * BTILE) * 4 <= 64 * 1024, "LDS");
+    constexpr int BTILE = 512;                       // floats: 32 pixels x 64 bytes per wave (wave-private, ONE buffer:
+                                                     // a wave's LDS instructions execute in order, the store of the next
+                                                     // image is issued behind the last transposing read of this one)
+    constexpr int TAB = 256;                         // table pitch: OH, OW <= 256
+    static_assert((2 * ATILE + NW * BTILE) * 4 + 2 * 4 * TAB * 2 <= 64 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) float ldsA[2 * ATILE];
-    __shared__ __attribute__((aligned(16))) float ldsB[2 * NW * BTILE];
+    __shared__ __attribute__((aligned(16))) float ldsB[NW * BTILE];
+    __shared__ unsigned short rtab[4 * TAB], ctab[4 * TAB];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -2214,6 +2223,24 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bfb_kernel(const WgradArgs
     const unsigned rec_lane = (unsigned)chunk * (unsigned)HW;     // + n * Cc * HW + ih * W + iw, x 32 bytes + half
     const int us = a.upsample ? 1 : 0;
     const bool refl = a.pad_mode == 1;
+    for (int i = tid; i < KS * (a.OH + a.OW); i += NT) {             // tap geometry tables (see the header comment)
+        const bool is_row = i < KS * a.OH;
+        const int e = is_row ? i : i - KS * a.OH;
+        const int L = is_row ? a.OH : a.OW, LL = is_row ? a.LH : a.LW;
+        const int kk = e / L, o = e - kk * L;
+        const int iv = o * a.stride + kk - a.pad;
+        int ivr = iv < 0 ? -iv : iv;
+        ivr = ivr >= LL ? 2 * (LL - 1) - ivr : ivr;
+        const bool ok = refl || ((unsigned)iv < (unsigned)LL);
+        const int src = (refl ? ivr : iv) >> us;
+        const unsigned short v = ok ? (unsigned short)(is_row ? src * a.W : src) : (unsigned short)0xffffu;
+        if (is_row) rtab[kk * TAB + o] = v; else ctab[kk * TAB + o] = v;
+    }
+    const unsigned short* rt = rtab + kh * TAB;
+    const unsigned short* ct = ctab + (t - kh * KS) * TAB;
+    // pixel steps without divisions in the loop: 16 and 32 pixels = (rows, columns) of the output map
+    const int rows16 = 16 / a.OW, cols16 = 16 - rows16 * a.OW;
+    const int rows32 = 32 / a.OW, cols32 = 32 - rows32 * a.OW;
     int pn, poh, pow_;                               // output pixel of this lane in the first half of the next iteration
     {
         const int p = p_begin + (lane >> 2);
@@ -2222,36 +2249,33 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bfb_kernel(const WgradArgs
         poh = r / a.OW;
         pow_ = r - poh * a.OW;
     }
-    auto rec_offset = [&](int n, int oh, int ow, bool in_range) -> unsigned {
-        const int ih = oh * a.stride + dh, iw = ow * a.stride + dw;
-        int ihr = ih < 0 ? -ih : ih;
-        int iwr = iw < 0 ? -iw : iw;
-        ihr = ihr >= a.LH ? 2 * (a.LH - 1) - ihr : ihr;
-        iwr = iwr >= a.LW ? 2 * (a.LW - 1) - iwr : iwr;
-        const bool inb = ((unsigned)ih < (unsigned)a.LH) && ((unsigned)iw < (unsigned)a.LW);
-        const bool ok = rec_ok && in_range && (refl || inb);
-        const int ihs = (refl ? ihr : ih) >> us, iws = (refl ? iwr : iw) >> us;
-        return ok ? (((unsigned)n * (unsigned)Cc * (unsigned)HW + rec_lane + (unsigned)(ihs * a.W + iws)) * 32u
-                     + (unsigned)((lane & 1) * 16)) : OG_OOB;
-    };
     int p_ld = p_begin + (lane >> 2);                // pixel index of (pn, poh, pow_)
+    const unsigned half16 = (unsigned)((lane & 1) * 16);
     auto load_b = [&](f32x4 (&rb)[2]) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            // second half: 16 pixels further (OW need not divide 16: carry into rows / images)
-            int n = pn, oh = poh, ow = pow_ + 16 * h;
-            while (ow >= a.OW) { ow -= a.OW; oh += 1; }
-            while (oh >= a.OH) { oh -= a.OH; n += 1; }
-            const unsigned off = rec_offset(n, oh, ow, p_ld + 16 * h < p_end);
+            int n = pn, oh = poh, ow = pow_;
+            if (h == 1) {                            // second half: 16 pixels further
+                ow += cols16;
+                const int c = ow >= a.OW ? 1 : 0;
+                ow -= c ? a.OW : 0;
+                oh += rows16 + c;
+                while (oh >= a.OH) { oh -= a.OH; n += 1; }
+            }
+            const unsigned r = rt[oh], c = ct[ow];
+            const bool ok = rec_ok && (p_ld + 16 * h < p_end) && r != 0xffffu && c != 0xffffu;
+            const unsigned off = ok ? ((unsigned)n * (unsigned)Cc * (unsigned)HW + rec_lane + r + c) * 32u + half16 : OG_OOB;
             rb[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 0));
         }
         p_ld += BK;
-        pow_ += BK;
-        while (pow_ >= a.OW) { pow_ -= a.OW; poh += 1; }
+        pow_ += cols32;
+        const int c = pow_ >= a.OW ? 1 : 0;
+        pow_ -= c ? a.OW : 0;
+        poh += rows32 + c;
         while (poh >= a.OH) { poh -= a.OH; pn += 1; }
     };
-    auto store_b = [&](const f32x4 (&rb)[2], int buf) {
-        float* Bs = ldsB + (buf * NW + wid) * BTILE;
+    auto store_b = [&](const f32x4 (&rb)[2]) {
+        float* Bs = ldsB + wid * BTILE;
 #pragma unroll
         for (int h = 0; h < 2; ++h) *reinterpret_cast<f32x4*>(Bs + h * 256 + lane * 4) = rb[h];
     };
@@ -2299,7 +2323,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bfb_kernel(const WgradArgs
 
     typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4;
     auto mma = [&](int buf, auto&& mid) {
-        const char* Bs = reinterpret_cast<const char*>(ldsB + (buf * NW + wid) * BTILE) + b_rd;
+        const char* Bs = reinterpret_cast<const char*>(ldsB + wid * BTILE) + b_rd;
         const float* As = ldsA + buf * ATILE + lcol * ALD + lrow * 4;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -2327,17 +2351,18 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bfb_kernel(const WgradArgs
 
     // prologue: iteration 0 in LDS buffer 0, iteration 1 in registers
     f32x4 rb[2];
+    __syncthreads();                                  // tables
     load_a(); load_b(rb);
-    store_a(0); store_b(rb, 0);
+    store_a(0); store_b(rb);
     load_a(); load_b(rb);
     __syncthreads();
     // two iterations per trip (literal buffer indices); the loads of iteration k + 2 are issued in iteration k and stored to
     // LDS in iteration k + 1 (unconditionally: past the end they hit the range check or unused records)
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
-        mma(0, [&]() { store_a(1); store_b(rb, 1); load_a(); load_b(rb); });
+        mma(0, [&]() { store_a(1); store_b(rb); load_a(); load_b(rb); });
         __syncthreads();
-        mma(1, [&]() { store_a(0); store_b(rb, 0); load_a(); load_b(rb); });
+        mma(1, [&]() { store_a(0); store_b(rb); load_a(); load_b(rb); });
         __syncthreads();
     }
     if (kt < nk) mma(0, [] {});
@@ -3088,7 +3113,8 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
         // bf16 mode: bf16 operands, x from its channel-blocked copy in the workspace (conv_wgrad_bfb_kernel); without a
         // workspace (or on maps of fewer than 32 pixels) the fp32-gather kernels below
         const int Cpb = (Cin + 15) / 16 * 16;
-        bool bfb = bf && OHW % 32 == 0 && (double)N * Cpb * H * W * 2.0 < 4.0e9 && (plan_only || ws != nullptr);
+        bool bfb = bf && OHW % 32 == 0 && OH <= 256 && OW <= 256 && (long)(H - 1) * W < 65535 && ksize <= 4
+                   && (double)N * Cpb * H * W * 2.0 < 4.0e9 && (plan_only || ws != nullptr);
         const long xb_floats = bfb ? (((long)N * H * W * Cpb / 2 + 3) & ~3L) : 0;
         const __bf16* xb = nullptr;
         if (bfb) {
