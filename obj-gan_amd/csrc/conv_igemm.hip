@@ -2143,6 +2143,17 @@ __global__ __launch_bounds__(256) void reflect_ring_fold_kernel(const float* __r
     }
 }
 
+// fp32 -> bf16 (RNE), same layout: the dy operand of conv_wgrad_bfb_kernel.  n4 = elements / 4.
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ out, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+        bf16x4 h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[j] = (__bf16)v[j];
+        *reinterpret_cast<bf16x4*>(out + 4 * i) = h;
+    }
+}
+
 // ---- weight gradient of the bf16 mode: bf16 operands, x read from its channel-blocked copy -----------------------------
 // dW[m][c][t] = sum over output pixels p = (n, oh, ow) of dy[n][m][p] * x[n][c][p @ tap t]: GEMM rows = output channels,
 // K = pixels, columns = (tap, channel).  Both MFMA operands want eight consecutive K = pixels per lane; x arrives
@@ -2154,8 +2165,11 @@ __global__ __launch_bounds__(256) void reflect_ring_fold_kernel(const float* __r
 // Two such reads are the lane's operand of one 32x32x16 MFMA (measured on the box: tools/tr_probe.hip).  No fp32
 // gathers, no conversions of x, every geometry (zero / reflect padding, stride, nearest-x2 upsampling) is just the
 // record address of the lane's pixel; records are 32 bytes, so every load is 16-byte aligned whatever the tap shift.
-// dy rows: fp32 NCHW, rounded to bf16 by the thread that stages them into LDS (80-byte pitch: conflict-free
-// ds_read_b128), shared by the NW waves of the workgroup -- NW column groups (tap, 32 channels) per row tile.
+// dy rows: a bf16 copy of dy in its own NCHW layout (f32_to_bf16_kernel; pixels are already contiguous there), staged
+// into LDS as 16-byte pieces (80-byte pitch: conflict-free ds_read_b128), shared by the NW waves of the workgroup --
+// NW column groups (tap, 32 channels) per row tile.  (The first version read fp32 dy and rounded it on the way into
+// LDS: the kernel runs against the L2 -> L1 fill rate -- 40 KB per workgroup and iteration at 353 TFLOP/s = 4.5 TB/s --
+// and the fp32 rows were 24 of those 40 KB.)
 // One iteration = 32 pixels = two MFMAs per row group.  Requires (OH * OW) % 32 == 0 and OH, OW <= 256.
 // The record address of a lane's pixel costs VALU work every iteration (K = pixels: nothing is constant across the
 // loop): the tap geometry -- stride, padding, reflection, upsampling, bounds -- sits in two small LDS tables per
@@ -2164,13 +2178,13 @@ __global__ __launch_bounds__(256) void reflect_ring_fold_kernel(const float* __r
 // iteration next to 12 MFMAs: VALU bound, 344 TFLOP/s).
 template <int TM, int NW>
 __global__ __launch_bounds__(64 * NW) void conv_wgrad_bfb_kernel(const WgradArgs a, const __bf16* __restrict__ xb,
-                                                                 const int KS, const int Cp) {
+                                                                 const __bf16* __restrict__ dyb, const int KS, const int Cp) {
     constexpr int NT = 64 * NW;
     constexpr int BM = 32 * TM;
     constexpr int BK = 32;
     constexpr int ALD = 20;                          // floats per dy row in LDS: 64 bytes of bf16 + 16 (odd multiple of 16)
     constexpr int ATILE = BM * ALD;
-    constexpr int NA4 = BM * 8;                      // 16-byte fp32 pieces (4 pixels) of a row tile per iteration
+    constexpr int NA4 = BM * 4;                      // 16-byte bf16 pieces (8 pixels) of a row tile per iteration
     constexpr int NA_PER = (NA4 + NT - 1) / NT;
     constexpr int BTILE = 512;                       // floats: 32 pixels x 64 bytes per wave (wave-private, ONE buffer:
                                                      // a wave's LDS instructions execute in order, the store of the next
@@ -2215,7 +2229,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bfb_kernel(const WgradArgs
     __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
         (void*)xb, 0, (int)((unsigned)a.N * (unsigned)Cc * (unsigned)HW * 32u), OG_BUF_FLAGS);
     __amdgpu_buffer_rsrc_t dyres = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.dy, 0, (int)((unsigned)a.N * a.Cout * OHW * 4u), OG_BUF_FLAGS);
+        (void*)dyb, 0, (int)((unsigned)a.N * a.Cout * OHW * 2u), OG_BUF_FLAGS);
 
     // ---- x records: lane = (pixel j = l >> 2 of a 16-pixel half, chunk (l >> 1) & 1, 16-byte half l & 1)
     const int chunk = cg * 2 + ((lane >> 1) & 1);
@@ -2288,16 +2302,16 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bfb_kernel(const WgradArgs
 #pragma unroll
     for (int i = 0; i < NA_PER; ++i) {
         const int idx = tid + NT * i;
-        const int row = idx >> 3, q = idx & 7;
+        const int row = idx >> 2, q = idx & 3;
         const bool on = (NA4 % NT == 0 || idx < NA4) && (m0 + row) < a.m_end;
-        avoff[i] = on ? ((unsigned)(m0 + row) * (unsigned)OHW + q * 4u) * 4u : OG_OOB;
-        alds[i] = (NA4 % NT == 0 || idx < NA4) ? row * ALD + q * 2 : -1;
+        avoff[i] = on ? ((unsigned)(m0 + row) * (unsigned)OHW + q * 8u) * 2u : OG_OOB;
+        alds[i] = (NA4 % NT == 0 || idx < NA4) ? row * ALD + q * 4 : -1;
     }
     int n_ld = p_begin / OHW;                        // scalar (image, offset) of the next dy iteration
     int rem_ld = p_begin - n_ld * OHW;
     f32x4 ra[NA_PER];
     auto load_a = [&]() {
-        const int so = (n_ld * a.Cout * OHW + rem_ld) * 4;
+        const int so = (n_ld * a.Cout * OHW + rem_ld) * 2;
         rem_ld += BK;
         if (rem_ld >= OHW) { rem_ld = 0; n_ld += 1; }
 #pragma unroll
@@ -2307,12 +2321,8 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bfb_kernel(const WgradArgs
     auto store_a = [&](int buf) {
         float* As = ldsA + buf * ATILE;
 #pragma unroll
-        for (int i = 0; i < NA_PER; ++i) {
-            bf16x4 h;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) h[j] = (__bf16)ra[i][j];
-            if (NA4 % NT == 0 || alds[i] >= 0) *reinterpret_cast<bf16x4*>(As + alds[i]) = h;
-        }
+        for (int i = 0; i < NA_PER; ++i)
+            if (NA4 % NT == 0 || alds[i] >= 0) *reinterpret_cast<f32x4*>(As + alds[i]) = ra[i];
     };
 
     f32x16 acc[TM];
@@ -3116,15 +3126,21 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
         bool bfb = bf && OHW % 32 == 0 && OH <= 256 && OW <= 256 && (long)(H - 1) * W < 65535 && ksize <= 4
                    && (double)N * Cpb * H * W * 2.0 < 4.0e9 && (plan_only || ws != nullptr);
         const long xb_floats = bfb ? (((long)N * H * W * Cpb / 2 + 3) & ~3L) : 0;
+        const long dyb_floats = bfb ? (((long)N * Cout * OHW / 2 + 3) & ~3L) : 0;       // (OHW % 32 == 0: a multiple of 4)
         const __bf16* xb = nullptr;
+        const __bf16* dyb = nullptr;
         if (bfb) {
-            if (plan_only) { *ws_need += xb_floats; }
+            if (plan_only) { *ws_need += xb_floats + dyb_floats; }
             else {
-                if (ws_floats < xb_floats) return OG_BAD_ARGS;
+                if (ws_floats < xb_floats + dyb_floats) return OG_BAD_ARGS;
                 hipLaunchKernelGGL(nchw_to_nhwc_bf16_kernel, dim3(og_cdiv(H * W, 64), og_cdiv(Cpb, 64), N), dim3(256), 0, s,
                                    x, reinterpret_cast<__bf16*>(ws), Cin, H * W, Cpb);
+                const long n4 = (long)N * Cout * OHW / 4;
+                hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(og_stream_grid(n4, 256)), dim3(256), 0, s, dy,
+                                   reinterpret_cast<__bf16*>(ws + xb_floats), n4);
                 xb = reinterpret_cast<const __bf16*>(ws);
-                ws_used = xb_floats;
+                dyb = reinterpret_cast<const __bf16*>(ws + xb_floats);
+                ws_used = xb_floats + dyb_floats;
             }
         }
         int groups = og_cdiv(Cout, 32);
@@ -3231,8 +3247,8 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
                     else if (use3) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv>), grid, dim3(256), 0, s, a, ksize); \
                     else hipLaunchKernelGGL((conv_wgrad2_kernel<TMv>), grid, dim3(256), 0, s, a, ksize);
             if (bfb) {
-#define OG_WGB(TMv) if (nw == 8) hipLaunchKernelGGL((conv_wgrad_bfb_kernel<(TMv <= 6 ? TMv : 6), 8>), grid, dim3(512), 0, s, a, xb, ksize, Cpb); \
-                    else hipLaunchKernelGGL((conv_wgrad_bfb_kernel<TMv, 4>), grid, dim3(256), 0, s, a, xb, ksize, Cpb);
+#define OG_WGB(TMv) if (nw == 8) hipLaunchKernelGGL((conv_wgrad_bfb_kernel<(TMv <= 6 ? TMv : 6), 8>), grid, dim3(512), 0, s, a, xb, dyb, ksize, Cpb); \
+                    else hipLaunchKernelGGL((conv_wgrad_bfb_kernel<TMv, 4>), grid, dim3(256), 0, s, a, xb, dyb, ksize, Cpb);
                 switch (tm) {
                     case 1: OG_WGB(1) break;
                     case 2: OG_WGB(2) break;
