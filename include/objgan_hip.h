@@ -120,7 +120,9 @@ int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float*
                                 int PH, int PW, int wt_packed, int math, float* ws, long ws_floats, void* stream);
 /* dw[co][ci][kh][kw] = (accumulate ? dw : 0) + sum dy * x; ksize in {1,3,4}.  The reduction over pixels is split
  * across workgroups; the partial tiles go through ws (objgan_conv_wgrad_ws_floats floats, host-only query) and are
- * summed in split order: the weight gradient is bit-reproducible and dw needs no zero-fill. */
+ * summed in split order: the weight gradient is bit-reproducible and dw needs no zero-fill.  math 1: the workspace also
+ * holds the bf16 copies the kernel reads (x channel-blocked as in objgan_conv_igemm, dy in its own layout); without a
+ * workspace the call gathers the fp32 tensors and rounds them in registers (same values). */
 long objgan_conv_wgrad_ws_floats(int N, int Cin, int H, int W, int upsample, int pad_mode,
                                  int Cout, int OH, int OW, int ksize, int stride, int pad, int math);
 int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
