@@ -804,18 +804,18 @@ struct WgradArgs {
                               // r02: -8 % on the 194 / 388-channel weight gradients at 128^2, -20 % at 32^2.
 };
 
-__device__ __forceinline__ void og_wgrad_store(const WgradArgs& a, int m, int col, float v) {
+__device__ __forceinline__ void og_wgrad_store(const WgradArgs& a, int m, int col, float v, int split) {
     if (a.ws) {
-        a.ws[(size_t)blockIdx.y * a.ws_stride + (size_t)(m - a.m_begin) * a.ncol + col] = v;
+        a.ws[(size_t)split * a.ws_stride + (size_t)(m - a.m_begin) * a.ncol + col] = v;
     } else {
         float* p = a.dw + (size_t)m * a.ncol + col;
         *p = a.accumulate ? *p + v : v;
     }
 }
 // extra row j of the XR kernels: local row (m_end - m_begin) + j of the workspace slot
-__device__ __forceinline__ void og_wgrad_store_xr(const WgradArgs& a, int j, int col, float v) {
+__device__ __forceinline__ void og_wgrad_store_xr(const WgradArgs& a, int j, int col, float v, int split) {
     if (a.ws) {
-        a.ws[(size_t)blockIdx.y * a.ws_stride + (size_t)(a.m_end - a.m_begin + j) * a.ncol + col] = v;
+        a.ws[(size_t)split * a.ws_stride + (size_t)(a.m_end - a.m_begin + j) * a.ncol + col] = v;
     } else {
         float* p = a.dw + (size_t)(a.xr_begin + j) * a.ncol + col;
         *p = a.accumulate ? *p + v : v;
@@ -961,7 +961,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-                if (m < a.m_end) og_wgrad_store(a, m, col, acc[i][j][r]);
+                if (m < a.m_end) og_wgrad_store(a, m, col, acc[i][j][r], blockIdx.y);
             }
         }
     }
@@ -1000,8 +1000,12 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
     const int T = KS * KS;
     const int tiles_m = (a.m_end - a.m_begin + BM - 1) / BM;
     const int tiles_n = (a.ncol + BN - 1) / BN;
+    // XCD placement over both grid dimensions: all tiles of a pixel split on one XCD (they read the same dy / x pixels),
+    // an XCD takes a contiguous range of splits (see conv_wgrad_bfb_kernel)
     const int nwg = tiles_m * tiles_n;
-    const int wg = og_xcd_remap(blockIdx.x, nwg);
+    const int vid = og_xcd_remap(blockIdx.x + nwg * blockIdx.y, nwg * gridDim.y);
+    const int split = vid / nwg;
+    const int wg = vid - split * nwg;
     const int tile_m = wg % tiles_m;
     const int tile_n = wg / tiles_m;
     const int m0 = a.m_begin + tile_m * BM;
@@ -1010,7 +1014,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
     const int OHW = a.OH * a.OW;
     const int HW = a.H * a.W;
     const int Npix = a.N * OHW;
-    const int p_begin = blockIdx.y * a.pix_per_split;
+    const int p_begin = split * a.pix_per_split;
     const int p_end = min(Npix, p_begin + a.pix_per_split);
     if (p_begin >= p_end) return;
 
@@ -1245,13 +1249,13 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(const WgradArgs a, con
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-            if (m < a.m_end) og_wgrad_store(a, m, ocol, acc[i][r]);
+            if (m < a.m_end) og_wgrad_store(a, m, ocol, acc[i][r], split);
         }
     }
     if (XR > 0 && has_x && lrow == 0) {
 #pragma unroll
         for (int j = 0; j < XR; ++j)
-            if (j < a.xr_count) og_wgrad_store_xr(a, j, ocol, accx[j]);
+            if (j < a.xr_count) og_wgrad_store_xr(a, j, ocol, accx[j], split);
     }
 }
 
@@ -1765,8 +1769,12 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad3_kernel(const WgradArgs a,
     const int T = KS * KS;
     const int tiles_m = (a.m_end - a.m_begin + BM - 1) / BM;
     const int tiles_n = (a.ncol + BN - 1) / BN;
+    // XCD placement over both grid dimensions: all tiles of a pixel split on one XCD (they read the same dy / x pixels),
+    // an XCD takes a contiguous range of splits (see conv_wgrad_bfb_kernel)
     const int nwg = tiles_m * tiles_n;
-    const int wg = og_xcd_remap(blockIdx.x, nwg);
+    const int vid = og_xcd_remap(blockIdx.x + nwg * blockIdx.y, nwg * gridDim.y);
+    const int split = vid / nwg;
+    const int wg = vid - split * nwg;
     const int tile_m = wg % tiles_m;
     const int tile_n = wg / tiles_m;
     const int m0 = a.m_begin + tile_m * BM;
@@ -1775,7 +1783,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad3_kernel(const WgradArgs a,
     const int OHW = a.OH * a.OW;
     const int HW = a.H * a.W;
     const int Npix = a.N * OHW;
-    const int p_begin = blockIdx.y * a.pix_per_split;
+    const int p_begin = split * a.pix_per_split;
     const int p_end = min(Npix, p_begin + a.pix_per_split);
     if (p_begin >= p_end) return;
 
@@ -2097,13 +2105,13 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad3_kernel(const WgradArgs a,
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-            if (m < a.m_end) og_wgrad_store(a, m, col, acc[i][r]);
+            if (m < a.m_end) og_wgrad_store(a, m, col, acc[i][r], split);
         }
     }
     if (XR > 0 && has_x && lrow == 0) {
 #pragma unroll
         for (int j = 0; j < XR; ++j)
-            if (j < a.xr_count) og_wgrad_store_xr(a, j, col, accx[j]);
+            if (j < a.xr_count) og_wgrad_store_xr(a, j, col, accx[j], split);
     }
 }
 
@@ -2394,7 +2402,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bfb_kernel(const WgradArgs
             const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
             if (m < a.m_end) {
                 if (a.ws) a.ws[(size_t)split * a.ws_stride + (size_t)(m - a.m_begin) * a.ncol + ocol] = acc[i][r];
-                else og_wgrad_store(a, m, ocol, acc[i][r]);         // one split
+                else og_wgrad_store(a, m, ocol, acc[i][r], split);  // one split
             }
         }
     }
