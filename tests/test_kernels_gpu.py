@@ -761,6 +761,36 @@ def test_bf16_blocked_operand_equals_the_fp32_gather_form(dev, case):
     assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
 
 
+def test_bf16_weight_gradient_places_single_products(dev):
+    """One non-zero in x, one in dy: the weight gradient of the bf16 mode (bf16 records through wave-private LDS images and
+    transposing reads) must hold exactly one product, at (m, c, kh, kw).  Found a hipcc miscompile of an element-wise
+    short -> bf16 vector copy in round 3 that the random-data tests only showed as 'wrong everywhere'."""
+    ops = _ops()
+    prev = ops.get_conv_math()
+    ops.set_conv_math("bf16")
+    try:
+        for (N, Cin, Cout, H, W, k, s, p, probes) in [
+                (1, 32, 32, 8, 8, 3, 1, 1, [(0, 0, 0, 0, 0, 0, 0), (0, 5, 3, 4, 7, 2, 4), (0, 17, 6, 1, 20, 6, 2),
+                                            (0, 31, 7, 7, 31, 7, 7), (0, 9, 4, 4, 3, 5, 5)]),
+                (2, 40, 64, 8, 8, 3, 1, 1, [(1, 33, 2, 2, 40, 2, 2), (1, 39, 5, 6, 63, 4, 6), (0, 16, 0, 7, 1, 0, 6)]),
+                (2, 48, 96, 16, 16, 4, 2, 1, [(1, 47, 9, 3, 95, 4, 1), (0, 3, 15, 15, 64, 7, 7), (1, 20, 0, 0, 5, 0, 0)])]:
+            OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+            for (n, c, h, w, m, oh, ow) in probes:
+                x = torch.zeros(N, Cin, H, W, device=dev)
+                x[n, c, h, w] = 1.0
+                g = torch.zeros(N, Cout, OH, OW, device=dev)
+                g[n, m, oh, ow] = 1.0
+                dw = ops._conv_wgrad(x, g, Cout, k, s, p, 0, False)
+                torch.cuda.synchronize()
+                kh, kw = h - oh * s + p, w - ow * s + p
+                want = [[m, c, kh, kw]] if 0 <= kh < k and 0 <= kw < k else []
+                assert torch.nonzero(dw).tolist() == want, ((N, Cin, Cout, H, k, s), (n, c, h, w, m, oh, ow))
+                if want:
+                    assert float(dw[m, c, kh, kw]) == 1.0
+    finally:
+        ops.set_conv_math(prev)
+
+
 def test_roi_align_backward_is_bit_reproducible(dev):
     """The ordered ROIAlign backward (per-image tap table + fixed-order gather) gives the same bits on every run --
     also when most samples of an image share a few anchor pixels (the hot path's 1/16 scale on feature-scale boxes)
