@@ -210,6 +210,39 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert lib.objgan_conv_packed_floats(388, 194, 9) == 512 * 208 * 9 * 3 // 2     # room for the 6-byte bf16x3 bank
 
 
+def test_workspace_queries_are_host_only_and_consistent():
+    """The *_ws_floats entry points plan on the host (no HIP call): they must answer without a GPU, and the answers must
+    cover what the kernels put there -- split partials, and in the bf16 mode the bf16 copies of the operands."""
+    from objgan_hip import _lib
+    lib = _lib.load()
+    up = lambda n, m: (n + m - 1) // m * m
+    # forward 192 -> 384, 4x4 stride 2 at 128^2, N = 16: a large unsplit launch
+    geo = (16, 192, 128, 128, 0, 0, 384, 192, 16, 0, 16, 64, 64, 2, 64, 64, 1, 1, 0, 0)
+    assert lib.objgan_conv_igemm_ws_floats(*geo, 2, 0) == 0                    # bf16x3: nothing to reduce
+    blocked = up(16 * 128 * 128 * up(192, 16) // 2, 4)
+    assert lib.objgan_conv_igemm_ws_floats(*geo, 1, 0) == blocked              # bf16: the channel-blocked copy of x
+    # a discriminator head: 8x8 maps, K = 16 * 768 -- split along K in every mode, slots are whole outputs
+    head = (16, 768, 8, 8, 0, 0, 1536, 768, 16, 0, 16, 4, 4, 2, 4, 4, 1, 1, 0, 0)
+    n2 = lib.objgan_conv_igemm_ws_floats(*head, 2, 0)
+    assert n2 > 0 and n2 % (16 * 1536 * 4 * 4) == 0
+    n1 = lib.objgan_conv_igemm_ws_floats(*head, 1, 0)
+    assert n1 >= up(16 * 8 * 8 * 768 // 2, 4) + 16 * 1536 * 4 * 4
+    # stride-2 data gradient in phases: only the bf16 mode needs a workspace (the copy of dY)
+    assert lib.objgan_conv_dgrad_s2_phases_ws_floats(16, 384, 64, 64, 2) == 0
+    assert lib.objgan_conv_dgrad_s2_phases_ws_floats(16, 384, 64, 64, 1) == up(16 * 64 * 64 * 384 // 2, 4)
+    # weight gradient: split partials; bf16 mode adds the blocked copy of x and the bf16 copy of dy
+    wg = (16, 192, 128, 128, 0, 0, 384, 64, 64, 4, 2, 1)
+    w2, w1 = lib.objgan_conv_wgrad_ws_floats(*wg, 2), lib.objgan_conv_wgrad_ws_floats(*wg, 1)
+    assert w2 > 0 and w2 % (384 * 192 * 16) == 0
+    assert w1 >= blocked + 16 * 384 * 64 * 64 // 2
+    # ROIAlign backward, ordered: per image [header | touched pixels | anchor starts | sorted samples | geometry]
+    r = lib.objgan_roi_align_backward_ws_floats(16, 160, 384, 64, 64, 6, 6)
+    assert r > 0 and r % 16 == 0
+    assert lib.objgan_roi_align_backward_ws_floats(16, 300, 384, 64, 64, 6, 6) == 0        # > 256 rois: scatter path
+    assert lib.objgan_norm_ws_floats(16, 96, 128 * 128, 1) > 2 * 96                         # totals + partial slots
+    assert lib.objgan_channel_sum_ws_floats(16, 96, 128 * 128) >= 0
+
+
 def test_state_dict_keys_match_reference_contract():
     import model as M
     keys = set(M.G_NET(80).state_dict().keys())
