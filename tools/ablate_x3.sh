@@ -1,4 +1,5 @@
 #!/bin/bash
+# main-loop ablation of the bf16x3 kernel (development build, OG_ABLATE bits): profiles/r03_ablation_bf16x3_mainloop.txt
 mkdir -p gpurun_out; export TMPDIR=/tmp
 for abl in 0 62 64 126 127; do
   for f in objd_l3 res2_128; do
