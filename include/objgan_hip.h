@@ -252,7 +252,8 @@ int objgan_adam_step(float* p, const float* g, float* m, float* v, long n, doubl
  * (state: 3 doubles {steps, beta1^steps, beta2^steps}, initialised {0, 1, 1}; coef: 3 floats scratch).
  * Replaces the host-side `if float(errObjSSD) > 0:` of reference image_generation/trainer.py:429,440
  * under data parallelism: the flag rides behind the gradient arena through the all-reduce, so every
- * rank takes or skips the same update without a device->host read. */
+ * rank takes or skips the same update without a device->host read.  grad_scale < 0: the gradient is divided by
+ * flag[0] -- after the all-reduce the number of ranks that contributed one -- instead of a fixed 1 / world size. */
 int objgan_adam_step_gated(float* p, const float* g, float* m, float* v, long n, double lr, double beta1,
                            double beta2, double eps, double* state, const float* flag, float* coef,
                            float grad_scale, void* stream);

@@ -180,13 +180,16 @@ __global__ __launch_bounds__(256) void adam_gated_kernel(float* __restrict__ p, 
                                                          long n, float lr, float beta1, float beta2,
                                                          float omb1, float omb2,
                                                          float eps, const float* __restrict__ coef,
-                                                         float grad_scale) {
+                                                         const float* __restrict__ flag, float grad_scale) {
     if (coef[0] <= 0.f) return;
     const float step_size = coef[1];
     const float bc2_sqrt = coef[2];
+    // grad_scale < 0: divide by the flag itself -- under data parallelism the all-reduced flag counts the ranks that
+    // contributed a gradient, and the mean is taken over THOSE (a rank without boxes of the wanted scale adds zeros)
+    const float gs = grad_scale < 0.f ? 1.0f / flag[0] : grad_scale;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long)gridDim.x * blockDim.x) {
-        const float gi = g[i] * grad_scale;
+        const float gi = g[i] * gs;
         const float mi = m[i] + (gi - m[i]) * omb1;
         const float vi = v[i] * beta2 + omb2 * gi * gi;
         m[i] = mi;
@@ -266,6 +269,7 @@ int objgan_adam_step(float* p, const float* g, float* m, float* v, long n, doubl
 
 // Adam step gated by the device flag `flag[0] > 0`; `state` = 3 doubles on the device initialised to
 // {0, 1, 1}, `coef` = 3 floats of device scratch (see adam_gate_kernel).  Nothing is read back.
+// grad_scale < 0: the gradient is divided by flag[0] (the number of ranks that contributed, after the all-reduce).
 int objgan_adam_step_gated(float* p, const float* g, float* m, float* v, long n, double lr, double beta1,
                            double beta2, double eps, double* state, const float* flag, float* coef,
                            float grad_scale, void* stream) {
@@ -276,7 +280,7 @@ int objgan_adam_step_gated(float* p, const float* g, float* m, float* v, long n,
                        lr, beta1, beta2);
     hipLaunchKernelGGL(adam_gated_kernel, dim3(og_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream,
                        p, g, m, v, n, (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1),
-                       (float)(1.0 - beta2), (float)eps, coef, grad_scale);
+                       (float)(1.0 - beta2), (float)eps, coef, flag, grad_scale);
     return og_launch_status();
 }
 

@@ -543,7 +543,9 @@ class condGANTrainer(object):
         for opt, handle, active in pending:
             if handle is not None:
                 self._wait(handle)                   # stream-side wait, the host runs on
-                opt.step(grad_scale=inv_world, gated=True)
+                # grad_scale < 0: mean over the ranks that CONTRIBUTED a gradient (the all-reduced flag counts them;
+                # all of them for the patch / shape discriminators, possibly fewer for the object discriminators)
+                opt.step(grad_scale=-1.0, gated=True)
             elif active:
                 opt.step(grad_scale=inv_world)
 

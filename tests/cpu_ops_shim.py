@@ -140,6 +140,8 @@ def adam_step_gated_(p, g, m, v, lr, beta1, beta2, eps, state, flag, coef, grad_
     state[1] *= beta1
     state[2] *= beta2
     coef[0] = 1.0
+    if grad_scale < 0:                       # divide by the flag (ranks that contributed a gradient)
+        grad_scale = 1.0 / float(flag.reshape(-1)[0])
     adam_step_(p, g, m, v, lr, beta1, beta2, eps, int(state[0].item()), grad_scale=grad_scale, n=n)
 
 

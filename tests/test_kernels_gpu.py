@@ -761,6 +761,29 @@ def test_bf16_blocked_operand_equals_the_fp32_gather_form(dev, case):
     assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
 
 
+def test_gated_adam_divides_by_the_flag_on_request(dev):
+    """grad_scale < 0: the gated Adam step divides the (all-reduced) gradient by the (all-reduced) flag -- the number of
+    ranks that contributed -- instead of a fixed 1 / world size."""
+    ops = _ops()
+    n = 5000
+    g = torch.Generator().manual_seed(8)
+    p0 = torch.randn(n, generator=g)
+    grad = torch.randn(n, generator=g)
+    outs = []
+    for flag, scale in ((3.0, -1.0), (3.0, 1.0 / 3.0)):
+        pd = p0.clone().to(dev)
+        gbuf = torch.cat([grad, torch.tensor([flag])]).to(dev)
+        md, vd = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        state = torch.tensor([0.0, 1.0, 1.0], dtype=torch.float64, device=dev)
+        coef = torch.zeros(3, device=dev)
+        for _ in range(2):
+            ops.adam_step_gated_(pd, gbuf, md, vd, 2e-4, 0.5, 0.999, 1e-8, state, gbuf[n:], coef, grad_scale=scale, n=n)
+        torch.cuda.synchronize()
+        outs.append((pd.cpu(), md.cpu(), vd.cpu()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_bf16_weight_gradient_places_single_products(dev):
     """One non-zero in x, one in dy: the weight gradient of the bf16 mode (bf16 records through wave-private LDS images and
     transposing reads) must hold exactly one product, at (m, c, kh, kw).  Found a hipcc miscompile of an element-wise
