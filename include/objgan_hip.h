@@ -53,7 +53,7 @@ int objgan_roi_align_backward(const float* top_grad, const float* rois, float* b
 /* The same adjoint with a FIXED summation order (bit-reproducible): the taps of an image's ROI samples are sorted once
  * by anchor pixel (stable) into a table in `ws`, and every (pixel, channel) gathers its taps in a fixed order.  The
  * reference's kernel (and objgan_roi_align_backward) leaves the order of its atomicAdds unspecified.  ws: at least
- * objgan_roi_align_backward_ws_floats(...) floats; shapes the query returns 0 for (more than 256 rois, maps over
+ * objgan_roi_align_backward_ws_floats(...) floats; shapes the query returns 0 for (more than 512 rois, maps over
  * ~5K pixels) and ws == NULL take objgan_roi_align_backward's path. */
 long objgan_roi_align_backward_ws_floats(int batch_size, int num_rois, int channels, int height, int width,
                                          int aligned_height, int aligned_width);
@@ -106,7 +106,7 @@ long objgan_conv_igemm_ws_floats(int N, int C, int H, int W, int upsample, int p
 /* ring (may be NULL): data gradient of a ReflectionPad2d(1) convolution without the padded intermediate -- the
  * GEMM runs over the padded pixel grid (PH = OHf + 2, PW = OWf + 2, y is the UNPADDED gradient), interior
  * pixels are stored into y, the one-pixel border into ring [N*M][2*PW + 2*PH]; objgan_reflect_ring_fold then
- * adds the border back at its mirror positions.  Only for calls objgan_conv_bank_layout classifies as 1 or 4. */
+ * adds the border back at its mirror positions.  Only for calls objgan_conv_bank_layout classifies as 1, 3 or 4. */
 int objgan_reflect_ring_fold(const float* ring, float* y, long planes, int H, int W, void* stream);
 /* Data gradient of a stride-2 convolution whose four output parity phases have the same number
  * of taps (k=4, pad 1, even sizes): one launch for all phases.  x = dY [N,Cout,OH,OW],

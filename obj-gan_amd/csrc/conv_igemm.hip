@@ -2982,7 +2982,7 @@ static int og_igemm_setup(PackArgs& p, IgemmArgs& a, int& MT, const float* x, co
         a.tap[t] = (int)(((unsigned)w_ << 16) | ((unsigned)h & 0xffffu));
     }
     if (!(osh == 1 && osw == 1 && PH == OHf && PW == OWf) && (bias || act)) return OG_BAD_ARGS;
-    if (ring && p.m_major != 1 && p.m_major != 4) return OG_BAD_ARGS;     // ring mode: conv_igemm3_kernel only (ask objgan_conv_bank_layout)
+    if (ring && p.m_major != 1 && p.m_major != 3 && p.m_major != 4) return OG_BAD_ARGS;     // ring mode: conv_igemm3_kernel only (ask objgan_conv_bank_layout)
     return OG_OK;
 }
 

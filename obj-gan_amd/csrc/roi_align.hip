@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(
 // One writer per element, no atomics on floats, bit-reproducible.  Same per-term arithmetic as roi_align_bwd_kernel
 // (and the reference's CUDA kernel, which leaves the order of its atomicAdds unspecified).  r02's privatised scatter
 // took 146 us per launch, an ordered gather without the table 609 us.
-#define ROI_TAB_MAX 256           // rois per call the table path takes (the hot path has 160: 16 images x 10)
+#define ROI_TAB_MAX 512           // rois per call the table path takes (the hot path has 160: 16 images x 10; 320 at B = 32)
 struct RoiTabDims { int maxs, maxp, o_start, o_sorted, o_smp, stride; };
 static inline RoiTabDims roi_tab_dims(int num_rois, int HW, int S) {
     RoiTabDims d;
@@ -167,12 +167,12 @@ static inline RoiTabDims roi_tab_dims(int num_rois, int HW, int S) {
 __global__ __launch_bounds__(256) void roi_tap_table_kernel(
     const float* __restrict__ rois, int* __restrict__ ws, int num_rois,
     int C, int H, int W, int AH, int AW, float spatial_scale, RoiTabDims d) {
-    extern __shared__ int tab_lds[];                                    // cnt[HW], st[HW], soff[maxs]
+    extern __shared__ int tab_lds[];                                    // cnt[HW], st[HW], soff[maxs] (16 bit)
     const int HW = H * W;
     const int S = AH * AW;
     int* cnt = tab_lds;
     int* st = tab_lds + HW;
-    int* soff = tab_lds + 2 * HW;
+    unsigned short* soff = reinterpret_cast<unsigned short*>(tab_lds + 2 * HW);     // anchor pixel, 0xffff: no gradient
     __shared__ int s_list[ROI_TAB_MAX];                                 // rois of this image, in index order
     __shared__ int s_wave[4];
     __shared__ int s_scan[2 * 256];
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void roi_tap_table_kernel(
         RoiSample g;
         roi_geometry(rois + (size_t)r * 5, spatial_scale, H, W, AH, AW, sidx, g);
         const int off = g.valid ? g.off : -1;
-        soff[i] = off;
+        soff[i] = (unsigned short)(off >= 0 ? off : 0xffff);
         smp[4 * i + 0] = off;
         smp[4 * i + 1] = __float_as_int(g.h_ratio);
         smp[4 * i + 2] = __float_as_int(g.w_ratio);
@@ -250,8 +250,8 @@ __global__ __launch_bounds__(256) void roi_tap_table_kernel(
     __syncthreads();
     // stable placement: a sample's slot = start of its anchor + the number of earlier samples with the same anchor
     for (int i = threadIdx.x; i < n_smp; i += blockDim.x) {
-        const int off = soff[i];
-        if (off < 0) continue;
+        const unsigned short off = soff[i];
+        if (off == 0xffff) continue;
         int rank = 0;
         for (int j = 0; j < i; ++j) rank += soff[j] == off;
         sorted[st[off] + rank] = i;
@@ -400,7 +400,7 @@ long objgan_roi_align_backward_ws_floats(int batch_size, int num_rois, int chann
     const int S = aligned_height * aligned_width;
     const long HW = (long)height * width;
     if (batch_size <= 0 || num_rois <= 0 || num_rois > ROI_TAB_MAX || S > ROI_MAX_SAMPLES) return 0;
-    if ((2 * HW + (long)num_rois * S) * 4 > 64 * 1024) return 0;                  // table kernel's LDS
+    if (2 * HW * 4 + (long)num_rois * S * 2 > 64 * 1024 || HW >= 65535) return 0;  // table kernel's LDS, 16-bit anchors
     if ((double)batch_size * channels * (double)HW >= 2.0e9) return 0;
     return (long)batch_size * roi_tab_dims(num_rois, (int)HW, S).stride;
 }
@@ -425,7 +425,7 @@ int objgan_roi_align_backward_ordered(const float* top_grad, const float* rois, 
     const int S = aligned_height * aligned_width;
     const int HW = height * width;
     const RoiTabDims d = roi_tab_dims(num_rois, HW, S);
-    const size_t lds = (2 * (size_t)HW + (size_t)num_rois * S) * sizeof(int);
+    const size_t lds = 2 * (size_t)HW * sizeof(int) + (((size_t)num_rois * S * 2 + 3) & ~(size_t)3);
     hipLaunchKernelGGL(roi_tap_table_kernel, dim3(batch_size), dim3(256), lds, (hipStream_t)stream,
                        rois, reinterpret_cast<int*>(ws), num_rois, channels, height, width,
                        aligned_height, aligned_width, spatial_scale, d);

@@ -822,7 +822,7 @@ def test_roi_align_backward_is_bit_reproducible(dev):
     from objgan_hip import _lib
     rng = np.random.RandomState(3)
     for trial, (B, C, H, W, scale, per) in enumerate([(4, 96, 64, 64, 1 / 16., 10), (3, 40, 32, 32, 1.0, 7),
-                                                     (2, 8, 20, 27, 0.5, 1)]):
+                                                     (2, 8, 20, 27, 0.5, 1), (32, 8, 64, 64, 1 / 16., 10)]):   # 320 rois
         n = B * per
         rois = np.zeros((n, 5), np.float32)
         rois[:, 0] = np.repeat(np.arange(B), per)

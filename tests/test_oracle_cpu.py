@@ -238,7 +238,8 @@ def test_workspace_queries_are_host_only_and_consistent():
     # ROIAlign backward, ordered: per image [header | touched pixels | anchor starts | sorted samples | geometry]
     r = lib.objgan_roi_align_backward_ws_floats(16, 160, 384, 64, 64, 6, 6)
     assert r > 0 and r % 16 == 0
-    assert lib.objgan_roi_align_backward_ws_floats(16, 300, 384, 64, 64, 6, 6) == 0        # > 256 rois: scatter path
+    assert lib.objgan_roi_align_backward_ws_floats(32, 320, 384, 64, 64, 6, 6) > 0         # B = 32: still the table path
+    assert lib.objgan_roi_align_backward_ws_floats(16, 600, 384, 64, 64, 6, 6) == 0        # > 512 rois: scatter path
     assert lib.objgan_norm_ws_floats(16, 96, 128 * 128, 1) > 2 * 96                         # totals + partial slots
     assert lib.objgan_channel_sum_ws_floats(16, 96, 128 * 128) >= 0
 
