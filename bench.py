@@ -20,10 +20,12 @@ One JSON line is printed by rank 0: the contract fields plus
                 that the headline carries no event overhead), against the fp32 MFMA peak;
                 traffic = HBM bytes per launch from the rocprofv3 --pmc passes kept in profiles/
   cpu_baseline  the CPU oracle (oracle/torch_model.py, a port of the reference path) timed on this host's
-                physical cores at the BASELINE batch: 1 warm-up + `--cpu-baseline-steps` (default 1) timed steps at
+                physical cores at the BASELINE batch: 1 warm-up + `--cpu-baseline-steps` (default 3) timed steps at
                 batch 16 (~90 s each; child process with a hard time limit, batch-8 fallback).  The unmodified
                 reference cannot run on the GPU box (no /root/reference there): `reference_vs_port` carries the
                 reference-vs-port timing measured in the build container (tools/cpu_ref_vs_port.py)
+  side_configs  (default N = 1 run only) two short side records measured after the headline, not the metric: the same
+                step on the true fp32 MFMA, and BASELINE config 5 (bf16 mixed precision, batch 32)
   comm          (data-parallel runs) what the gradient exchange moved and what it cost: bytes all-reduced per step,
                 collectives per step, time the compute stream stood still waiting for them, stand-alone all-reduce
                 times of the arena sizes, RCCL version
@@ -174,14 +176,14 @@ def _cpu_baseline_worker(sample_batch, threads, timed_steps, seed=1234):
 REF_VS_PORT_JSON = os.path.join(ROOT, "profiles", "r03_cpu_reference_vs_port.json")
 
 
-def cpu_baseline(sample_batch=16, timed_steps=1, timeout_s=410):
+def cpu_baseline(sample_batch=16, timed_steps=3, timeout_s=630):
     """The oracle timed on the host's physical cores at the BASELINE batch (1 warm-up + timed
     steps), in a child process with a hard time limit so that the default bench run always finishes; if
     the full-batch run does not fit the limit a batch-8 sample is reported instead.  One thread per
     PHYSICAL core: with all 256 hardware threads of the GPU box's two EPYC 9575F the same step did not
     finish in 420 s (fork-join cost of the many small operators), with 128 it takes about 90 s.  Default
-    sample: one warm-up step + ONE timed step at batch 16 (the first step runs ~5 % slower than a warmed one;
-    should the timed step not fit the limit, the un-warmed one is reported and says so)."""
+    sample: one warm-up step + THREE timed steps at batch 16 (the first step runs ~5 % slower than a warmed one;
+    should the timed steps not fit the limit, the un-warmed one is reported and says so)."""
     import subprocess
     threads = max(1, min(128, (os.cpu_count() or 2) // 2))
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads),
@@ -212,6 +214,30 @@ def cpu_baseline(sample_batch=16, timed_steps=1, timeout_s=410):
         note += "batch %d: no step finished; " % batch
     return {"value": None, "unit": "images/sec", "cores": threads, "kind": "port", "cpu": _cpu_model(),
             "sample": note}
+
+
+def side_configs(steps=6, warmup=2, timeout_s=240):
+    """Two short side records of the default N = 1 run, each a child `bench.py` on the same GPU after the headline is
+    measured (they are NOT the metric): the same step on the true fp32 MFMA (`--math fp32`, the arithmetic of rounds
+    1-2) and BASELINE config 5 (`--math bf16 --batch 32`: bf16 matrix-core inputs, fp32 accumulation)."""
+    import subprocess
+    out = {}
+    for key, extra in (("fp32_mfma_b16", ["--math", "fp32"]), ("config5_bf16_b32", ["--math", "bf16", "--batch", "32"])):
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup),
+               "--no-cpu-baseline", "--no-side-configs"] + extra
+        try:
+            txt = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout_s).stdout.decode()
+            line = [ln for ln in txt.splitlines() if ln.startswith("{")][-1]
+            r = json.loads(line)
+            out[key] = {k: r.get(k) for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype")}
+            out[key]["per_gpu_batch"] = r["config"]["per_gpu_batch"]
+            if "roofline" in r:
+                out[key]["roofline"] = {k: r["roofline"].get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "traffic")}
+            if "conv_total" in r:
+                out[key]["conv_total"] = r["conv_total"]
+        except Exception as e:                                   # noqa: BLE001 (a side record never fails the headline)
+            out[key] = {"error": repr(e)[:200]}
+    return out
 
 
 def _respawn_under_torchrun(n):
@@ -322,8 +348,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 16; 32 with --math bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-steps", type=int, default=1,
-                    help="timed CPU steps after the warm-up step (default 1; 0: report the un-warmed first step)")
+    ap.add_argument("--cpu-baseline-steps", type=int, default=3,
+                    help="timed CPU steps after the warm-up step (default 3, SURVEY.md 8d; 0: report the un-warmed "
+                         "first step)")
+    ap.add_argument("--no-side-configs", action="store_true",
+                    help="skip the two short side records of the default N = 1 run (true fp32 MFMA arithmetic; BASELINE "
+                         "config 5 = bf16 mixed precision at batch 32)")
     ap.add_argument("--no-is-monitor", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--force-ddp", action="store_true",
@@ -438,7 +468,8 @@ def main():
             "value": round(n_img / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp32" if args.math != "bf16" else "bf16-in/fp32-acc (mixed precision, config 5)",
+            "dtype": {"fp32": "fp32", "bf16x3": "fp32 (bf16x3: operands split exactly three ways on the bf16 MFMA)",
+                      "bf16": "bf16-in/fp32-acc (mixed precision, config 5)"}[args.math],
             "data": "synthetic",
             "config": {"workload": workload_name + ("" if args.no_is_monitor else "+IS-monitor"),
                        "d_streams_timed_pass": timed_streams,
@@ -481,10 +512,13 @@ def main():
                                    "measured_in": "second pass of %d steps ON ONE STREAM with hipEvents around every conv "
                                                   "launch (%.1f ms/step; the timed pass above runs without them and "
                                                   "on %d streams)" % (prof_steps, 1000.0 * prof_dt, timed_streams),
-                                   "peak_note": ({"bf16x3": "2500 TFLOP/s dense bf16 MFMA / 6 products per fp32 MAC; an "
-                                                            "MFMA-only ablation of this loop (no loads, no LDS, no "
-                                                            "barriers) runs at 211-229 TFLOP/s on random data: "
-                                                            "profiles/r03_ablation_bf16x3_mainloop.txt"}
+                                   "peak_note": ({"bf16x3": "2500 TFLOP/s dense bf16 MFMA / 6 products per fp32 MAC.  "
+                                                            "Stand-alone probe of the instruction (tools/mfma_rate.hip, "
+                                                            "profiles/r04_mfma_rate.txt): 2.46-2.48 PF on zero operands "
+                                                            "(32 cycles per MFMA and SIMD at 2.38 GHz), 1.78-1.85 PF on "
+                                                            "random / split-fp32 operands (same 32 cycles, clock held at "
+                                                            "1.75-1.82 GHz by the power limit) = 297-308 TFLOP/s of "
+                                                            "fp32-equivalent work for this arithmetic on real data"}
                                                  .get(args.math))}
                 res["kernel_breakdown"] = [
                     {"kernel": c[0], "ms_per_step": round(c[1] / prof_steps, 3),
@@ -506,6 +540,9 @@ def main():
             except Exception:                                   # noqa: BLE001 (CPU build / gloo)
                 comm["rccl_version"] = None
             res["comm"] = comm
+        if (world == 1 and not use_dist and not args.no_side_configs and not args.no_cpu_baseline
+                and args.workload == "stage3_obj" and args.math == "bf16x3" and args.batch == 16):
+            res["side_configs"] = side_configs()
         if world == 1 and not args.no_cpu_baseline and args.workload == "stage3_obj":
             res["cpu_baseline"] = cpu_baseline(timed_steps=args.cpu_baseline_steps,
                                                timeout_s=300 + 110 * args.cpu_baseline_steps)

@@ -74,7 +74,7 @@ struct IgemmArgs {
                          // added to a zeroed y with fp32 atomics (partial-coverage launches, first-generation kernel)
     float* ws;           // split-K partials [splits][ws_stride]: y-shaped, then (ring mode) ring-shaped
     long ws_stride;
-    int nphase;          // > 1 (v2 kernel only): blockIdx.z = output phase p with its own tap table
+    int nphase;          // > 1 (conv_igemm3_kernel only): workgroup id % nphase = output phase p with its own tap table
                          // tap[p*8 ..], packed bank wt + p*M*Kpad and output offset (ooh, oow) = (p>>1, p&1)
     float* ring;         // != nullptr (conv_igemm3_kernel only): data gradient of a ReflectionPad2d(1) convolution.
                          // The GEMM runs over the PADDED grid (PH = OHf + 2, PW = OWf + 2); interior pixels are
@@ -1319,14 +1319,20 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
     const int Npix = a.N * a.PH * a.PW;
     const int tiles_m = (a.m_end - a.m_begin + BM - 1) / BM;
     const int tiles_n = (Npix + BN - 1) / BN;
+    // Phase-fastest workgroup order: the nphase output phases of a stride-2 data gradient / up-convolution read the SAME
+    // source pixels, so the phases of a tile sit next to each other in the XCD-remapped id (same L2, same time) -- with
+    // the phase on blockIdx.z they ran a whole grid apart and every phase re-fetched the source from HBM / MALL
+    // (r03: 562 MB fetched per launch of the 4-phase 192 -> 96 up-convolution for 136 MB algorithmic).
+    const int nph = a.nphase > 1 ? a.nphase : 1;
     const int nwg = tiles_m * tiles_n;
-    const int wg = og_xcd_remap(blockIdx.x, nwg);
+    const int wgp = og_xcd_remap(blockIdx.x, nwg * nph);
+    const int phase = wgp % nph;
+    const int wg = wgp / nph;
     const int tile_m = wg % tiles_m;
     const int tile_n = wg / tiles_m;
     const int m0 = a.m_begin + tile_m * BM;
     const int n0 = tile_n * BN;
 
-    const int phase = a.nphase > 1 ? (int)blockIdx.z : 0;
     const int tapbase = phase * 8;
     const int HW = a.H * a.W;
     __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
@@ -2799,7 +2805,7 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed, float* ws, lo
         ProfRec* pr = prof_begin(nw == 8 ? OG_CAT_IGEMM2_NW8(TM) : OG_CAT_IGEMM2(TM),
                                  2.0 * (a.m_end - a.m_begin) * (double)a.K * (double)Npix * nph, s);
         prof_meta(pr, 0, TM, a.m_end - a.m_begin, a.C, a.T, a.N, a.PH * nph, a.PW, a.stride * (a.osh > 1 ? -1 : 1), splits);
-        rc = launch_igemm2(a, TM, dim3(full_rows * tiles_n, splits, nph), s, nw);
+        rc = launch_igemm2(a, TM, dim3(full_rows * tiles_n * nph, splits, 1), s, nw);
         prof_end(pr, s);
         if (rc != OG_OK) return rc;
     }
@@ -2808,7 +2814,7 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed, float* ws, lo
         ProfRec* pr = prof_begin(nw == 8 ? OG_CAT_IGEMM2_NW8(rest) : OG_CAT_IGEMM2(rest),
                                  2.0 * (a.m_end - a.m_begin) * (double)a.K * (double)Npix * nph, s);
         prof_meta(pr, 0, rest, a.m_end - a.m_begin, a.C, a.T, a.N, a.PH * nph, a.PW, a.stride * (a.osh > 1 ? -1 : 1), splits);
-        rc = launch_igemm2(a, rest, dim3(tiles_n, splits, nph), s, nw);
+        rc = launch_igemm2(a, rest, dim3(tiles_n * nph, splits, 1), s, nw);
         prof_end(pr, s);
         if (rc != OG_OK) return rc;
     }
@@ -3035,7 +3041,7 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
 }
 
 // Data gradient of a stride-2 convolution whose four output parity phases have the same tap count
-// (k = 4, pad 1, even sizes: 2x2 taps each): ONE launch, blockIdx.z = phase.  x = dY [N, Cout, OH, OW],
+// (k = 4, pad 1, even sizes: 2x2 taps each): ONE launch, the phase is the fastest digit of the workgroup id.  x = dY [N, Cout, OH, OW],
 // y = dX [N, Cin, 2*PH, 2*PW] (every element is written by exactly one phase: no pre-zeroing).
 // dh/dw/src_tap: 4 phases x Tg entries, phase p = (row parity << 1) | column parity.
 // wt: 4 * ceil(1.5 * Cin * Tg * ceil16(Cout)) floats (<= 4 x objgan_conv_packed_floats(Cin, Cout, Tg)).

@@ -364,4 +364,4 @@ def test_bench_main_end_to_end_on_the_cpu_shim(monkeypatch, capsys):
     assert abs(roof["achieved"] - 100.0) < 1e-6 and abs(roof["frac"] - 100.0 / roof["peak"]) < 1e-3
     assert roof["traffic"] is None or roof["traffic"] > 1e8             # committed PMC record of that kernel
     assert res["conv_total"]["tflops"] == roof["achieved"] and res["kernel_breakdown"][0]["launches_per_step"] == 2.0
-    assert "cpu_baseline" not in res and res["dtype"] == "fp32"
+    assert "cpu_baseline" not in res and "side_configs" not in res and res["dtype"].startswith("fp32 (bf16x3")
