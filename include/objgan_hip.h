@@ -141,8 +141,9 @@ int objgan_lstm_bidir_forward(const float* table, const long* captions, const in
 
 /* ---- normalisation + GLU / LeakyReLU / residual (BatchNorm train mode, InstanceNorm) -------- */
 /* `sums` (forward) / `bsums` (backward): statistics workspace of objgan_norm_ws_floats(N, C, HW, per_channel) floats
- * (host-only query): the per-workgroup partial sums of a group are combined in slot order by the last workgroup to
- * arrive -- bit-reproducible statistics, no fp32 atomics; the totals are the first 2G floats. */
+ * (host-only query): every workgroup of the statistics launch stores its partial pair into its own slot, a second
+ * one-thread-per-group kernel (norm_partials_sum_kernel) adds the slots in slot order -- bit-reproducible statistics, no
+ * fp32 atomics, nothing to pre-zero; the totals are the first 2G floats. */
 long objgan_norm_ws_floats(int N, int C, int HW, int per_channel);
 int objgan_norm_forward(const float* x, float* y, const float* residual,
                         const float* gamma, const float* beta,
@@ -272,6 +273,17 @@ int objgan_resize_pil_kmax(int max_in, int S);
 int objgan_resize_pil_rgb8(const unsigned char* src, const long* offs, const int* hs, const int* ws, int B,
                            int Hmax, int kmax, int S, int* coef_scratch, unsigned char* tmp_scratch, float* out,
                            void* stream);
+
+/* ---- per-box instance masks on the device (the loader side of the path) --------------------
+ * Replaces the four `skimage.transform.resize(mask, [s, s])` calls per box of reference
+ * image_generation/miscc/load.py:160-176 (s = 32, 64, 128, 256 from the 64 x 64 instance mask): `count` square
+ * float64 masks src[count][n][n] (n <= 64) -> out[k][count][sizes[k]][sizes[k]] float64 for nsizes <= 4 sizes (out: HOST
+ * array of device pointers).  skimage's defaults as scipy.ndimage evaluates them (Gaussian anti-aliasing when
+ * shrinking, order-1 zoom, mode 'mirror', grid_mode, clip to the input range), in float64 and in scipy's operation
+ * order: bit for bit scipy's results.  taps[k * 17 ..]: the ntaps[k] = 2 radius + 1 <= 17 normalised weights of the
+ * anti-aliasing filter of size k (host array; ntaps[k] = 0 when sizes[k] >= n). */
+int objgan_mask_resize(const double* src, int count, int n, int nsizes, const int* sizes, double* const* out,
+                       const int* ntaps, const double* taps, void* stream);
 
 /* ---- measurement aid (bench.py roofline leg): hipEvent-bracketed conv launches ------------------ */
 int objgan_prof_enable(int on);

@@ -585,7 +585,8 @@ int objgan_attn_general_forward(const float* x, const float* src, const unsigned
     return og_launch_status();
 }
 
-// dsrc must be zero on entry (it is accumulated with atomics); dattn may be null.
+// dsrc is fully written (per-wave partial tiles in `ws`, summed in wave order by a second kernel): nothing to pre-zero,
+// no atomics; dattn may be null.
 static inline int attn_bwd_chunks(int Q) {
     // pixels per wave: enough chunks that a wave's partial tile is amortised, while the grid still covers the chip
     int chunks = Q / (64 * 4 * 16);

@@ -819,7 +819,8 @@ int objgan_act_backward(const float* dy, const float* y, float* dz, long total, 
     return og_launch_status();
 }
 
-// out [C] is zeroed here, then out[c] = sum over n, i of x[n, c, i]
+// out[c] = sum over n, i of x[n, c, i]: fully written (one workgroup per channel, or S partial slots per channel in `ws`
+// summed in slot order by channel_partials_sum_kernel); nothing is pre-zeroed
 // floats of workspace objgan_channel_sum needs: [C * S partial sums]
 long objgan_channel_sum_ws_floats(int N, int C, int HW) {
     if (N <= 0 || C <= 0 || HW <= 0) return 0;

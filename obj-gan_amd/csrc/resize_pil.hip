@@ -119,6 +119,127 @@ __global__ __launch_bounds__(256) void pil_vertical_kernel(PilGeom g, const int*
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Per-box instance masks of the training loader (reference image_generation/miscc/load.py:160-176): every 64 x 64
+// mask is resized to the feature scale (32) and to the three branch sizes (64 / 128 / 256) with
+// skimage.transform.resize's defaults = scipy.ndimage.gaussian_filter (when shrinking) + scipy.ndimage.zoom(order 1,
+// mode 'mirror', grid_mode) + clip.  One workgroup per mask: the source in LDS as float64, every output element
+// evaluated in float64 in scipy's operation order (NI_Correlate1D symmetric branch, axis 0 then axis 1; NI_ZoomShift
+// order 1: t = 0, t += (x * wy) * wx per neighbour, row-major) -- this file is built with -ffp-contract=off -- so the
+// results equal scipy's BIT FOR BIT (tests/test_kernels_gpu.py; oracle/mask_resize.py states the same order on the CPU).
+#define MASK_MAX_N 64
+#define MASK_MAX_TAPS 17
+#define MASK_MAX_SIZES 4
+struct MaskResizeArgs {
+    const double* src;              // [count][n][n]
+    double* out[MASK_MAX_SIZES];    // out[k]: [count][size[k]][size[k]]
+    int size[MASK_MAX_SIZES];
+    int ntaps[MASK_MAX_SIZES];      // 2 * radius + 1 of the anti-aliasing filter of size k (0: none)
+    double taps[MASK_MAX_SIZES][MASK_MAX_TAPS];
+    int n, nsizes;
+};
+
+__device__ __forceinline__ int mask_mirror(int i, int n) {      // d c b | a b c d | c b a
+    if (n == 1) return 0;
+    const int p = 2 * n - 2;
+    i %= p;
+    if (i < 0) i += p;
+    return i < n ? i : p - i;
+}
+
+__device__ __forceinline__ double mask_map_mirror(double c, int n) {      // map_coordinate, NI_EXTEND_MIRROR
+    if (n <= 1) return 0.0;
+    const int sz2 = 2 * n - 2;
+    if (c < 0) {
+        c = sz2 * (double)(int)(-c / sz2) + c;
+        c = c <= 1 - n ? c + sz2 : -c;
+    } else if (c > n - 1) {
+        c -= sz2 * (double)(int)(c / sz2);
+        if (c >= n) c = sz2 - c;
+    }
+    return c;
+}
+
+__global__ __launch_bounds__(256) void mask_resize_kernel(const MaskResizeArgs a) {
+    __shared__ double A[MASK_MAX_N * MASK_MAX_N];
+    __shared__ double Bf[MASK_MAX_N * MASK_MAX_N];
+    __shared__ double red[2][4];
+    const int n = a.n, nn = n * n, tid = threadIdx.x;
+    const double* src = a.src + (size_t)blockIdx.x * nn;
+    double lo = 1.0 / 0.0, hi = -1.0 / 0.0;
+    for (int i = tid; i < nn; i += 256) {
+        const double v = src[i];
+        A[i] = v;
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = lo; red[1][tid >> 6] = hi; }
+    __syncthreads();
+    lo = fmin(fmin(red[0][0], red[0][1]), fmin(red[0][2], red[0][3]));
+    hi = fmax(fmax(red[1][0], red[1][1]), fmax(red[1][2], red[1][3]));
+    // sizes that need no filter first (they read the unfiltered source), the shrinking ones after them: each filters
+    // A -> Bf (axis 0) -> A (axis 1) from a re-loaded source
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int k = 0; k < a.nsizes; ++k) {
+            const int S = a.size[k];
+            const bool shrink = a.ntaps[k] > 0;
+            if (shrink != (pass == 1)) continue;
+            double* out = a.out[k] + (size_t)blockIdx.x * S * S;
+            if (S == n) {
+                for (int i = tid; i < nn; i += 256) out[i] = A[i];
+                continue;
+            }
+            if (shrink) {
+                __syncthreads();
+                for (int i = tid; i < nn; i += 256) A[i] = src[i];
+                __syncthreads();
+                const int c = a.ntaps[k] / 2;
+                for (int ax = 0; ax < 2; ++ax) {
+                    const double* X = ax == 0 ? A : Bf;
+                    double* Y = ax == 0 ? Bf : A;
+                    for (int i = tid; i < nn; i += 256) {
+                        const int r = i / n, q = i - r * n;
+                        const int l = ax == 0 ? r : q;
+                        double tmp = X[i] * a.taps[k][c];
+                        for (int jj = -c; jj < 0; ++jj) {
+                            const int l0 = mask_mirror(l + jj, n), l1 = mask_mirror(l - jj, n);
+                            const double x0 = ax == 0 ? X[l0 * n + q] : X[r * n + l0];
+                            const double x1 = ax == 0 ? X[l1 * n + q] : X[r * n + l1];
+                            tmp = tmp + (x0 + x1) * a.taps[k][jj + c];
+                        }
+                        Y[i] = tmp;
+                    }
+                    __syncthreads();
+                }
+            }
+            const double zoom = (double)n / (double)S;
+            for (int e = tid; e < S * S; e += 256) {
+                const int oy = e / S, ox = e - oy * S;
+                const double cy = mask_map_mirror(((double)oy + 0.5) * zoom - 0.5, n);
+                const double cx = mask_map_mirror(((double)ox + 0.5) * zoom - 0.5, n);
+                const int iy = (int)floor(cy), ix = (int)floor(cx);
+                const double wy1 = cy - iy, wx1 = cx - ix, wy0 = 1.0 - wy1, wx0 = 1.0 - wx1;
+                const int i0 = mask_mirror(iy, n), i1 = mask_mirror(iy + 1, n);
+                const int j0 = mask_mirror(ix, n), j1 = mask_mirror(ix + 1, n);
+                double t = 0.0;
+                t += (A[i0 * n + j0] * wy0) * wx0;
+                t += (A[i0 * n + j1] * wy0) * wx1;
+                t += (A[i1 * n + j0] * wy1) * wx0;
+                t += (A[i1 * n + j1] * wy1) * wx1;
+                t = t < lo ? lo : t;
+                t = t > hi ? hi : t;
+                out[e] = t;
+            }
+        }
+    }
+}
+
 extern "C" {
 
 // Number of taps Pillow allots per output pixel for the largest source side of a batch:
@@ -151,6 +272,29 @@ int objgan_resize_pil_rgb8(const unsigned char* src, const long* offs, const int
                        tmp_scratch);
     hipLaunchKernelGGL(pil_vertical_kernel, dim3(gx, S, B), dim3(256), 0, s, g, (const int*)coef_scratch,
                        (const unsigned char*)tmp_scratch, out);
+    return og_launch_status();
+}
+
+// count square masks src[count][n][n] (float64, n <= 64) -> nsizes resized copies out[k][count][sizes[k]][sizes[k]]
+// (float64, device pointers in a HOST array), skimage.transform.resize defaults as scipy evaluates them (see
+// mask_resize_kernel).  taps[k * 17 ..]: the normalised anti-aliasing Gaussian of size k (ntaps[k] = 2 radius + 1 <= 17
+// values, host array; 0 taps: not shrinking) -- the caller computes them in double exactly as scipy does.
+int objgan_mask_resize(const double* src, int count, int n, int nsizes, const int* sizes, double* const* out,
+                       const int* ntaps, const double* taps, void* stream) {
+    OG_ENTRY();
+    if (count <= 0) return OG_OK;
+    if (!src || !sizes || !out || !ntaps || n < 2 || n > MASK_MAX_N || nsizes < 1 || nsizes > MASK_MAX_SIZES)
+        return OG_BAD_ARGS;
+    MaskResizeArgs a;
+    a.src = src; a.n = n; a.nsizes = nsizes;
+    for (int k = 0; k < nsizes; ++k) {
+        if (!out[k] || sizes[k] < 1 || sizes[k] > 4096 || ntaps[k] < 0 || ntaps[k] > MASK_MAX_TAPS ||
+            (ntaps[k] > 0 && (!taps || !(ntaps[k] & 1))) || (sizes[k] < n) != (ntaps[k] > 0))
+            return OG_BAD_ARGS;
+        a.out[k] = out[k]; a.size[k] = sizes[k]; a.ntaps[k] = ntaps[k];
+        for (int j = 0; j < ntaps[k]; ++j) a.taps[k][j] = taps[k * MASK_MAX_TAPS + j];
+    }
+    hipLaunchKernelGGL(mask_resize_kernel, dim3(count), dim3(256), 0, (hipStream_t)stream, a);
     return og_launch_status();
 }
 

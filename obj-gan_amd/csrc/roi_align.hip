@@ -400,7 +400,12 @@ long objgan_roi_align_backward_ws_floats(int batch_size, int num_rois, int chann
     const int S = aligned_height * aligned_width;
     const long HW = (long)height * width;
     if (batch_size <= 0 || num_rois <= 0 || num_rois > ROI_TAB_MAX || S > ROI_MAX_SAMPLES) return 0;
-    if (2 * HW * 4 + (long)num_rois * S * 2 > 64 * 1024 || HW >= 65535) return 0;  // table kernel's LDS, 16-bit anchors
+    // table kernel's LDS: dynamic (two HW-int histograms + 16-bit anchors) + its static arrays (s_list, s_scan, s_wave);
+    // 16-bit anchors; and its stable rank is quadratic in the samples of ONE image -- beyond ~64 rois x 36 samples of a
+    // single image (the hot path has 10) the unordered scatter of objgan_roi_align_backward is the faster kernel
+    const long static_lds = (long)(ROI_TAB_MAX + 4 + 2 * 256) * 4;
+    if (2 * HW * 4 + (long)num_rois * S * 2 + static_lds > 64 * 1024 || HW >= 65535) return 0;
+    if ((long)og_cdiv(num_rois, batch_size) * S > 64 * 36 && (long)num_rois * S > 8 * 64 * 36) return 0;
     if ((double)batch_size * channels * (double)HW >= 2.0e9) return 0;
     return (long)batch_size * roi_tab_dims(num_rois, (int)HW, S).stride;
 }

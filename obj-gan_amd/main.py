@@ -55,11 +55,14 @@ def parse_args(argv=None):
     parser.add_argument('--BATCH_SIZE', type=int, default=24)
     parser.add_argument('--BRANCH_NUM', type=int, default=3)
     parser.add_argument('--FLAG', dest='FLAG', action='store_true')
-    # beyond the reference surface (both off by default = the reference's host-side item tuple):
+    # beyond the reference surface (all off by default = the reference's host-side item tuple):
     parser.add_argument('--device_hmaps', action='store_true',
                         help='hand over the box masks only and rebuild the layout maps on the device')
     parser.add_argument('--device_imgs', action='store_true',
                         help='hand over the decoded 8-bit images and resize them on the device (Pillow-exact)')
+    parser.add_argument('--device_masks', action='store_true',
+                        help='hand over the raw 64 x 64 instance masks and resize them on the device (scipy-exact); '
+                             'implies --device_hmaps')
     return parser.parse_args(argv)
 
 
@@ -144,7 +147,8 @@ def build_training(args, rank, world, device):
     output_dir = '{0}/output_image_generation/{1}_{2}'.format(args.output_dir, cfg.DATASET_NAME, timestamp)
     dataset = TrainDataset(cfg.DATA_DIR, 'train', base_size=cfg.TREE.BASE_SIZE,
                            device_hmaps=getattr(args, "device_hmaps", False),
-                           device_imgs=getattr(args, "device_imgs", False))
+                           device_imgs=getattr(args, "device_imgs", False),
+                           device_masks=getattr(args, "device_masks", False))
     assert dataset
     dataloader = build_loader(dataset, cfg.TRAIN.BATCH_SIZE, workers=int(cfg.WORKERS), rank=rank,
                               world=world, seed=args.manualSeed or 0, shuffle=True)

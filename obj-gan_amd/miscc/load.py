@@ -291,27 +291,42 @@ def resize_mask(mask, size):
     return np.clip(out, mask.min(), mask.max())
 
 
-def get_hmaps_rois(anno_dict, hmap_size, fmap_size, cats_index_dict, with_hmaps=True):
+def get_hmaps_rois(anno_dict, hmap_size, fmap_size, cats_index_dict, with_hmaps=True, with_resized_masks=True):
     """Layout maps (per-category sums of the instance masks), per-slot box masks at every branch
     size and at the 32x32 feature scale, and the box-map tensors of the shape generator
-    (reference load.py:152-191)."""
+    (reference load.py:152-191).
+    with_resized_masks=False (the `device_masks` hand-over of TrainDataset): no host resize at all -- bt_masks[0] carries
+    the raw instance masks (the 64-px branch mask IS the raw mask: resizing 64 -> 64 is the identity), the other mask
+    arrays are empty ([0, S, S]) and `prepare_data` produces them on the device (objgan_hip.ops.resize_masks)."""
     rois = anno_dict['rois']
     fm_rois = anno_dict['fm_rois']
     raw_masks = anno_dict['masks']
     num_rois = anno_dict['num_rois']
     nb, ncat, R = cfg.TREE.BRANCH_NUM, len(cats_index_dict), cfg.ROI.BOXES_NUM
     hmaps = [np.zeros((ncat, hmap_size[b], hmap_size[b]) if with_hmaps else (0,)) for b in range(nb)]
-    bt_masks = [np.zeros((R, hmap_size[b], hmap_size[b])) for b in range(nb)]
-    fm_bt_masks = np.zeros((R, hmap_size[0] // 2, hmap_size[0] // 2))
-    for r in range(num_rois):
-        mask = raw_masks[r]
-        cat = int(rois[0][r, 4])
-        fm_bt_masks[r] = resize_mask(mask, hmap_size[0] // 2)
-        for b in range(nb):
-            re_mask = resize_mask(mask, hmap_size[b])
-            bt_masks[b][r] = re_mask
-            if with_hmaps:
-                hmaps[b][cat] += re_mask
+    if not with_resized_masks:
+        if with_hmaps:
+            raise ValueError("get_hmaps_rois: the device mask hand-over rebuilds the layout maps on the device too")
+        bt_masks = [np.zeros((R, hmap_size[0], hmap_size[0]))] + [np.zeros((0, hmap_size[b], hmap_size[b])) for b in range(1, nb)]
+        fm_bt_masks = np.zeros((0, hmap_size[0] // 2, hmap_size[0] // 2))
+        for r in range(num_rois):
+            m = np.asarray(raw_masks[r], dtype=np.float64)
+            if m.shape != (hmap_size[0], hmap_size[0]):
+                raise ValueError("get_hmaps_rois: raw instance masks must be %d x %d for the device hand-over, got %s"
+                                 % (hmap_size[0], hmap_size[0], m.shape))
+            bt_masks[0][r] = m
+    else:
+        bt_masks = [np.zeros((R, hmap_size[b], hmap_size[b])) for b in range(nb)]
+        fm_bt_masks = np.zeros((R, hmap_size[0] // 2, hmap_size[0] // 2))
+        for r in range(num_rois):
+            mask = raw_masks[r]
+            cat = int(rois[0][r, 4])
+            fm_bt_masks[r] = resize_mask(mask, hmap_size[0] // 2)
+            for b in range(nb):
+                re_mask = resize_mask(mask, hmap_size[b])
+                bt_masks[b][r] = re_mask
+                if with_hmaps:
+                    hmaps[b][cat] += re_mask
     bbox_maps_fwd = np.zeros((R, ncat, hmap_size[0], hmap_size[0]))
     bbox_maps_bwd = np.zeros((R, ncat, hmap_size[0], hmap_size[0]))
     bbox_fmaps = np.zeros((R, fmap_size, fmap_size))

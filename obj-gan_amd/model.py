@@ -656,6 +656,8 @@ class _Encoder(nn.Sequential):
         while i < len(mods):
             conv = mods[i]
             if isinstance(mods[i + 1], nn.BatchNorm2d):
+                if x2 is not None:
+                    raise ValueError("_Encoder: a two-part input needs an activation-only first layer")
                 y = ops.conv2d(x, conv.weight, None, 2, 1, "zeros")
                 x = _bn_act(y, mods[i + 1], "lrelu")
                 i += 3

@@ -77,6 +77,7 @@ SIGNATURES = {
     "objgan_ema_update": [_ptr, _ptr, _c_long, _c_float, _c_float, _ptr],
     "objgan_resize_pil_kmax": [_c_int, _c_int],
     "objgan_resize_pil_rgb8": [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr],
+    "objgan_mask_resize": [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr],
     "objgan_prof_enable": [_c_int],
     "objgan_conv_bank_layout": [_c_int] * 10,
     "objgan_prof_collect": [_ptr, _ptr, _ptr],

@@ -15,13 +15,17 @@ CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 LIB_PATH = os.path.join(HERE, "libobjgan_hip.so")
 OBJ_DIR = os.path.join(CSRC, "build")
 
-BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # OBJGAN_DEV=1: development build -- the OG_* switches of csrc/common.h (OG_KNOB) read the environment
 if os.environ.get("OBJGAN_DEV") == "1":
     BASE_FLAGS.append("-DOG_DEV")
 # ROIAlign index math must be bit-exact with the reference C loop: no FMA contraction.
 # The Pillow-exact image resize evaluates its filter coefficients in double in Pillow's operation order.
-PER_FILE_FLAGS = {"roi_align.hip": ["-ffp-contract=off"], "resize_pil.hip": ["-ffp-contract=off"]}
+# -munsafe-fp-atomics (hardware fp32 atomic add instead of a CAS loop) only where a float atomic is left: the
+# reference-signature objgan_roi_align_backward (unordered scatter, as the CUDA original) and the first-generation /
+# partial-coverage split-K path of conv_igemm.hip; the training step itself runs without fp32 atomics.
+PER_FILE_FLAGS = {"roi_align.hip": ["-ffp-contract=off", "-munsafe-fp-atomics"], "resize_pil.hip": ["-ffp-contract=off"],
+                  "conv_igemm.hip": ["-munsafe-fp-atomics"]}
 
 
 def _hipcc():

@@ -64,7 +64,10 @@ import os as _os
 _MATH_IDS = {"fp32": 0, "bf16": 1, "bf16x3": 2}
 # default: bf16x3 -- fp32 results at 1.5x the speed of the fp32 MFMA on the hot-path shapes; measured against fp64 its
 # error is at or below the fp32 MFMA's on every operator (tests/test_kernels_gpu.py, profiles/r03_parity.txt)
-_MATH = {"mode": _MATH_IDS.get(_os.environ.get("OBJGAN_CONV_MATH", "bf16x3"), 2)}
+if _os.environ.get("OBJGAN_CONV_MATH", "bf16x3") not in _MATH_IDS:      # a typo must not silently change the arithmetic
+    raise _lib.ObjganHipError("OBJGAN_CONV_MATH=%r: must be one of %s"
+                              % (_os.environ["OBJGAN_CONV_MATH"], sorted(_MATH_IDS)))
+_MATH = {"mode": _MATH_IDS[_os.environ.get("OBJGAN_CONV_MATH", "bf16x3")]}
 
 
 def set_conv_math(mode):
@@ -297,12 +300,12 @@ def _conv_dgrad(g, w, N, Cin, H, W, stride, pad, refl, upsample, cacheable=True)
             dxl = torch.empty((N, Cin, LH, LW), dtype=_F32, device=g.device)
             ring = torch.empty((N * Cin, 2 * TW + 2 * TH), dtype=_F32, device=g.device)
             _igemm(g, w, None, dxl, N, Cout, OH, OW, 0, 0, Cout, Cin, k * k, 1,
-                   dh, dw, st, TH, TW, 1, LH, LW, 1, 1, 0, 0, 0, ring=ring)
+                   dh, dw, st, TH, TW, 1, LH, LW, 1, 1, 0, 0, 0, ring=ring, cache=cacheable)
             _lib.call("objgan_reflect_ring_fold", _p(ring), _p(dxl), N * Cin, LH, LW, _stream())
         else:
             dxl = torch.empty((N, Cin, TH, TW), dtype=_F32, device=g.device)
             _igemm(g, w, None, dxl, N, Cout, OH, OW, 0, 0, Cout, Cin, k * k, 1,
-                   dh, dw, st, TH, TW, 1, TH, TW, 1, 1, 0, 0, 0)
+                   dh, dw, st, TH, TW, 1, TH, TW, 1, 1, 0, 0, 0, cache=cacheable)
             if refl:
                 folded = torch.empty((N, Cin, LH, LW), dtype=_F32, device=g.device)
                 _lib.call("objgan_reflect_fold", _p(dxl), _p(folded), N * Cin, LH, LW, _stream())
@@ -1095,6 +1098,50 @@ def resize_pil_bilinear(images, sizes, device):
         _lib.call("objgan_resize_pil_rgb8", _p(src), _p(offs_d), _p(hs), _p(ws), B, Hmax, kmax, S,
                   _p(coef), _p(tmp), _p(out), _stream())
         outs.append(out)
+    return outs
+
+
+# ---- per-box instance masks: skimage.transform.resize (= two scipy.ndimage calls) on the device ----------
+def _gaussian_taps(sigma, truncate=4.0):
+    """the normalised weights scipy.ndimage.gaussian_filter1d uses for this sigma, computed like scipy computes them
+    (float64 numpy, radius = int(truncate * sigma + 0.5))"""
+    import numpy as np
+    radius = int(truncate * float(sigma) + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+    return phi / phi.sum()
+
+
+def resize_masks(masks, sizes):
+    """masks: float64 [..., n, n] on the GPU (n <= 64; the 64 x 64 instance masks of a batch) -> one float64
+    [..., S, S] tensor per S in `sizes` (<= 4), each bit for bit `skimage.transform.resize(mask, [S, S])` as scipy
+    evaluates skimage's defaults (reference miscc/load.py:160-176: S = 32, 64, 128, 256); csrc/resize_pil.hip."""
+    if not masks.is_cuda or masks.dtype != torch.float64 or masks.dim() < 2 or masks.shape[-1] != masks.shape[-2]:
+        raise _lib.ObjganHipError("resize_masks: float64 [..., n, n] on the GPU (got %s %s on %s; no CPU path)"
+                                  % (masks.dtype, tuple(masks.shape), masks.device))
+    n = int(masks.shape[-1])
+    sizes = [int(S) for S in sizes]
+    if not 2 <= n <= 64 or not 1 <= len(sizes) <= 4:
+        raise _lib.ObjganHipError("resize_masks: n <= 64 and at most four sizes")
+    src = _c(masks)
+    lead = tuple(src.shape[:-2])
+    count = 1
+    for d in lead:
+        count *= int(d)
+    outs = [torch.empty(lead + (S, S), dtype=torch.float64, device=src.device) for S in sizes]
+    ntaps, taps = [], [0.0] * (17 * len(sizes))
+    for k, S in enumerate(sizes):
+        if S < n:
+            w = _gaussian_taps((n / float(S) - 1.0) / 2.0)
+            if len(w) > 17:
+                raise _lib.ObjganHipError("resize_masks: shrinking %d -> %d is outside the table (radius <= 8)" % (n, S))
+            ntaps.append(len(w))
+            taps[17 * k:17 * k + len(w)] = [float(v) for v in w]
+        else:
+            ntaps.append(0)
+    outp = (ctypes.c_void_p * len(sizes))(*[o.data_ptr() for o in outs])
+    _lib.call("objgan_mask_resize", _p(src), count, n, len(sizes), _iarr(sizes), outp, _iarr(ntaps),
+              (ctypes.c_double * len(taps))(*taps), _stream())
     return outs
 
 

@@ -22,14 +22,18 @@ class TrainDataset(data.Dataset):
     rebuilds them on the device from the per-slot box masks (`hmaps_from_box_masks`).  The 80-channel
     float64 maps are 55 MB per sample on the host and 27 MB over PCIe, the ten box masks they are
     sums of are 3.4 MB.
+    `device_masks=True` goes one step further: no `skimage.transform.resize` in the loader workers at all (33 calls
+    per sample in the reference, load.py:160-176) -- the items carry the ten raw 64 x 64 instance masks (0.3 MB) and
+    `prepare_data` resizes them to 32 / 128 / 256 on the device (`ops.resize_masks`, bit for bit scipy's arithmetic).
 
     Attributes follow the reference class (trainer and evaluator read them): filenames, captions,
     ixtoword / wordtoix / n_words, glove_captions / glove_ixtoword / glove_wordtoix / glove_embed,
     cat_labels / cat_label_lens / sorted_cat_label_indices, class_id, cats_dict / cats_index_dict,
     img_bytes, insanns_dict."""
 
-    def __init__(self, data_dir, split='train', base_size=64, device_hmaps=False, device_imgs=False):
-        self.device_hmaps = device_hmaps
+    def __init__(self, data_dir, split='train', base_size=64, device_hmaps=False, device_imgs=False, device_masks=False):
+        self.device_masks = device_masks
+        self.device_hmaps = device_hmaps or device_masks      # the maps are sums of the masks: rebuilt behind them
         self.device_imgs = device_imgs
         self.data_dir = data_dir
         self.embeddings_num = cfg.TEXT.CAPTIONS_PER_IMAGE
@@ -59,7 +63,7 @@ class TrainDataset(data.Dataset):
         num_rois, bt_masks[3], fm_bt_masks, class id, key) -- the reference item tuple."""
         key = self.filenames[index]
         maps = get_hmaps_rois(self.insanns_dict[key], self.imsize, self.fmsize, self.cats_index_dict,
-                              with_hmaps=not self.device_hmaps)
+                              with_hmaps=not self.device_hmaps, with_resized_masks=not self.device_masks)
         hmaps, rois, fm_rois, num_rois, bt_masks, fm_bt_masks = maps[0], maps[4], maps[5], maps[6], maps[7], maps[8]
         pick = index * self.embeddings_num + random.randint(0, self.embeddings_num)    # one of the image's captions
         caps, glove_caps, cap_len = get_caption(self.captions, self.glove_captions, pick)
@@ -109,8 +113,19 @@ def prepare_data(data, device=None, num_classes=None):
         out_imgs = [take(imgs[b]) for b in branches]
     out_rois = [take_small(rois[b]) for b in branches]
     out_masks, out_hmaps = [], []
+    fm_masks = None
+    if len(bt_masks) > 1 and bt_masks[1].shape[1] == 0:
+        # `device_masks` hand-over: bt_masks[0] holds the raw 64 x 64 instance masks, everything else is made here
+        if device is None:
+            raise ValueError("prepare_data: raw instance masks are resized on the device; pass `device`")
+        raw = take(bt_masks[0]).to(torch.float64)
+        sizes = [fm_bt_masks.shape[-1]] + [bt_masks[b].shape[-1] for b in branches[1:]]
+        resized = ops.resize_masks(raw, sizes)
+        fm_masks, dev_masks = resized[0], [raw] + resized[1:]
+    else:
+        dev_masks = [take(bt_masks[b]) for b in branches]
     for b in branches:
-        masks = take(bt_masks[b])
+        masks = dev_masks[b]
         if hmaps[b].numel() == 0:           # lean hand-over: rebuild on the device, before the float32 cast
             if num_classes is None:
                 raise ValueError("prepare_data: num_classes is needed to rebuild the layout maps")
@@ -121,7 +136,8 @@ def prepare_data(data, device=None, num_classes=None):
     order_list = order.tolist()
     lens_out = lens_sorted if device is None else attach_host(put(lens_sorted), lens_sorted)
     return [out_imgs, take(captions).squeeze(), take(glove_captions).squeeze(), lens_out, out_hmaps,
-            out_rois, take_small(fm_rois), take_small(num_rois), out_masks, take(fm_bt_masks).float(),
+            out_rois, take_small(fm_rois), take_small(num_rois), out_masks,
+            (take(fm_bt_masks) if fm_masks is None else fm_masks).float(),
             class_ids[order].numpy(), [keys[i] for i in order_list]]
 
 

@@ -156,6 +156,14 @@ def resize_pil_bilinear(images, sizes, device):
             for S in sizes]
 
 
+def resize_masks(masks, sizes):
+    from oracle import mask_resize as mr
+    m = masks.detach().cpu().numpy().astype(np.float64)
+    flat = m.reshape((-1,) + m.shape[-2:])
+    return [torch.from_numpy(np.stack([mr.resize_mask(x, int(S)) for x in flat]).reshape(m.shape[:-2] + (int(S), int(S))))
+            .to(masks.device) for S in sizes]
+
+
 def set_conv_math(mode):
     pass
 
@@ -167,7 +175,7 @@ def get_conv_math():
 API = ("conv2d", "conv2d_cat", "conv2d_frozen", "linear", "norm_act", "norm_act_eval", "attn_general", "attn_bu", "masked_max",
        "softmax_strided", "roi_align", "avgpool2s1", "bilinear_resize", "lstm_bidir_forward", "adam_step_",
        "adam_step_gated_", "ema_update_", "max_pool2d", "avg_pool2d", "lift_stem_conv", "bmm", "repack_arena", "bce_const",
-       "resize_pil_bilinear")
+       "resize_pil_bilinear", "resize_masks")
 
 
 def install(monkeypatch):

@@ -12,6 +12,8 @@ import torch
 
 from conftest import rel_l2
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
@@ -1128,6 +1130,77 @@ def test_images_resized_on_the_device_equal_pillow_bit_for_bit(dev):
     assert torch.equal(ramp[0, 0], torch.arange(256, dtype=torch.float32).div(255).sub(0.5).div(0.5))
     with pytest.raises(Exception):
         ops.resize_pil_bilinear([torch.zeros(4, 4, dtype=torch.uint8)], [64], dev)
+
+
+def test_instance_masks_resized_on_the_device_equal_scipy_bit_for_bit(dev):
+    """csrc/resize_pil.hip mask_resize_kernel: the per-box 64 x 64 instance masks -> 32 / 64 / 128 / 256 (reference
+    miscc/load.py:160-176, four skimage.transform.resize calls per box) against scipy.ndimage itself -- the two calls
+    skimage makes, `miscc.load.resize_mask` -- and against the oracle restatement: every float64 equal.  Cases: random
+    floats, binary and scaled ellipses (what the loader holds), a checkerboard, constants, all-zero slots; plus another
+    source size / other anti-aliasing radii (48 -> 12: radius 6), and the guard rails."""
+    from miscc.load import resize_mask
+    from oracle import mask_resize as mr
+    ops = _ops()
+    rng = np.random.RandomState(7)
+    yy, xx = np.mgrid[:64, :64]
+    masks = np.stack([rng.rand(64, 64), np.zeros((64, 64)), np.full((64, 64), 0.375), np.ones((64, 64)),
+                      (((yy - 30) ** 2 / 110. + (xx - 20) ** 2 / 200.) < 1).astype(float),
+                      (((yy - 11) ** 2 / 40. + (xx - 50) ** 2 / 90.) < 1).astype(float) * 0.8125,
+                      ((yy + xx) % 2).astype(float), (rng.rand(64, 64) > 0.6).astype(float),
+                      rng.rand(64, 64) * 1e-3, np.eye(64)]).reshape(2, 5, 64, 64)
+    sizes = [32, 64, 128, 256]
+    outs = ops.resize_masks(torch.from_numpy(masks).to(dev), sizes)
+    torch.cuda.synchronize()
+    for S, out in zip(sizes, outs):
+        assert tuple(out.shape) == (2, 5, S, S) and out.dtype == torch.float64
+        got = out.cpu().numpy()
+        for i in range(2):
+            for j in range(5):
+                want = resize_mask(masks[i, j], S)
+                assert np.array_equal(got[i, j], want), (S, i, j, np.abs(got[i, j] - want).max())
+                assert np.array_equal(want, mr.resize_mask(masks[i, j], S))
+    small = rng.rand(3, 48, 48)
+    o12, o24, o96 = ops.resize_masks(torch.from_numpy(small).to(dev), [12, 24, 96])
+    for k in range(3):
+        for S, o in ((12, o12), (24, o24), (96, o96)):
+            assert np.array_equal(o[k].cpu().numpy(), resize_mask(small[k], S)), (k, S)
+    from objgan_hip import _lib
+    with pytest.raises(_lib.ObjganHipError):
+        ops.resize_masks(torch.zeros(2, 64, 64, dtype=torch.float64), [32])             # CPU tensor: no CPU path
+    with pytest.raises(_lib.ObjganHipError):
+        ops.resize_masks(torch.zeros(2, 64, 64, device=dev), [32])                      # float32
+    with pytest.raises(_lib.ObjganHipError):
+        ops.resize_masks(torch.zeros(2, 128, 128, dtype=torch.float64, device=dev), [32])
+
+
+def test_device_mask_handover_on_the_gpu_equals_the_host_path(dev):
+    """TrainDataset(device_masks=True) + prepare_data on the MI355X: raw instance masks in, the reference's prepared batch
+    out -- box masks at the three branch sizes and the feature scale, layout maps -- equal to the host path (scipy resize
+    in the loader) element for element, and to the fingerprints of the unmodified reference loader
+    (tests/golden/data_tiny_ref.pt)."""
+    from torch.utils.data.dataloader import default_collate
+    import trainDataset
+    data = os.path.join(ROOT, "tests", "golden", "data_tiny")
+    gold = torch.load(os.path.join(ROOT, "tests", "golden", "data_tiny_ref.pt"), weights_only=False)
+    lean = trainDataset.TrainDataset(data, "train", base_size=64, device_masks=True)
+    full = trainDataset.TrainDataset(data, "train", base_size=64)
+    np.random.seed(11)
+    items = [lean[i] for i in range(len(lean))]
+    np.random.seed(11)
+    items_full = [full[i] for i in range(len(full))]
+    got = trainDataset.prepare_data(default_collate(items), dev, lean.num_classes)
+    want = trainDataset.prepare_data(default_collate(items_full), dev, full.num_classes)
+    torch.cuda.synchronize()
+    for b in range(3):
+        assert torch.equal(got[8][b], want[8][b]) and got[8][b].dtype == torch.float32 and got[8][b].is_cuda
+        assert rel_l2(got[4][b], want[4][b]) < 1e-7          # float64 sums of <= 10 masks per category, then float32
+    assert torch.equal(got[9], want[9])
+    g = gold["prepared"]
+    for t, fp in ((got[4][0], g["hmap64"]), (got[4][2], g["hmap256"]), (got[8][0], g["bt_mask64"]), (got[9], g["fm_bt_masks"])):
+        t = t.double().cpu()
+        assert tuple(t.shape) == tuple(fp["shape"])
+        assert abs(float(t.sum()) - fp["sum"]) <= 1e-6 * max(1.0, abs(fp["sum"]))
+        assert torch.allclose(t[..., ::8, ::8].float(), fp["sample"], atol=1e-6, rtol=0)
 
 
 def test_bank_cache_serves_views_and_aliases_without_repacking(dev):
