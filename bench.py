@@ -425,8 +425,6 @@ def main():
     timed_streams = int(tr.d_streams)
 
     def prof_begin():
-        if use_dist:
-            tr.enable_comm_stats(True)              # every rank: the bookkeeping must not change what ranks execute
         # per-kernel durations are those of a kernel ALONE on the device: the profiling pass runs on one stream
         # (in the timed pass kernels of different streams overlap and stretch each other)
         tr.d_streams = 1
@@ -438,11 +436,19 @@ def main():
             lib.objgan_prof_enable(0)
         tr.d_streams = timed_streams
     dt, prof_dt = timed_passes(step, barrier, max_over_ranks, args.steps, args.warmup, prof_steps,
-                               prof_begin if (timing or use_dist) else None,
-                               prof_end if (timing or use_dist) else None)
+                               prof_begin if timing else None, prof_end if timing else None)
     comm = None
     if use_dist and prof_steps > 0:
+        # third, untimed pass on EVERY rank alike, in the stream configuration of the timed pass (the collectives are
+        # issued from the side streams the discriminator updates run on, beside the small-map launches of the other
+        # streams): events around every stream-side wait for a collective = time the compute stream stood still
+        tr.enable_comm_stats(True)
+        barrier()
+        for _ in range(prof_steps):
+            step()
+        barrier()
         comm = tr.comm_summary(prof_steps)
+        comm["measured_with_d_streams"] = timed_streams
         tr.enable_comm_stats(False)
         comm.update(standalone_allreduce(tr, device, barrier))
     # host-side cost of a step: with the queue empty, the time the host needs to ISSUE one step (it does not wait for

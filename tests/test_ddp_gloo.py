@@ -130,7 +130,9 @@ def test_param_arena_keeps_views_and_survives_zero_grad_none():
 def _trainer_worker(rank, world, port, q):
     """One rank of the product trainer (stage-1 + stage-2 tree, both object discriminators) on the CPU
     shim of the kernels; rank 1's boxes are all small, so its large-scale object discriminator sees no
-    box and contributes zeros -- it must still take the same update as rank 0."""
+    box and contributes zeros -- it must still take the same update as rank 0.  (World size 4: ranks 2 and 3
+    hold only LARGE boxes -- no gradient for the small-scale object discriminator from them.  A minibatch without any
+    box at all is not a case: the reference's generator raises on it, model.py:553-572, and so does the product.)"""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -145,7 +147,7 @@ def _trainer_worker(rank, world, port, q):
     from miscc.config import cfg
     from oracle import ref_harness as rh
     cpu_ops_shim.install_plain()
-    torch.set_num_threads(4)
+    torch.set_num_threads(4 if world <= 2 else 2)
     cfg.TREE.BRANCH_NUM = 2
     cfg.TRAIN.BATCH_SIZE = 2
     cfg.TRAIN.NET_G = ''
@@ -189,9 +191,22 @@ def _trainer_worker(rank, world, port, q):
         b["rois"][0][:, :, 2:4] = b["rois"][0][:, :, 2:4].clamp(max=6.0)
         b["rois"][1][:, :, 2:4] = b["rois"][1][:, :, 2:4].clamp(max=12.0)
         b["fm_rois"][:, :, 2:4] = b["fm_rois"][:, :, 2:4].clamp(max=3.0)
+    if rank >= 2:                                   # every box of this rank is large (>= 16 of the 32-px feature map)
+        b["fm_rois"][:, :, 2:4] = b["fm_rois"][:, :, 2:4].clamp(min=17.0)
+        b["rois"][0][:, :, 2:4] = b["rois"][0][:, :, 2:4].clamp(min=34.0)
+        b["rois"][1][:, :, 2:4] = b["rois"][1][:, :, 2:4].clamp(min=68.0)
     tr.netG.ca_net.fixed_eps = b["ca_eps"]
     random.seed(7 + rank)
     out = tr.train_step(b, noise=b["noise"])
+    if world > 2:
+        # the flag slots behind the gradient arenas after the exchange = number of ranks that contributed a gradient
+        q.put((rank, "errObjLSD" in out, "errObjSSD" in out,
+               [o.arena.flat.numpy().copy() for o in [tr.optimizerG] + tr._d_optimizers()], tr.avg_param_G.numpy().copy(),
+               float(tr.optimizerObjLSD.arena.grad[-1]), float(tr.optimizerObjSSD.arena.grad[-1]),
+               tr.optimizerObjLSD.steps_taken, tr.optimizerObjSSD.steps_taken, init_ls.numpy().copy(), tuple(tr.g_buckets)))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     # numpy copies: a tensor put on the queue travels through shared memory owned by this process
     assert tr.g_buckets[0] >= 3 and tr.g_buckets[1] <= 1, tr.g_buckets   # generator all-reduce overlapped its backward
     q.put((rank, "errObjLSD" in out, tr.optimizerG.arena.flat.numpy().copy(),
@@ -220,6 +235,46 @@ def test_two_rank_trainer_step_keeps_replicas_identical():
     assert np.array_equal(g0, g1) and np.array_equal(d0, d1) and np.array_equal(ema0, ema1), "replicas diverged"
     assert np.array_equal(objls0, objls1), "conditional object-discriminator update diverged across ranks"
     assert not np.array_equal(objls0, init0), "the large-scale object discriminator was not updated at all"
+
+
+def test_four_rank_trainer_step_with_a_rank_without_large_boxes_and_a_rank_without_boxes():
+    """World size 4: rank 0 has boxes of both scales, rank 1 only small boxes, ranks 2 and 3 only
+    large ones.  Every rank must issue the same collectives in the same order (a mismatch hangs: the queue times out),
+    all replicas must end bit-identical, both object discriminators must be updated on every rank, and the gated Adam
+    must have divided by the number of CONTRIBUTING ranks: 3 for the large-scale discriminator, 2 for the small-scale.
+    (No rank without ANY box: the reference's generator raises on such a minibatch and the product keeps that contract.)"""
+    import numpy as np
+    world = 4
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(world):
+            res.append(q.get(timeout=600))
+    finally:
+        if len(res) < world:                       # a rank died: the others wait in a collective for ever
+            for p in procs:
+                p.terminate()
+    res.sort(key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    has_ls = [r[1] for r in res]
+    has_ss = [r[2] for r in res]
+    assert has_ls == [True, False, True, True] and has_ss == [True, True, False, False], (has_ls, has_ss)
+    for r in res[1:]:
+        for a0, a1 in zip(res[0][3], r[3]):
+            assert np.array_equal(a0, a1), "replicas diverged (rank %d)" % r[0]
+        assert np.array_equal(res[0][4], r[4])
+    for r in res:
+        assert r[5] == 3.0 and r[6] == 2.0, ("contributing-rank counts", r[5], r[6])
+        assert r[7] == 1 and r[8] == 1, "a gated object-discriminator update was skipped"
+        assert r[10][0] >= 3, r[10]           # generator buckets reduced inside the backward on every rank
+    assert not np.array_equal(res[0][3][-1], res[0][9]), "the large-scale object discriminator was not updated"
 
 
 def _bench_protocol_worker(rank, world, port, q):
