@@ -68,8 +68,9 @@ int objgan_avgpool2s1_backward(const float* grad_out, float* grad_in, long plane
 
 /* ---- implicit-GEMM convolution on MFMA (reference model.py conv stacks, via cuDNN) ---------- */
 long objgan_conv_packed_floats(int M, int C, int T);
-/* layout class (0..4) of the packed bank objgan_conv_igemm uses for these arguments: part of the key of
- * any caller-side bank cache (the same filter is served by different kernels at different sizes) */
+/* layout of the packed bank objgan_conv_igemm uses for these arguments -- low byte: layout class (0..4), bits 8..:
+ * channel chunks per K group of the row-major classes 1 / 3 / 4 -- : part of the key of any caller-side bank cache
+ * (the same filter is served by different kernels and K orders at different sizes) */
 int objgan_conv_bank_layout(int N, int C, int H, int W, int M, int Tg, int PH, int PW, int act, int math);
 /* y[n,m,a*osh+ooh,b*osw+oow] = act(bias[m] + sum_{c,t} Wp[m][c*Tg+t] * x[n,c,a*s+dh[t],b*s+dw[t]])
  * for (a,b) in PH x PW.  w: [Cout][Cin][Torig]; transpose=0 -> m=cout,c=cin; 1 -> m=cin,c=cout.
@@ -106,7 +107,8 @@ long objgan_conv_igemm_ws_floats(int N, int C, int H, int W, int upsample, int p
 /* ring (may be NULL): data gradient of a ReflectionPad2d(1) convolution without the padded intermediate -- the
  * GEMM runs over the padded pixel grid (PH = OHf + 2, PW = OWf + 2, y is the UNPADDED gradient), interior
  * pixels are stored into y, the one-pixel border into ring [N*M][2*PW + 2*PH]; objgan_reflect_ring_fold then
- * adds the border back at its mirror positions.  Only for calls objgan_conv_bank_layout classifies as 1, 3 or 4. */
+ * adds the border back at its mirror positions.  Only for calls whose objgan_conv_bank_layout class (low byte) is
+ * 1, 3 or 4. */
 int objgan_reflect_ring_fold(const float* ring, float* y, long planes, int H, int W, void* stream);
 /* Data gradient of a stride-2 convolution whose four output parity phases have the same number
  * of taps (k=4, pad 1, even sizes): one launch for all phases.  x = dY [N,Cout,OH,OW],

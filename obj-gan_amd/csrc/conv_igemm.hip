@@ -60,6 +60,9 @@ struct IgemmArgs {
                             // run_igemm2 makes in the caller's workspace (conv_igemm3_kernel<.., 3, ..>)
     int Krow;               // row pitch of the [M][Krow] bank in elements (= Kpad; bf16 bank: Kpad rounded up to 32)
     int T, Cp;              // taps, channels rounded up to 16
+    int kgroup;             // conv_igemm3_kernel: K walk order -- groups of `kgroup` 16-channel chunks, all taps of a group
+                            // before the next group (og_kstep; = Cp / 16: plain tap-major).  The bank is packed in the
+                            // same order (PackArgs::kgroup).
     int m_begin, m_end;  // output-channel rows covered by this launch
     int PH, PW;          // GEMM pixel grid per image
     int OHf, OWf;        // physical output dims
@@ -574,8 +577,21 @@ struct PackArgs {
                          // 3: bf16 wt[M][Krow], Krow = Kpad rounded up to 32 (bf16 MFMA kernels)
                          // 4: bf16x3 split wt[M][Kpad/16][3][16]: every fp32 entry as its exact three-way bf16
                          //    split h + m + l (og_split8), the three pieces of a 16-deep K step back to back
+    int kgroup;          // row-major banks (m_major 1 / 3 / 4): chunks per K group (see og_kstep)
     signed char src_tap[OG_MAX_TAPS];
 };
+
+// K walk order of conv_igemm3_kernel and of its banks.  Tap-major (all channels of tap 0, then tap 1, ...) keeps the
+// tap geometry out of the inner steps, but every tap re-reads the SAME source pixels one full channel sweep later: at
+// 128 x 128 x 194..388 channels a sweep of the workgroups of one XCD is 6-16 MB, the 4 MB L2 has long lost the lines
+// and every tap fetches them again from HBM / MALL (r03 PMC: 3.9-4.1x the algorithmic bytes).  Walking the channels in
+// GROUPS of G chunks -- all taps of a group back to back -- bounds the reuse distance to T * G steps.
+//   step(t, chunk c): g = c / G; steps of the full groups before it + t * (chunks in group g) + (c - g * G)
+__host__ __device__ __forceinline__ int og_kstep(int t, int c16, int spt, int T, int G) {
+    const int g = c16 / G;
+    const int Gg = min(G, spt - g * G);
+    return g * T * G + t * Gg + (c16 - g * G);
+}
 
 // Work items of a job.  Row-major banks (m_major 1 / 3: wt[m][t*Cp + ck]) are packed per (m, ck) PAIR: a
 // thread reads the Torig taps of its pair -- one contiguous 36..64-byte run of w, adjacent pairs adjacent runs
@@ -653,13 +669,13 @@ __device__ __forceinline__ void pack_pair(const PackArgs& a, unsigned i, int Kpa
             float v = 0.f;
 #pragma unroll
             for (int j = 0; j < 16; ++j) v = st == j ? r[j] : v;
-            pack_store(a, row, t * a.Cp + ck, v);
+            pack_store(a, row, og_kstep(t, ck >> 4, a.Cp >> 4, a.Tg, a.kgroup) * 16 + (ck & 15), v);
         }
     } else {
         for (int t = 0; t < a.Tg; ++t) {
             const int st = a.src_tap[t];
             const float v = (live && st >= 0) ? src[st] : 0.f;
-            pack_store(a, row, t * a.Cp + ck, v);
+            pack_store(a, row, og_kstep(t, ck >> 4, a.Cp >> 4, a.Tg, a.kgroup) * 16 + (ck & 15), v);
         }
     }
     if (a.m_major == 3 && ck < Krow - Kpad)               // bf16 rows are padded to a multiple of 32
@@ -1377,6 +1393,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
         else bvoff = ok ? (img_off + (unsigned)(ihs * a.W + iws)) * 4u : OG_OOB;
     };
     int t_ld, cb_ld;
+    int gb_ld, ge_ld;                                   // channel range of the current K group (og_kstep)
     const int spt = a.Cp / BK;
     // channels past C (padding of the last 16-channel chunk) read finite neighbouring data or the
     // range-check zero; their filter entries are zero  (NH: the copy holds zeros there)
@@ -1391,10 +1408,15 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
                 rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, bvoff, (cb_ld + i) * HW * 4, 0));
         }
         cb_ld += BK;
-        if (cb_ld >= a.Cp) {
-            cb_ld = 0;
+        if (cb_ld >= ge_ld) {                           // end of this tap's run of the group
             t_ld += 1;
-            if (t_ld < a.T) tap_geometry(t_ld);
+            if (t_ld >= a.T) {                          // all taps done: next group of channels (past the last one:
+                t_ld = 0;                               // channel offsets beyond the tensor, the range check returns 0)
+                gb_ld = ge_ld;
+                ge_ld = min(a.Cp, ge_ld + a.kgroup * BK);
+            }
+            cb_ld = gb_ld;
+            if (gb_ld < a.Cp) tap_geometry(t_ld);
         }
     };
     auto load_b = [&](float (&rb)[NB]) {
@@ -1438,8 +1460,17 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
     const int nk = a.ksplit_steps > 0 ? min(nk_all, kt0 + a.ksplit_steps) : nk_all;
     {
         const int sub0 = BF ? 2 * kt0 : kt0;            // first 16-channel chunk of this block
-        t_ld = sub0 / spt;
-        cb_ld = (sub0 - t_ld * spt) * BK;
+        const int G = a.kgroup, TG = a.T * G, nfull = spt / G;
+        int g = sub0 / TG, r = sub0 - g * TG, Gg = G;
+        if (g >= nfull) {                               // the (shorter) last group, or past the end
+            g = nfull;
+            r = sub0 - nfull * TG;
+            Gg = spt - nfull * G;
+        }
+        t_ld = Gg > 0 ? r / Gg : a.T;
+        gb_ld = g * G * BK;
+        ge_ld = min(a.Cp, gb_ld + G * BK);
+        cb_ld = gb_ld + (Gg > 0 ? r - t_ld * Gg : 0) * BK;
     }
     tap_geometry(min(t_ld, a.T - 1));
 
@@ -2476,6 +2507,9 @@ OG_KNOB(og_split_target, "OG_SPLIT_TARGET", 1024)
 OG_KNOB(og_no_xrows, "OG_NO_XROWS", 0)
 OG_KNOB(og_nw8_min, "OG_NW8_MIN", 512)             // bf16x3: 8-wave workgroups from this many workgroups on (0: never)
 OG_KNOB(og_ablate, "OG_ABLATE", 0)                 // development builds: IgemmArgs::ablate
+OG_KNOB(og_kgroup_s1, "OG_KGROUP_S1", 4)           // chunks per K group (og_kstep), stride-1 multi-tap launches (0: tap-major)
+OG_KNOB(og_kgroup_s2, "OG_KGROUP_S2", 0)           // ... stride-2 forward launches
+OG_KNOB(og_kgroup_ph, "OG_KGROUP_PH", 4)           // ... the four-phase stride-2 data gradient / up-convolution
 OG_KNOB(og_x3_wgrad3_maxtm, "OG_X3_WGRAD3_MAXTM", 2)   // bf16x3: register-fragment weight gradient up to this tile height
 static int og_igemm_tmmax() { const int v = og_igemm_tmmax_raw(); return (v < 1 || v > 8) ? 8 : v; }
 
@@ -2841,6 +2875,21 @@ static inline int og_krow(int Kpad, int math) {
     return math == 1 ? (Kpad + 31) / 32 * 32 : (math == 2 ? 3 * Kpad : Kpad);
 }
 
+// Chunks per K group (og_kstep) of a row-major bank / conv_igemm3_kernel launch: a function of what both the pack job
+// and the launch know (channels, taps, source and pixel-grid heights).  The resident workgroups of an XCD cover ~8192
+// output pixels; one 16-channel chunk of their source pixels is ~0.8 MB at stride 1 (3 MB at stride 2), and the groups
+// are sized so that a group's taps find their lines in the 4 MB L2.
+static int og_kgroup(int C, int Tg, int H, int PH) {
+    const int spt = (C + 15) / 16;
+    if (Tg <= 1) return spt;
+    const int G = (H > PH + PH / 2) ? og_kgroup_s2() : og_kgroup_s1();
+    return (G <= 0 || G > spt) ? spt : G;
+}
+static int og_kgroup_phases(int C) {
+    const int spt = (C + 15) / 16, G = og_kgroup_ph();
+    return (G <= 0 || G > spt) ? spt : G;
+}
+
 // Which packed-bank layout (PackArgs::m_major) a call with these arguments uses; MT_out = accumulator
 // count of the thin kernel when the answer is 2.  The single source of truth for
 // objgan_conv_igemm and objgan_conv_bank_layout.
@@ -2869,6 +2918,7 @@ static int og_fill_pack(PackArgs& p, const float* w, float* wt, int N, int C, in
     p.transpose = transpose;
     int MT = 32;
     p.m_major = og_bank_layout(N, C, H, W, M, Tg, PH, PW, act, math, &MT);
+    p.kgroup = og_kgroup(C, Tg, H, PH);
     if (p.m_major == 2) p.Mpad = MT;
     for (int t = 0; t < OG_MAX_TAPS; ++t) p.src_tap[t] = (signed char)(t < Tg ? src_tap[t] : -1);
     if (MT_out) *MT_out = MT;
@@ -2885,6 +2935,7 @@ static void og_fill_pack_phase(PackArgs& p, const float* w, float* wt, int Cout,
     p.w = w; p.wt = wt + phase * bank; p.Cout = Cout; p.Cin = Cin; p.Torig = Torig; p.Tg = Tg;
     p.M = M; p.Mpad = (M + 127) / 128 * 128; p.Ck = C; p.Cp = Cp;
     p.transpose = 1; p.m_major = math == 1 ? 3 : (math == 2 ? 4 : 1);
+    p.kgroup = og_kgroup_phases(C);
     for (int t = 0; t < OG_MAX_TAPS; ++t) p.src_tap[t] = (signed char)(t < Tg ? src_tap_phase[t] : -1);
 }
 
@@ -2928,11 +2979,13 @@ int objgan_conv_pack_jobs_run(const void* jobs_dev, int njobs, void* stream) {
     return og_launch_status();
 }
 
-// Layout class of the packed bank objgan_conv_igemm would write / expect for these arguments (0..3).
-// A caller that keeps packed banks (wt_packed = 1) must key them on this value as well: the same
-// filter can be served by different kernels -- hence different bank layouts -- at different sizes.
+// Layout of the packed bank objgan_conv_igemm would write / expect for these arguments: low byte = layout class
+// (0..4), bits 8.. = chunks per K group of the row-major classes (og_kstep).  A caller that keeps packed banks
+// (wt_packed = 1) must key them on this value as well: the same filter can be served by different kernels and K
+// orders -- hence different bank layouts -- at different sizes.
 int objgan_conv_bank_layout(int N, int C, int H, int W, int M, int Tg, int PH, int PW, int act, int math) {
-    return og_bank_layout(N, C, H, W, M, Tg, PH, PW, act, math, nullptr);
+    const int cls = og_bank_layout(N, C, H, W, M, Tg, PH, PW, act, math, nullptr);
+    return (cls == 1 || cls >= 3) ? (cls | (og_kgroup(C, Tg, H, PH) << 8)) : cls;
 }
 
 // Size (in floats) of the packed-weight scratch for an M x K GEMM.
@@ -2968,7 +3021,7 @@ static int og_igemm_setup(PackArgs& p, IgemmArgs& a, int& MT, const float* x, co
     a.x = x; a.wt = wt; a.bias = bias; a.y = y;
     a.N = N; a.C = C; a.H = H; a.W = W;
     a.LH = upsample ? 2 * H : H; a.LW = upsample ? 2 * W : W;
-    a.M = M; a.Mpad = p.Mpad; a.K = C * Tg; a.Kpad = Tg * p.Cp; a.T = Tg; a.Cp = p.Cp;
+    a.M = M; a.Mpad = p.Mpad; a.K = C * Tg; a.Kpad = Tg * p.Cp; a.T = Tg; a.Cp = p.Cp; a.kgroup = p.kgroup;
     a.math = kmath;
     a.nhwc = igemm2_nhwc_floats(kmath, N, H, W, p.Cp) > 0 ? 1 : 0;
     a.Krow = og_krow(a.Kpad, kmath);
@@ -3075,6 +3128,7 @@ int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float*
     a.x = x; a.wt = wt; a.bias = nullptr; a.y = y;
     a.N = N; a.C = C; a.H = OH; a.W = OW; a.LH = OH; a.LW = OW;
     a.M = M; a.Mpad = (M + 127) / 128 * 128; a.K = C * Tg; a.Kpad = Kpad; a.T = Tg; a.Cp = Cp;
+    a.kgroup = og_kgroup_phases(C);
     a.math = math; a.Krow = Krow;
     a.nhwc = igemm2_nhwc_floats(math, N, OH, OW, Cp) > 0 ? 1 : 0;
     a.m_begin = 0; a.m_end = M;

@@ -293,7 +293,7 @@ def _conv_dgrad(g, w, N, Cin, H, W, stride, pad, refl, upsample, cacheable=True)
         dw = [pe - kw for kh in range(k) for kw in range(k)]
         st = list(range(k * k))
         ring_ok = (refl and pad == 1 and LH >= 3 and LW >= 3 and
-                   _lib.load().objgan_conv_bank_layout(N, Cout, OH, OW, Cin, k * k, TH, TW, 0, _MATH["mode"]) in (1, 3, 4))
+                   (_lib.load().objgan_conv_bank_layout(N, Cout, OH, OW, Cin, k * k, TH, TW, 0, _MATH["mode"]) & 255) in (1, 3, 4))
         if ring_ok:
             # gradient of the reflect-padded conv without the padded intermediate: interior pixels go straight
             # into dX, the one-pixel border into a small ring buffer that is mirrored back afterwards
