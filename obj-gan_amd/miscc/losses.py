@@ -232,7 +232,7 @@ def _obj_g_term(netObjD, fake_img, seg, slabels_emb, raw_bt_c_codes, rois, num_r
 
 def G_loss(netsPatD, netsShpD, netObjSSD, netObjLSD, image_encoder, fake_imgs, seg_conditions,
            words_embs, sent_emb, slabels_emb, raw_bt_c_codes, match_labels, cap_lens, class_ids,
-           rois, fm_rois, num_rois, quiet=False, use_obj=True, streams=None, damsm_early=None):
+           rois, fm_rois, num_rois, quiet=False, use_obj=True, streams=None):
     """quiet=True skips the log string, the DAMSM accuracies and attention maps (every `.item()` / `.cpu()` in
     them is a device->host sync).
     streams (quiet only): HIP streams the nine terms -- DAMSM first, then the discriminators in the order below --
@@ -240,12 +240,11 @@ def G_loss(netsPatD, netsShpD, netObjSSD, netObjLSD, image_encoder, fake_imgs, s
     forward).  (Round 2 measured no gain from side streams: the host was stalling on index uploads then and never
     ran ahead of the device.  Round 3, host 130 ms ahead per step: 205.6 -> 190.0 ms with three streams.)
     use_obj=False leaves the two object-discriminator terms out (BASELINE.json configs 1-3: the
-    reference has no such switch, its stage-1 / no-ObjD runs are harness compositions).
-    damsm_early (streams + quiet only): (w_loss, s_loss, d(w_loss + s_loss)/d(fake image)) from `damsm_term_early`."""
+    reference has no such switch, its stage-1 / no-ObjD runs are harness compositions)."""
     if streams and quiet:
         return _g_loss_streams(netsPatD, netsShpD, netObjSSD, netObjLSD, image_encoder, fake_imgs, seg_conditions,
                                words_embs, sent_emb, slabels_emb, raw_bt_c_codes, match_labels, cap_lens, class_ids,
-                               rois, fm_rois, num_rois, use_obj, streams, damsm_early), ''
+                               rois, fm_rois, num_rois, use_obj, streams), ''
     numDs = len(netsPatD)
     batch_size = fake_imgs[0].size(0)
     logs = ''
@@ -296,34 +295,10 @@ def G_loss(netsPatD, netsShpD, netObjSSD, netObjLSD, image_encoder, fake_imgs, s
     return errG_total, logs
 
 
-def damsm_term_early(image_encoder, fake_img, words_embs, sent_emb, match_labels, cap_lens, class_ids):
-    """The DAMSM term of the generator loss and its gradient w.r.t. the fake image, evaluated on the CURRENT stream
-    from a detached copy of the image: -> (w_loss, s_loss, d(w_loss + s_loss) / d(image)), all detached.
-    The term depends on the image and the frozen encoders only -- not on the discriminators -- so the trainer issues
-    it right behind the generator's forward, on a stream of its own: its ~400 small launches (94 Inception
-    convolutions forward and backward on 35 x 35 .. 8 x 8 maps) run beside the large convolutions of the eight
-    discriminator updates instead of holding up the generator's backward (r04 kernel-trace timeline: 13 ms per step
-    with nothing but these launches in flight).  `_g_loss_streams` then adds <image, gradient> in place of the term:
-    the same gradient reaches the generator, the reported loss carries the term's value."""
-    sm = cfg.TRAIN.SMOOTH
-    leaf = fake_img.detach().requires_grad_()
-    batch_size = leaf.size(0)
-    with torch.enable_grad():
-        region_features, cnn_code = image_encoder(leaf)
-        w0, w1, _, _ = words_loss(region_features, words_embs, match_labels, cap_lens, class_ids, batch_size,
-                                  top1=False, need_att_maps=False)
-        s0, s1, _ = sent_loss(cnn_code, sent_emb, match_labels, class_ids, batch_size, top1=False)
-        w, s_ = (w0 + w1) * sm.DAMSM_LAMBDA, (s0 + s1) * sm.DAMSM_LAMBDA
-        (w + s_).backward()
-    return w.detach(), s_.detach(), leaf.grad
-
-
 def _g_loss_streams(netsPatD, netsShpD, netObjSSD, netObjLSD, image_encoder, fake_imgs, seg_conditions,
                     words_embs, sent_emb, slabels_emb, raw_bt_c_codes, match_labels, cap_lens, class_ids,
-                    rois, fm_rois, num_rois, use_obj, streams, damsm_early=None):
-    """The terms of G_loss (same arithmetic, same summation order) issued round-robin on `streams`.
-    -> the loss whose BACKWARD is the generator gradient; with `damsm_early` its value differs from the reported loss
-    (attribute `.reported` of the result: the sum with the DAMSM term's value in place of the inner product)."""
+                    rois, fm_rois, num_rois, use_obj, streams):
+    """The terms of G_loss (same arithmetic, same summation order) issued round-robin on `streams`."""
     numDs = len(netsPatD)
     batch_size = fake_imgs[0].size(0)
     sm = cfg.TRAIN.SMOOTH
@@ -351,8 +326,7 @@ def _g_loss_streams(netsPatD, netsShpD, netObjSSD, netObjLSD, image_encoder, fak
         n = _net(netsShpD[i])
         return _bce(n.UNCOND_DNET(netsShpD[i](fake_imgs[i], seg_conditions[i])), 1) * sm.SHP_LAMBDA
 
-    # the longest chain of small launches first: it overlaps everything (or, already evaluated: damsm_term_early)
-    order = [("damsm", damsm)] if damsm_early is None else []
+    order = [("damsm", damsm)]                    # the longest chain of small launches first: it overlaps everything
     for i in range(numDs):
         order += [("pat%d" % i, lambda i=i: pat(i)), ("shp%d" % i, lambda i=i: shp(i))]
     if use_obj:
@@ -371,20 +345,10 @@ def _g_loss_streams(netsPatD, netsShpD, netObjSSD, netObjLSD, image_encoder, fak
     for i in range(numDs):
         total = total + terms["pat%d" % i]
         total = total + terms["shp%d" % i]
-    reported = None
-    if damsm_early is None:
-        total = total + terms["damsm"][0] + terms["damsm"][1]
-    else:
-        w, s_, g_img = damsm_early
-        reported = total.detach() + w + s_
-        total = total + (fake_imgs[numDs - 1] * g_img).sum()      # d/d(image) = the DAMSM term's gradient
+    total = total + terms["damsm"][0] + terms["damsm"][1]
     for name in ("objss", "objls"):
         if name in terms and torch.is_tensor(terms[name]):
             total = total + terms[name]
-            if reported is not None:
-                reported = reported + terms[name].detach()
-    if reported is not None:
-        total.reported = reported
     return total
 
 

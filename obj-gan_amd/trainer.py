@@ -397,15 +397,6 @@ class condGANTrainer(object):
     # Side streams for the eight discriminator updates and the nine generator-loss terms (1: everything on the
     # caller's stream).  r03, one MI355X, B = 16: 205.6 / 192.7 / 190.0 / 198.5 ms per step with 1 / 2 / 3 / 4.
     d_streams = 3
-    # the generator loss's DAMSM term (frozen Inception encoder, forward + image gradient) issued behind the generator's
-    # forward on its own stream, beside the discriminator updates (needs side streams; off: inside the generator loss)
-    early_damsm = True
-
-    def _encoder_stream(self):
-        es = getattr(self, "_enc_stream", None)
-        if es is None:
-            es = self._enc_stream = torch.cuda.Stream(device=self.device)
-        return es
 
     def _d_side_streams(self):
         n = int(self.d_streams)
@@ -502,20 +493,6 @@ class condGANTrainer(object):
             fm_rois, num_rois, b["bt_masks"], b["fm_bt_masks"], glb_max_num_roi)
         bt_c_codes = [c.detach() for c in bt_c_codes]
 
-        # (2b) the DAMSM term of the generator loss and its image gradient depend on the fake image and the frozen
-        # encoders only: issued here, on a stream of their own, they run beside the discriminator updates
-        # (losses.damsm_term_early) instead of in front of the generator's backward
-        damsm_early = None
-        if (self.early_damsm and not want_logs and self.image_encoder is not None and self._d_side_streams()):
-            es = self._encoder_stream()
-            main0 = torch.cuda.current_stream()
-            es.wait_stream(main0)
-            with torch.cuda.stream(es):
-                import miscc.losses as L
-                damsm_early = L.damsm_term_early(self.image_encoder, fake_imgs[-1], words_embs, sent_emb,
-                                                 self.match_labels, b["cap_lens"], b["class_ids"])
-            fake_imgs[-1].record_stream(es)
-
         # (3) the eight discriminator updates (reference trainer.py:398-443).  They are independent of
         # each other (own weights, the real batch, the detached fake images); issuing them on separate
         # HIP streams was measured and bought nothing (the step is MFMA-bound, 317.5 vs 319.6 ms), so
@@ -583,9 +560,8 @@ class condGANTrainer(object):
                                     clabels_emb, bt_last, self.match_labels, b["cap_lens"],
                                     b["class_ids"], rois[0], fm_rois, num_rois, use_obj=self.use_obj) \
             if want_logs else _g_loss_quiet(self, fake_imgs, hmaps, words_embs, sent_emb, clabels_emb,
-                                            bt_last, b, rois, fm_rois, num_rois, damsm_early)
+                                            bt_last, b, rois, fm_rois, num_rois)
         kl = KL_loss(mu, logvar)
-        reported = getattr(errG_total, "reported", None)
         errG_total = errG_total + kl
         # data parallel: the generator's gradient arena is all-reduced in buckets AS its backward pass
         # completes them (stage 3 first), not in one piece after it
@@ -607,7 +583,7 @@ class condGANTrainer(object):
                 self._wait(h)
         self.optimizerG.step(grad_scale=inv_world)
         ops.ema_update_(self.avg_param_G, self.optimizerG.arena.flat, 0.999)
-        out["errG"] = errG_total.detach() if reported is None else reported + kl.detach()
+        out["errG"] = errG_total.detach()
         out["kl"] = kl.detach()
         out["fake_imgs"] = [f.detach() for f in fake_imgs]
         if want_logs:
@@ -730,13 +706,11 @@ class condGANTrainer(object):
 
 
 def _g_loss_quiet(tr, fake_imgs, hmaps, words_embs, sent_emb, clabels_emb, bt_c, b, rois, fm_rois,
-                  num_rois, damsm_early=None):
+                  num_rois):
     """G_loss without building the log string (no .item() host syncs on non-print steps)."""
     import miscc.losses as L
-    if damsm_early is not None:          # evaluated on the encoder stream: the terms read it from here on
-        torch.cuda.current_stream().wait_stream(tr._encoder_stream())
     total, _ = L.G_loss(tr.netsPatD, tr.netsShpD, tr.netObjSSD, tr.netObjLSD, tr.image_encoder,
                         fake_imgs, hmaps, words_embs, sent_emb, clabels_emb, bt_c, tr.match_labels,
                         b["cap_lens"], b["class_ids"], rois[0], fm_rois, num_rois, quiet=True,
-                        use_obj=tr.use_obj, streams=tr._d_side_streams() or None, damsm_early=damsm_early)
+                        use_obj=tr.use_obj, streams=tr._d_side_streams() or None)
     return total, ''
