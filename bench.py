@@ -394,6 +394,8 @@ def main():
                        workload=args.workload)
     if args.d_streams is not None:
         tr.d_streams = args.d_streams
+    if os.environ.get("OG_DIRECT_WGRAD") == "0":      # development A/B
+        ops.direct_wgrad(False)
     branch_num, _, workload_name = WORKLOADS[args.workload]
     side = 64 << (branch_num - 1)
     # a new minibatch every step, like training: four distinct per-rank batches in rotation (the trainer

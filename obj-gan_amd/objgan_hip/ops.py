@@ -341,17 +341,44 @@ def _conv_dgrad(g, w, N, Cin, H, W, stride, pad, refl, upsample, cacheable=True)
     return dxl
 
 
-def _conv_wgrad(x, g, Cout, k, stride, pad, refl, upsample):
+def _conv_wgrad(x, g, Cout, k, stride, pad, refl, upsample, sink=None):
     """Gradient w.r.t. the filter bank [Cout, Cin, k, k] of conv(x, w) given g = dL/d(conv output).
-    (Accumulating straight into the optimizer arena's gradient view instead of a fresh zeroed buffer --
-    360 fewer fill / add launches per step -- was measured in round 2: 274.2 vs 273.2 ms, no gain.)"""
+    sink: the weight's (gradient view, notify) pair from its optimizer arena (`_grad_sink`): the ordered combine of the
+    splits ADDS its sum into the view (the same `grad + dw` autograd's AccumulateGrad would compute, bit for bit, without
+    the temporary and the add launch) and None is returned -- the caller hands None to autograd and calls notify()."""
     N, Cin, H, W = x.shape
-    dw_ = torch.empty((Cout, Cin, k, k), dtype=_F32, device=x.device)      # fully written: no zero-fill
+    if sink is not None:
+        dw_ = sink[0]
+    else:
+        dw_ = torch.empty((Cout, Cin, k, k), dtype=_F32, device=x.device)      # fully written: no zero-fill
     geo = (N, Cin, H, W, int(upsample), refl, Cout, g.shape[2], g.shape[3], k, stride, pad, _MATH["mode"])
     nws = _lib.load().objgan_conv_wgrad_ws_floats(*geo)
     ws = torch.empty(nws, dtype=_F32, device=x.device) if nws > 0 else None
-    _lib.call("objgan_conv_wgrad", _p(x), _p(g), _p(dw_), *geo, 0, _p(ws), nws, _stream())
+    _lib.call("objgan_conv_wgrad", _p(x), _p(g), _p(dw_), *geo, 0 if sink is None else 1, _p(ws), nws, _stream())
+    if sink is not None:
+        sink[1]()
+        return None
     return dw_
+
+
+# Weight gradients straight into the optimizer arena.  A parameter that lives in a flat arena (trainer.ParamArena)
+# carries `_og_grad_sink = (view of its slot in the gradient arena, notify)`; its `.grad` IS that view.  The convolution
+# backward then accumulates into the view itself and returns None to autograd (no temporary, no AccumulateGrad `add`
+# launch: 537 of them per training step in round 3) and calls notify() in AccumulateGrad's place (the arena's
+# "gradient is final" bookkeeping for the bucketed all-reduce).  Only under .backward() into .grad -- the arena's
+# owner switches the sinks off (`direct_wgrad(False)`) around anything else.
+_DIRECT_WGRAD = {"on": True}
+
+
+def direct_wgrad(on):
+    _DIRECT_WGRAD["on"] = bool(on)
+
+
+def _grad_sink(w, shape):
+    sink = getattr(w, "_og_grad_sink", None) if _DIRECT_WGRAD["on"] else None
+    if sink is None or w.grad is None or w.grad.data_ptr() != sink[0].data_ptr() or tuple(sink[0].shape) != tuple(shape):
+        return None
+    return sink
 
 
 def _channel_sum(g, out, N, C, HW):
@@ -403,7 +430,7 @@ class _Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _conv_dgrad(g, w, N, Cin, H, W, stride, pad, refl, upsample)
         if ctx.needs_input_grad[1]:
-            dw_ = _conv_wgrad(x, g, Cout, k, stride, pad, refl, upsample)
+            dw_ = _conv_wgrad(x, g, Cout, k, stride, pad, refl, upsample, sink=_grad_sink(w, (Cout, Cin, k, k)))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(Cout, dtype=_F32, device=x.device)
             _channel_sum(g, db, N, Cout, g.shape[2] * g.shape[3])
@@ -539,7 +566,7 @@ class _Conv2dCatFn(torch.autograd.Function):
         elif n2:
             dx2 = _conv_dgrad(g, w[:, c1:].contiguous(), N, C - c1, H, W, stride, pad, 0, False, cacheable=False)
         if nw:
-            dw_ = _conv_wgrad(x, g, w.shape[0], k, stride, pad, 0, False)
+            dw_ = _conv_wgrad(x, g, w.shape[0], k, stride, pad, 0, False, sink=_grad_sink(w, tuple(w.shape)))
         return dx1, dx2, dw_, None, None, None
 
 

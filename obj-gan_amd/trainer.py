@@ -72,8 +72,13 @@ class ParamArena(object):
             p.data = self.flat[off:off + k].view_as(p)
             gview = self.grad[off:off + k].view_as(p)
             p.grad = gview
+            # ops' convolution backward accumulates a weight gradient straight into this view and reports here in
+            # AccumulateGrad's place (ops._grad_sink)
+            p._og_grad_sink = (gview, lambda i=len(self._views): self._mark(i))
             self._views.append(gview)
             off += k
+
+    _armed = None
 
     def zero_grad(self):
         self.grad.zero_()
