@@ -13,7 +13,7 @@ test) rm -f gpurun_out/parity_numbers.txt
 testk) ( time timeout 900 python -m pytest tests -m gpu -x -v --timeout=240 --durations=10 -k "$OG_K" ) > gpurun_out/${TAG}_pytestk.log 2>&1; tail -15 gpurun_out/${TAG}_pytestk.log ;;
 convbench) ( timeout 300 tools/conv_bench "" 5 ) > gpurun_out/${TAG}_convbench.log 2>&1; cat gpurun_out/${TAG}_convbench.log ;;
 bench) ( time timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --shape-table gpurun_out/${TAG}_shapes.txt ) > gpurun_out/${TAG}_bench.log 2>&1; tail -3 gpurun_out/${TAG}_bench.log ;;
-benchfull) ( time timeout 900 python bench.py --steps 20 --warmup 5 ) > gpurun_out/${TAG}_benchfull.log 2>&1; tail -3 gpurun_out/${TAG}_benchfull.log ;;
+benchfull) ( time timeout 1700 python bench.py --steps 20 --warmup 5 --shape-table gpurun_out/${TAG}_conv_shapes.txt ) > gpurun_out/${TAG}_benchfull.log 2>&1; tail -3 gpurun_out/${TAG}_benchfull.log ;;
 benchddp) ( time timeout 600 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --force-ddp ) > gpurun_out/${TAG}_benchddp.log 2>&1; tail -3 gpurun_out/${TAG}_benchddp.log ;;
 benchbf16) ( time timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --math bf16 --batch 32 ) > gpurun_out/${TAG}_benchbf16.log 2>&1; tail -3 gpurun_out/${TAG}_benchbf16.log | cut -c1-600 ;;
 benchcfg) for w in stage3 stage1; do ( time timeout 300 python bench.py --steps 8 --warmup 2 --workload $w ) > gpurun_out/${TAG}_bench_$w.log 2>&1; tail -3 gpurun_out/${TAG}_bench_$w.log | cut -c1-700; done ;;
