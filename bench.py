@@ -48,23 +48,31 @@ import torch.distributed as dist                # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3                   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0                  # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
 # timing categories of the library = kernel instances, named as rocprofv3 prints them
-MATH_IDS = {"fp32": 0, "bf16": 1, "bf16x3": 2}
-# bf16x3: six bf16 MFMAs (K = 16) do the work of eight fp32 ones (K = 2) at 16x their rate
+MATH_IDS = {"fp32": 0, "bf16": 1, "bf16x3": 2, "fp16x2": 4}
+# bf16x3: six bf16 MFMAs (K = 16) do the work of eight fp32 ones (K = 2) at 16x their rate; fp16x2: three fp16 MFMAs
 BF16X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
+FP16X2_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3.0
 
 
 def cat_names(math):
     """rocprofv3's names of the kernel instances behind the library's timing categories (leading template
-    arguments: tile height, LDS-free form / arithmetic)."""
+    arguments: tile height, LDS-free form / arithmetic), indexed by category id."""
+    def names(mi, m, bfb=False):
+        return (["conv_igemm3_kernel<%d, false, %d, 4>" % (tm, mi) for tm in range(1, 8)] +
+                # (bf16 mode: the bf16-operand weight-gradient kernel reports in the slots of the LDS-staged one)
+                [("conv_wgrad_bfb_kernel<%d," % tm) if bfb else ("conv_wgrad2_kernel<%d, %d" % (tm, min(m, 2))) for tm in range(1, 8)] +
+                ["conv_thin_kernel", "conv_thin3x3_kernel", "conv_igemm_kernel", "conv_wgrad_kernel",
+                 "conv_igemm3_kernel<1, true, %d, 4>" % m] + ["conv_wgrad3_kernel<%d, %d" % (tm, m) for tm in range(1, 8)] +
+                ["conv_igemm3_kernel<%d, false, %d, 8>" % (tm, mi) for tm in range(1, 8)] +
+                ["conv_wgrad3_kernel<%d, %d, *, 0, 8>" % (tm, m) for tm in range(1, 8)])
+    if math == "fp16x2":       # categories 0..47: this mode's bf16x3 launches (small ones, LDS-staged weight gradients);
+        base = names(2, 2)               # 48..95: the fp16x2 instances of the same kernel families
+        return base + [""] * (48 - len(base)) + names(4, 4)
     m = MATH_IDS[math]
-    mi = 3 if m == 1 else m          # bf16 mode: the matrix kernels read the bf16 channel-blocked copy (template value 3)
-    return (["conv_igemm3_kernel<%d, false, %d, 4>" % (tm, mi) for tm in range(1, 8)] +
-            # (bf16 mode: the bf16-operand weight-gradient kernel reports in the slots of the LDS-staged one)
-            [("conv_wgrad_bfb_kernel<%d," % tm) if m == 1 else ("conv_wgrad2_kernel<%d, %d" % (tm, m)) for tm in range(1, 8)] +
-            ["conv_thin_kernel", "conv_thin3x3_kernel", "conv_igemm_kernel", "conv_wgrad_kernel",
-             "conv_igemm3_kernel<1, true, %d, 4>" % m] + ["conv_wgrad3_kernel<%d, %d" % (tm, m) for tm in range(1, 8)] +
-            ["conv_igemm3_kernel<%d, false, %d, 8>" % (tm, mi) for tm in range(1, 8)] +
-            ["conv_wgrad3_kernel<%d, %d, *, 0, 8>" % (tm, m) for tm in range(1, 8)])
+    # bf16 mode: the matrix kernels read the bf16 channel-blocked copy (template value 3)
+    return names(3 if m == 1 else m, m, bfb=(m == 1))
+
+
 PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
@@ -217,12 +225,14 @@ def cpu_baseline(sample_batch=16, timed_steps=3, timeout_s=630):
 
 
 def side_configs(steps=6, warmup=2, timeout_s=240):
-    """Two short side records of the default N = 1 run, each a child `bench.py` on the same GPU after the headline is
+    """Three short side records of the default N = 1 run, each a child `bench.py` on the same GPU after the headline is
     measured (they are NOT the metric): the same step on the true fp32 MFMA (`--math fp32`, the arithmetic of rounds
-    1-2) and BASELINE config 5 (`--math bf16 --batch 32`: bf16 matrix-core inputs, fp32 accumulation)."""
+    1-2), on the bf16 MFMA with exactly split operands (`--math bf16x3`, round 3's) and BASELINE config 5
+    (`--math bf16 --batch 32`: bf16 matrix-core inputs, fp32 accumulation)."""
     import subprocess
     out = {}
-    for key, extra in (("fp32_mfma_b16", ["--math", "fp32"]), ("config5_bf16_b32", ["--math", "bf16", "--batch", "32"])):
+    for key, extra in (("fp32_mfma_b16", ["--math", "fp32"]), ("bf16x3_b16", ["--math", "bf16x3"]),
+                       ("config5_bf16_b32", ["--math", "bf16", "--batch", "32"])):
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup),
                "--no-cpu-baseline", "--no-side-configs"] + extra
         try:
@@ -365,10 +375,12 @@ def main():
                          "BASELINE configs 3 and 2 (parity-test cases; their lines are side records, not the metric)")
     ap.add_argument("--d-streams", type=int, default=None,
                     help="HIP streams the eight discriminator updates are spread over (default: the trainer's)")
-    ap.add_argument("--math", choices=("fp32", "bf16x3", "bf16"), default="bf16x3",
+    ap.add_argument("--math", choices=("fp32", "bf16x3", "fp16x2", "bf16"), default="fp16x2",
                     help="fp32: fp32 operands on the fp32 MFMA; bf16x3: fp32 operands split exactly three ways on the "
-                         "bf16 MFMA, six partial products, fp32 accumulation (fp32 results); bf16: mixed precision of "
-                         "BASELINE config 5 (bf16 matrix-core inputs, fp32 accumulation / storage / norms / optimizer)")
+                         "bf16 MFMA, six partial products; fp16x2 (default): fp32 operands as two fp16 pieces of x * 2^s on "
+                         "the fp16 MFMA, three partial products -- fp32 accumulation and fp32 results in all three; bf16: "
+                         "mixed precision of BASELINE config 5 (bf16 matrix-core inputs, fp32 accumulation / storage / "
+                         "norms / optimizer)")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 16
@@ -477,6 +489,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "fp32", "bf16x3": "fp32 (bf16x3: operands split exactly three ways on the bf16 MFMA)",
+                      "fp16x2": "fp32 (fp16x2: operands as two fp16 pieces of x * 2^s on the fp16 MFMA)",
                       "bf16": "bf16-in/fp32-acc (mixed precision, config 5)"}[args.math],
             "data": "synthetic",
             "config": {"workload": workload_name + ("" if args.no_is_monitor else "+IS-monitor"),
@@ -488,18 +501,23 @@ def main():
                                      "bf16x3": "fp32 operands split exactly into 3 bf16 pieces each, 6 partial products "
                                                "on v_mfma_f32_32x32x16_bf16, fp32 accumulation: fp32 results (error vs "
                                                "fp64 <= the fp32 MFMA's, profiles/r03_parity.txt)",
+                                     "fp16x2": "fp32 operands as two fp16 pieces of x * 2^s (s from the tensor's maximum; residual "
+                                               "<= 2^-24 |x|), 3 partial products on v_mfma_f32_32x32x16_f16, fp32 "
+                                               "accumulation, scales undone exactly: fp32 results (error vs fp64 <= the "
+                                               "fp32 MFMA's, profiles/r04_parity.txt); launches below 1 GFLOP and the "
+                                               "LDS-staged weight-gradient kernels run bf16x3 (six products on the bf16 MFMA)",
                                      "bf16": "operands rounded to bf16, fp32 accumulation"}[args.math]},
         }
         if timing:
-            ms = (ctypes.c_double * 48)()
-            fl = (ctypes.c_double * 48)()
-            cnt = (ctypes.c_long * 48)()
+            ms = (ctypes.c_double * 96)()
+            fl = (ctypes.c_double * 96)()
+            cnt = (ctypes.c_long * 96)()
             lib.objgan_prof_collect(ms, fl, cnt)
             CAT_NAMES = cat_names(args.math)
-            cats = [(CAT_NAMES[i], ms[i], fl[i], cnt[i]) for i in range(len(CAT_NAMES)) if cnt[i] > 0]
+            cats = [(CAT_NAMES[i], ms[i], fl[i], cnt[i], i) for i in range(len(CAT_NAMES)) if cnt[i] > 0]
             cats.sort(key=lambda c: -c[1])
             if cats:
-                name, tms, tfl, n = cats[0]
+                name, tms, tfl, n, cat_index = cats[0]
                 ach = tfl / (tms * 1e-3) / 1e12
                 traffic = None          # HBM bytes / launch from the committed rocprofv3 --pmc passes
                 if os.path.exists(PMC_TRAFFIC_JSON):
@@ -510,7 +528,9 @@ def main():
                     except (ValueError, KeyError, OSError):
                         traffic = None
                 peak = {"fp32": FP32_MFMA_PEAK_TFLOPS, "bf16": BF16_MFMA_PEAK_TFLOPS,
-                        "bf16x3": round(BF16X3_PEAK_TFLOPS, 1)}[args.math]
+                        "bf16x3": round(BF16X3_PEAK_TFLOPS, 1), "fp16x2": round(FP16X2_PEAK_TFLOPS, 1)}[args.math]
+                if args.math == "fp16x2" and cat_index < 48:      # the dominant instance is one of the mode's bf16x3 launches
+                    peak = round(BF16X3_PEAK_TFLOPS, 1)
                 res["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2),
                                    "peak": peak, "unit": "TFLOP/s",
                                    "frac": round(ach / peak, 4), "traffic": traffic,
@@ -526,7 +546,15 @@ def main():
                                                             "(32 cycles per MFMA and SIMD at 2.38 GHz), 1.78-1.85 PF on "
                                                             "random / split-fp32 operands (same 32 cycles, clock held at "
                                                             "1.75-1.82 GHz by the power limit) = 297-308 TFLOP/s of "
-                                                            "fp32-equivalent work for this arithmetic on real data"}
+                                                            "fp32-equivalent work for this arithmetic on real data",
+                                                  "fp16x2": "2500 TFLOP/s dense fp16 MFMA (same rate as bf16) / 3 products "
+                                                            "per fp32 MAC.  Stand-alone probe of the matrix pipe "
+                                                            "(tools/mfma_rate.hip, profiles/r04_mfma_rate.txt): 32 cycles per "
+                                                            "32x32x16 MFMA and SIMD in every arrangement, 1.78-1.85 PF on real "
+                                                            "operands (clock held at 1.75-1.82 GHz by the power limit) = "
+                                                            "593-617 TFLOP/s of fp32-equivalent work for this arithmetic; the "
+                                                            "category also holds this tile class's launches below 1 GFLOP, "
+                                                            "which run the bf16x3 instance"}
                                                  .get(args.math))}
                 res["kernel_breakdown"] = [
                     {"kernel": c[0], "ms_per_step": round(c[1] / prof_steps, 3),
@@ -549,7 +577,7 @@ def main():
                 comm["rccl_version"] = None
             res["comm"] = comm
         if (world == 1 and not use_dist and not args.no_side_configs and not args.no_cpu_baseline
-                and args.workload == "stage3_obj" and args.math == "bf16x3" and args.batch == 16):
+                and args.workload == "stage3_obj" and args.math == "fp16x2" and args.batch == 16):
             res["side_configs"] = side_configs()
         if world == 1 and not args.no_cpu_baseline and args.workload == "stage3_obj":
             res["cpu_baseline"] = cpu_baseline(timed_steps=args.cpu_baseline_steps,

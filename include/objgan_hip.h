@@ -68,8 +68,8 @@ int objgan_avgpool2s1_backward(const float* grad_out, float* grad_in, long plane
 
 /* ---- implicit-GEMM convolution on MFMA (reference model.py conv stacks, via cuDNN) ---------- */
 long objgan_conv_packed_floats(int M, int C, int T);
-/* layout of the packed bank objgan_conv_igemm uses for these arguments -- low byte: layout class (0..4), bits 8..:
- * channel chunks per K group of the row-major classes 1 / 3 / 4 -- : part of the key of any caller-side bank cache
+/* layout of the packed bank objgan_conv_igemm uses for these arguments -- low byte: layout class (0..5), bits 8..:
+ * channel chunks per K group of the row-major classes 1 / 3 / 4 / 5 -- : part of the key of any caller-side bank cache
  * (the same filter is served by different kernels and K orders at different sizes) */
 int objgan_conv_bank_layout(int N, int C, int H, int W, int M, int Tg, int PH, int PW, int act, int math);
 /* y[n,m,a*osh+ooh,b*osw+oow] = act(bias[m] + sum_{c,t} Wp[m][c*Tg+t] * x[n,c,a*s+dh[t],b*s+dw[t]])
@@ -94,8 +94,14 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
                       int Tg, const int* dh, const int* dw, const int* src_tap,
                       int PH, int PW, int stride,
                       int OHf, int OWf, int osh, int osw, int ooh, int oow,
-                      int act, int y_prezeroed, int wt_packed, int math, float* ring,
+                      int act, int y_prezeroed, int wt_packed, int math, float* ring, const float* xmax,
                       float* ws, long ws_floats, void* stream);
+/* math: 0 fp32 operands on the fp32 MFMA; 1 operands rounded to bf16; 2 "bf16x3" (fp32 operands split exactly three ways
+ * on the bf16 MFMA, six products); 4 "fp16x2" (fp32 operands as two fp16 pieces of x * 2^s on the fp16 MFMA, three
+ * products: residual <= 2^-24 |x| for every element within 2^-10 of its tensor's maximum, 2^-39 of that maximum below;
+ * filter entries must stay below 64 in magnitude).  xmax: math 4 only -- the 256 floats objgan_absmax_partials wrote
+ * for x (the kernel derives the scale 2^s from them); NULL otherwise. */
+int objgan_absmax_partials(const float* x, long n, float* out256, void* stream);
 /* ws: the bf16 channel-blocked copy of x (math 1), then the split-K workspace.  Small-grid / long-K launches are split along K: every split stores its partial output into
  * its own slot of ws and a second kernel sums the slots in split order (+ bias, activation) -- bit-reproducible, no
  * zero-fill of y, no atomics.  objgan_conv_igemm_ws_floats (host-only, same geometry arguments; ring != 0 when a ring
@@ -119,7 +125,8 @@ long objgan_conv_dgrad_s2_phases_ws_floats(int N, int Cout, int OH, int OW, int 
 int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float* wt,
                                 int N, int Cout, int OH, int OW, int Cin, int Torig,
                                 int Tg, const int* dh, const int* dw, const int* src_tap,
-                                int PH, int PW, int wt_packed, int math, float* ws, long ws_floats, void* stream);
+                                int PH, int PW, int wt_packed, int math, const float* xmax, float* ws, long ws_floats,
+                                void* stream);
 /* dw[co][ci][kh][kw] = (accumulate ? dw : 0) + sum dy * x; ksize in {1,3,4}.  The reduction over pixels is split
  * across workgroups; the partial tiles go through ws (objgan_conv_wgrad_ws_floats floats, host-only query) and are
  * summed in split order: the weight gradient is bit-reproducible and dw needs no zero-fill.  math 1: the workspace also
@@ -130,7 +137,9 @@ long objgan_conv_wgrad_ws_floats(int N, int Cin, int H, int W, int upsample, int
 int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
                       int N, int Cin, int H, int W, int upsample, int pad_mode,
                       int Cout, int OH, int OW, int ksize, int stride, int pad, int math,
-                      int accumulate, float* ws, long ws_floats, void* stream);
+                      int accumulate, const float* xmax, const float* dymax, float* ws, long ws_floats, void* stream);
+/* (math 4: xmax / dymax = objgan_absmax_partials of x / dy; launches planned on the LDS-staged or first-generation
+ * kernels run bf16x3 instead -- both are fp32-result arithmetics) */
 
 /* ---- frozen text encoder (reference model.py:85-179 RNN_ENCODER: Embedding + bidirectional LSTM on
  * a packed sequence).  table [ntoken][I]; captions [B][L] int64; lens [B] int32; wt_ih [2][I][4H] and
@@ -289,7 +298,7 @@ int objgan_mask_resize(const double* src, int count, int n, int nsizes, const in
 
 /* ---- measurement aid (bench.py roofline leg): hipEvent-bracketed conv launches ------------------ */
 int objgan_prof_enable(int on);
-int objgan_prof_collect(double* ms, double* flops, long* count);   /* arrays of 48 categories */
+int objgan_prof_collect(double* ms, double* flops, long* count);   /* arrays of 96 categories (48..95: fp16x2 instances) */
 /* per-launch records of the current window (call before objgan_prof_collect, which resets it):
  * meta[10*i..] = {kind 0 GEMM / 1 weight gradient / 2 thin, tile height, rows, K channels, taps, images,
  * pixel-grid rows, pixel-grid columns, stride (negative: strided output phases), K splits} */

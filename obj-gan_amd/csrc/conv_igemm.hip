@@ -39,6 +39,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define OG_MAX_TAPS 32
 #define OG_ACT_NONE 0
@@ -55,7 +56,8 @@ struct IgemmArgs {
     int N, C, H, W;      // physical source dims
     int LH, LW;          // logical source dims seen by the taps (2H x 2W when upsampling)
     int M, Mpad, K, Kpad;   // K = T*C (algorithmic), Kpad = T*Cp (padded, what the loop walks)
-    int math;               // 0: fp32 MFMA, 1: bf16 inputs (RNE) on the bf16 MFMA, fp32 accumulation
+    const float* xmax;      // math 4: the 256 per-workgroup maxima of |x| (objgan_absmax_partials)
+    int math;               // 0: fp32 MFMA, 1: bf16 inputs (RNE) on the bf16 MFMA, fp32 accumulation; 2: bf16x3; 4: fp16x2
     int nhwc;               // bf16 mode: 1 = the pixel operand comes from a bf16 [N][Cp/16][H][W][16] copy of x that
                             // run_igemm2 makes in the caller's workspace (conv_igemm3_kernel<.., 3, ..>)
     int Krow;               // row pitch of the [M][Krow] bank in elements (= Kpad; bf16 bank: Kpad rounded up to 32)
@@ -157,6 +159,37 @@ __device__ __forceinline__ void og_split4(const f32x4 v, bf16x4& h, bf16x4& m, b
 }
 // the six products of one row group and K step, smallest terms first
 #define OG_MFMA_BF(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
+
+// ---- fp32 on the fp16 matrix pipe ("fp16x2", math 4) --------------------------------------------------------------
+// v_mfma_f32_32x32x16_f16 runs at the rate of the bf16 MFMA, and fp16 carries 11 significand bits: TWO pieces
+// x * 2^s = h + l (round-to-nearest at each cut) leave |residual| <= 2^-24 |x| -- half an fp32 ulp -- as long as l stays
+// a normal fp16, which a power-of-two scale 2^s per operand tensor arranges (filter banks: the constant 2^10, |w| < 64;
+// activations / gradients: max |x| * 2^s in [2^14, 2^15), from the per-workgroup maxima of objgan_absmax_partials; an
+// element below 2^-10 of its tensor's maximum keeps an ABSOLUTE error of 2^-39 of that maximum instead).  Three
+// products hh, hl, lh (ll is below 2^-24 of a product) are three MFMAs per 16-deep K step and row group instead of
+// the six of bf16x3; the scales are undone exactly in the epilogue.  Measured against fp64 the error is BELOW
+// bf16x3's (the MFMA adds 16 products before it rounds, and there are half as many accumulations): loop laboratory
+// K = 3072: 6.1e-7 vs 8.7e-7, at 295-302 vs 190-193 TFLOP/s (profiles/r04_loop_lab.txt).
+#define OG_H2_WEXP 10
+#define OG_MFMA_H(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
+// scale exponent s of a tensor from its 256 per-workgroup maxima: max * 2^s in [2^14, 2^15)  (0 for an all-zero tensor)
+__device__ __forceinline__ int og_h2_exponent(const float* __restrict__ pm, int lane) {
+    float m = fmaxf(fmaxf(pm[lane], pm[lane + 64]), fmaxf(pm[lane + 128], pm[lane + 192]));
+    m = og_wave_max(m);
+    const int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
+    int sx = (e > 0 && e < 255) ? 127 + 14 - e : 0;
+    sx = sx > 100 ? 100 : (sx < -100 ? -100 : sx);
+    return __builtin_amdgcn_readfirstlane(sx);
+}
+__device__ __forceinline__ float og_pow2(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }
+__device__ __forceinline__ void og_h2_split_h(const float* v, float xs, float* sc, f16x8& h) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = v[j] * xs; h[j] = (_Float16)sc[j]; }
+}
+__device__ __forceinline__ void og_h2_split_l(const float* sc, const f16x8& h, f16x8& l) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) l[j] = (_Float16)og_sub(sc[j], (float)h[j]);
+}
 
 // bijective XCD-aware remap of a linear workgroup id (dispatcher places id b on XCD b % 8)
 __device__ __forceinline__ int og_xcd_remap(int id, int nwg) {
@@ -577,6 +610,7 @@ struct PackArgs {
                          // 3: bf16 wt[M][Krow], Krow = Kpad rounded up to 32 (bf16 MFMA kernels)
                          // 4: bf16x3 split wt[M][Kpad/16][3][16]: every fp32 entry as its exact three-way bf16
                          //    split h + m + l (og_split8), the three pieces of a 16-deep K step back to back
+                         // 5: fp16x2 split wt[M][Kpad/16][2][16] fp16: w * 2^10 = h + l
     int kgroup;          // row-major banks (m_major 1 / 3 / 4): chunks per K group (see og_kstep)
     signed char src_tap[OG_MAX_TAPS];
 };
@@ -638,6 +672,11 @@ __device__ __forceinline__ void pack_store(const PackArgs& a, size_t row, int k,
         const float r1 = v - (float)h;
         const __bf16 m = (__bf16)r1;
         o[0] = h; o[16] = m; o[32] = (__bf16)(r1 - (float)m);
+    } else if (a.m_major == 5) {         // fp16x2: w * 2^10 = h + l, saturating beyond |w| = 63.9
+        _Float16* o = reinterpret_cast<_Float16*>(a.wt) + row + (size_t)(k >> 4) * 32 + (k & 15);
+        const float sv = fminf(fmaxf(v * (float)(1 << OG_H2_WEXP), -65504.f), 65504.f);
+        const _Float16 h = (_Float16)sv;
+        o[0] = h; o[16] = (_Float16)(sv - (float)h);
     } else if (a.m_major == 3) {
         reinterpret_cast<__bf16*>(a.wt)[row + k] = (__bf16)v;
     } else {
@@ -720,7 +759,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_bf16_kernel(const float* __r
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
     const int Kpad = a.Tg * a.Cp;
-    const int Krow = a.m_major == 3 ? (Kpad + 31) / 32 * 32 : (a.m_major == 4 ? 3 * Kpad : Kpad);
+    const int Krow = a.m_major == 3 ? (Kpad + 31) / 32 * 32 : (a.m_major == 4 ? 3 * Kpad : (a.m_major == 5 ? 2 * Kpad : Kpad));
     const long total = pack_total(a, Kpad, Krow);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
         pack_item(a, i, Kpad, Krow);
@@ -737,7 +776,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackArgs* __restrict__ jobs) {
     const PackArgs a = jobs[blockIdx.y];
     const int Kpad = a.Tg * a.Cp;
-    const int Krow = a.m_major == 3 ? (Kpad + 31) / 32 * 32 : (a.m_major == 4 ? 3 * Kpad : Kpad);
+    const int Krow = a.m_major == 3 ? (Kpad + 31) / 32 * 32 : (a.m_major == 4 ? 3 * Kpad : (a.m_major == 5 ? 2 * Kpad : Kpad));
     const long total = pack_total(a, Kpad, Krow);
     for (long base = (long)blockIdx.x * OG_PACK_CHUNK; base < total; base += (long)gridDim.x * OG_PACK_CHUNK) {
 #pragma unroll
@@ -805,7 +844,9 @@ struct WgradArgs {
     int m_begin, m_end;
     int ncol;
     int pix_per_split;
-    int math;          // 0 fp32, 1 bf16 inputs, 2 bf16x3
+    int math;          // 0 fp32, 1 bf16 inputs, 2 bf16x3, 4 fp16x2 (register-fragment kernel only; else bf16x3 runs)
+    const float* xmax;   // math 4: per-workgroup maxima of |x| and |dy| (objgan_absmax_partials)
+    const float* dymax;
     // Where a workgroup's tile goes.  One split (gridDim.y == 1): straight into dw -- stored, or added to what is there
     // when `accumulate` -- every element by exactly one thread.  Several splits: the partial tile of split s goes to
     // ws[s * ws_stride + (m - m_begin) * ncol + col] (extra rows behind the block rows); wgrad_combine_kernel sums the
@@ -1300,11 +1341,13 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
     // 16-byte load, no conversion -- instead of eight channel-strided dword gathers and eight conversions; the 32
     // pixels of a wave that are neighbours in a row read 1 KiB of contiguous memory per instruction (a plain
     // channels-last [N][H][W][Cp] copy made every such load touch 32 cache lines: 517 -> 603 TFLOP/s).
-    constexpr bool NH = MATH == 3, BF = MATH == 1 || NH, SP = MATH == 2;
+    // 4 (H2): fp32 operands as two fp16 pieces on the fp16 MFMA, three products (see OG_MFMA_H): the SP pipeline with a
+    // 64-byte bank record [h16 | l16] per row and step and the scales of the two operands undone in the epilogue.
+    constexpr bool NH = MATH == 3, BF = MATH == 1 || NH, SP = MATH == 2, H2 = MATH == 4;
     // P3: three LDS row tiles / three pixel-fragment register sets, loads two steps ahead (see the main loop).  SP: a
     // step is 6 TM MFMAs; NH: 2 TM MFMAs -- 0.2 us at TM = 6, far below a loaded L2 round trip, and the fragment of a
     // step is only 8 registers.
-    constexpr bool P3 = SP || NH;
+    constexpr bool P3 = SP || NH || H2;
     constexpr int BM = 32 * TM;
     constexpr int BN = 32 * NW;
     constexpr int BK = 16;
@@ -1320,7 +1363,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
     // accumulation.  One loop iteration then covers 32 k (two 16-channel gathers, two MFMAs per row
     // group); the bank is bf16 [M][Krow], so a row piece is again 64 bytes per iteration and the
     // LDS image / fragment reads keep their 80-byte pitch.
-    constexpr int ESZ = (BF || SP) ? 2 : 4;
+    constexpr int ESZ = (BF || SP || H2) ? 2 : 4;
     constexpr int NBC = NH ? 4 : 8;                   // registers per 16-channel chunk of the pixel operand
     constexpr int NB = BF ? 2 * NBC : 8;              // pixel-operand registers per lane and iteration
 
@@ -1438,12 +1481,12 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
         }
     }
     const unsigned adir = (m0 + lcol) < a.m_end
-        ? (unsigned)(m0 + lcol) * (unsigned)a.Krow * (unsigned)ESZ + lrow * ((BF || SP) ? 16u : 32u) : OG_OOB;
+        ? (unsigned)(m0 + lcol) * (unsigned)a.Krow * (unsigned)ESZ + lrow * ((BF || SP || H2) ? 16u : 32u) : OG_OOB;
     f32x4 ra[NA_PER];
     auto load_a = [&](int kt) {
         // (SP: hipcc keeps the strength-reduced offset of the three-step loop in a VGPR -- SGPR pressure -- and would
         // wrap every load in a waterfall loop; one readfirstlane instead)
-        const int so = SP ? __builtin_amdgcn_readfirstlane(kt * ABYTES) : kt * ABYTES;
+        const int so = (SP || H2) ? __builtin_amdgcn_readfirstlane(kt * ABYTES) : kt * ABYTES;
 #pragma unroll
         for (int i = 0; i < NA_PER; ++i)
             ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, avoff[i], so, 0));
@@ -1474,6 +1517,12 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
     }
     tap_geometry(min(t_ld, a.T - 1));
 
+    float h2_xs = 1.f, h2_inv = 1.f;                  // H2: scale of the pixel operand, inverse of both scales
+    if (H2) {
+        const int sx = og_h2_exponent(a.xmax, lane);
+        h2_xs = og_pow2(sx);
+        h2_inv = og_pow2(-sx - OG_H2_WEXP);
+    }
     f32x16 acc[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1484,9 +1533,9 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
     float rb0[NB], rb1[NB];
     f32x4 ad0[NAD], ad1[NAD];                          // TM == 1: direct row fragments (ping-pong)
     auto load_adir = [&](f32x4 (&ad)[NAD], int kt) {
-        const int so = SP ? __builtin_amdgcn_readfirstlane(kt * ABYTES) : kt * ABYTES;
+        const int so = (SP || H2) ? __builtin_amdgcn_readfirstlane(kt * ABYTES) : kt * ABYTES;
         ad[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, adir, so, 0));
-        ad[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, adir + ((BF || SP) ? 32u : 16u), so, 0));
+        ad[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, adir + ((BF || SP || H2) ? 32u : 16u), so, 0));
         if (SP) ad[NAD - 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, adir + 64u, so, 0));
     };
     // `mid`: the refill of the software pipeline (LDS store of the next row tile, next pixel gather, next
@@ -1494,6 +1543,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
     // in the fp32 LDS form it goes behind the first TM MFMAs and runs in the shadow of the rest (r02:
     // weight-gradient kernel 110 -> 119 TFLOP/s with the same move).
     bf16x8 ah[SP ? TM : 1], am[SP ? TM : 1], al[SP ? TM : 1];     // SP: row fragments of the current step
+    f16x8 hh[H2 ? TM : 1], hl[H2 ? TM : 1];                         // H2: the two pieces of the row fragments
 #ifdef OG_DEV
     if (SP) {
 #pragma unroll
@@ -1542,6 +1592,38 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
             for (int i = 0; i < TM; ++i) OG_MFMA_BF(ah[i], bm, acc[i]);
 #pragma unroll
             for (int i = 0; i < TM; ++i) OG_MFMA_BF(ah[i], bl, acc[i]);
+            return;
+        }
+        if (H2) {
+            // Order as SP: the product that needs only the h piece of the pixel fragment first, the refill behind the
+            // first TM MFMAs, the l piece (16 VALU) between the next TM.
+            f16x8 bh, bl;
+            float sc[8];
+            og_h2_split_h(rb, h2_xs, sc, bh);
+            if (ALDS) {
+                const char* T = reinterpret_cast<const char*>(lds + cur * TILE) + lcol * (LD * 4) + lrow * 16;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    hl[i] = *reinterpret_cast<const f16x8*>(T + i * 32 * LD * 4 + 32);
+                    hh[i] = *reinterpret_cast<const f16x8*>(T + i * 32 * LD * 4);
+                }
+            } else {
+                hh[0] = __builtin_bit_cast(f16x8, ad[0]);
+                hl[0] = __builtin_bit_cast(f16x8, ad[1]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OG_MFMA_H(hl[i], bh, acc[i]);
+            if (ALDS) {
+                __builtin_amdgcn_sched_barrier(0);
+                mid();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            og_h2_split_l(sc, bh, bl);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OG_MFMA_H(hh[i], bh, acc[i]);
+            if (ALDS) og_interleave<TM, (16 + TM - 1) / TM>();
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OG_MFMA_H(hh[i], bl, acc[i]);
             return;
         }
         if (BF) {
@@ -1757,7 +1839,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
             if (m < a.m_end) {
-                float v = acc[i][r];
+                float v = H2 ? acc[i][r] * h2_inv : acc[i][r];
                 if (to_ws) {
                     yb[(size_t)m * plane] = v;
                 } else if (split) {
@@ -1784,7 +1866,9 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad3_kernel(const WgradArgs a,
     // MATH as in conv_igemm3_kernel.  SP (bf16x3): the dy rows are split by their loader thread on the way into
     // LDS (row image [h 16 | m 16 | l 16] bf16, 112-byte pitch), the gathered x fragment in registers; the gather
     // runs two steps ahead (three fragment sets), see conv_igemm3_kernel.
-    constexpr bool BF = MATH == 1, SP = MATH == 2;
+    // H2 (fp16x2, math 4): both operands scaled by their tensors' power-of-two scales, dy rows split into two fp16 pieces
+    // on the way into LDS (row image [h 16 | l 16], 80-byte pitch), x in registers; three MFMAs per row group and step.
+    constexpr bool BF = MATH == 1, SP = MATH == 2, H2 = MATH == 4, P3 = SP || H2;
     constexpr int BM = 32 * TM;
     constexpr int BN = 32 * NW;
     constexpr int BK = 16;
@@ -1795,7 +1879,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad3_kernel(const WgradArgs a,
     constexpr bool ALDS = TM > 1;
     static_assert(XR == 0 || (MATH == 0 && TM > 1), "extra rows: fp32 LDS form only");
 
-    __shared__ __attribute__((aligned(16))) float lds[ALDS ? (SP ? 3 : 2) * TILE : 4];
+    __shared__ __attribute__((aligned(16))) float lds[ALDS ? (P3 ? 3 : 2) * TILE : 4];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1828,6 +1912,12 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad3_kernel(const WgradArgs a,
         (void*)a.x, 0, (int)((unsigned)a.N * a.Cin * HW * 4u), OG_BUF_FLAGS);
     __amdgpu_buffer_rsrc_t dyres = __builtin_amdgcn_make_buffer_rsrc(
         (void*)a.dy, 0, (int)((unsigned)a.N * a.Cout * OHW * 4u), OG_BUF_FLAGS);
+
+    float h2_xs = 1.f, h2_dys = 1.f, h2_inv = 1.f;
+    if (H2) {
+        const int sx = og_h2_exponent(a.xmax, lane), sd = og_h2_exponent(a.dymax, lane);
+        h2_xs = og_pow2(sx); h2_dys = og_pow2(sd); h2_inv = og_pow2(-sx - sd);
+    }
 
     // ---- column of this lane
     const int col = c0 + wid * 32 + lcol;
@@ -1910,7 +2000,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad3_kernel(const WgradArgs a,
             const int row = idx >> 2, q = idx & 3;
             const bool on = (NA4 % NT == 0 || idx < NA4) && (m0 + row) < a.m_end;
             avoff[i] = on ? ((unsigned)(m0 + row) * (unsigned)OHW + q * 4u) * 4u : OG_OOB;
-            alds[i] = (NA4 % NT == 0 || idx < NA4) ? row * LD + q * (SP ? 2 : 4) : -1;
+            alds[i] = (NA4 % NT == 0 || idx < NA4) ? row * LD + q * (P3 ? 2 : 4) : -1;
         }
     }
     const unsigned adir = (m0 + lcol) < a.m_end ? ((unsigned)(m0 + lcol) * (unsigned)OHW + lrow * 8u) * 4u : OG_OOB;
@@ -1938,6 +2028,24 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad3_kernel(const WgradArgs a,
     };
     auto store_a = [&](int buf) {
         float* As = lds + buf * TILE;
+        if (H2) {
+#pragma unroll
+            for (int i = 0; i < NA_PER; ++i) {
+                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                f16x4 h, l;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float sv = ra[i][j] * h2_dys;
+                    h[j] = (_Float16)sv;
+                    l[j] = (_Float16)og_sub(sv, (float)h[j]);
+                }
+                if (NA4 % NT == 0 || alds[i] >= 0) {
+                    *reinterpret_cast<f16x4*>(As + alds[i]) = h;
+                    *reinterpret_cast<f16x4*>(As + alds[i] + 8) = l;
+                }
+            }
+            return;
+        }
         if (SP) {
 #pragma unroll
             for (int i = 0; i < NA_PER; ++i) {
@@ -1967,7 +2075,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad3_kernel(const WgradArgs a,
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    const int a_rd = lcol * LD + lrow * (SP ? 4 : 8);
+    const int a_rd = lcol * LD + lrow * (P3 ? 4 : 8);
     float accx[XR > 0 ? XR : 1];
 #pragma unroll
     for (int j = 0; j < (XR > 0 ? XR : 1); ++j) accx[j] = 0.f;
@@ -1975,6 +2083,39 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad3_kernel(const WgradArgs a,
     f32x4 ad0[2], ad1[2];
     auto mma = [&](const float (&rb)[8], const f32x4 (&ad)[2], int cur, auto&& mid) {      // mid: see conv_igemm3_kernel
         if (BF || !ALDS) mid();
+        if (H2) {                                       // order and pinning as SP
+            f16x8 bh, bl;
+            float sc[8];
+            og_h2_split_h(rb, h2_xs, sc, bh);
+            f16x8 ah[TM], al[TM];
+            if (ALDS) {
+                const float* Tl = lds + cur * TILE;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    al[i] = *reinterpret_cast<const f16x8*>(Tl + a_rd + i * 32 * LD + 8);
+                    ah[i] = *reinterpret_cast<const f16x8*>(Tl + a_rd + i * 32 * LD);
+                }
+            } else {
+                const float d[8] = {ad[0][0], ad[0][1], ad[0][2], ad[0][3], ad[1][0], ad[1][1], ad[1][2], ad[1][3]};
+                float dsc[8];
+                og_h2_split_h(d, h2_dys, dsc, ah[0]);
+                og_h2_split_l(dsc, ah[0], al[0]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OG_MFMA_H(al[i], bh, acc[i]);
+            if (ALDS) {
+                __builtin_amdgcn_sched_barrier(0);
+                mid();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            og_h2_split_l(sc, bh, bl);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OG_MFMA_H(ah[i], bh, acc[i]);
+            if (ALDS) og_interleave<TM, (16 + TM - 1) / TM>();
+#pragma unroll
+            for (int i = 0; i < TM; ++i) OG_MFMA_H(ah[i], bl, acc[i]);
+            return;
+        }
         if (SP) {                                       // order and pinning: see conv_igemm3_kernel
             bf16x8 bh, bm, bl;
             og_split8_h(rb, bh);
@@ -2082,16 +2223,16 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad3_kernel(const WgradArgs a,
     if (ALDS) {
         load_a();
         store_a(0);
-        if (SP || nk > 1) load_a();
+        if (P3 || nk > 1) load_a();
     } else {
         load_adir(ad0);
     }
     load_b(rb0);
-    if (SP && ALDS) load_b(rb1);
+    if (P3 && ALDS) load_b(rb1);
     if (ALDS) __syncthreads();
     int cur = 0;
     int kt = 0;                                       // two steps per trip, see conv_igemm3_kernel
-    if (SP && ALDS) {               // three fragment sets / three LDS tiles, gather two steps ahead (conv_igemm3_kernel)
+    if (P3 && ALDS) {               // three fragment sets / three LDS tiles, gather two steps ahead (conv_igemm3_kernel)
         float rb2[8];
         int ks = 0;
         if (ks + 2 < nk) {
@@ -2142,7 +2283,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad3_kernel(const WgradArgs a,
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-            if (m < a.m_end) og_wgrad_store(a, m, col, acc[i][r], split);
+            if (m < a.m_end) og_wgrad_store(a, m, col, H2 ? acc[i][r] * h2_inv : acc[i][r], split);
         }
     }
     if (XR > 0 && has_x && lrow == 0) {
@@ -2450,7 +2591,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bfb_kernel(const WgradArgs
 // When enabled, every conv launch is bracketed by hipEvents on its own stream and tagged with a
 // category (kind, taps / ksize, tile config) and its ALGORITHMIC flops 2*M*K*Npix.  Off by default;
 // the only mutable global state of the library, touched by the host thread only.
-#define OG_PROF_CATS 48
+#define OG_PROF_CATS 96          // 0..47: see OG_CAT_*; 48..95: the same kernel families in their fp16x2 instances
 #define OG_PROF_MAX 65536
 // meta: {kind (0 forward / data-gradient GEMM, 1 weight gradient, 2 thin VALU), tile height TM, rows M,
 //        K channels C, taps T, images N, pixel-grid rows, pixel-grid columns, stride, grid.y splits}
@@ -2689,6 +2830,24 @@ static int launch_igemm2(const IgemmArgs& a, int TM, dim3 grid, hipStream_t s, i
 #undef OG_IGNH
         return og_launch_status();
     }
+    if (a.math == 4) {                     // fp16x2
+#define OG_IGH2(TMv)                                                                                                  \
+        if (nw == 8) hipLaunchKernelGGL((conv_igemm3_kernel<TMv, false, 4, 8>), grid, dim3(512), 0, s, a);            \
+        else hipLaunchKernelGGL((conv_igemm3_kernel<TMv, false, 4, 4>), grid, dim3(256), 0, s, a);
+        switch (TM) {
+            case 1: if (a.M <= 32) hipLaunchKernelGGL((conv_igemm3_kernel<1, true, 4, 4>), grid, dim3(256), 0, s, a);
+                    else { OG_IGH2(1) }
+                    break;
+            case 2: OG_IGH2(2) break;
+            case 3: OG_IGH2(3) break;
+            case 4: OG_IGH2(4) break;
+            case 5: OG_IGH2(5) break;
+            case 6: OG_IGH2(6) break;
+            default: OG_IGH2(7) break;
+        }
+#undef OG_IGH2
+        return og_launch_status();
+    }
     if (a.math == 2 && nw == 8) {          // 8-wave workgroups: 32 * TM rows x 256 pixels
         switch (TM) {
             case 1: hipLaunchKernelGGL((conv_igemm3_kernel<1, false, 2, 8>), grid, dim3(512), 0, s, a); break;
@@ -2750,7 +2909,7 @@ static Igemm2Plan igemm2_plan(const IgemmArgs& a, int y_prezeroed) {
     // layers 179 vs 158 TFLOP/s; with 8 waves the block rows are as tall as the row count allows)
     p.nw = 4;
     const int tm_tall = og_cdiv(groups, og_cdiv(groups, 7));
-    if ((a.math == 2 || (a.math == 1 && a.nhwc)) && tm_tall >= 4 && og_nw8_min() > 0 &&
+    if ((a.math == 2 || a.math == 4 || (a.math == 1 && a.nhwc)) && tm_tall >= 4 && og_nw8_min() > 0 &&
         (long)og_cdiv(groups, 7) * og_cdiv(Npix, 256) * nph >= og_nw8_min()) p.nw = 8;
     p.tiles_n = og_cdiv(Npix, 32 * p.nw);
     // (Carrying the 2 / 4 rows that 194 / 388 channels have beyond a multiple of 32 on the VALU next to the
@@ -2836,7 +2995,7 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed, float* ws, lo
     int rc = OG_OK;
     if (full_rows > 0) {
         a.m_begin = 0; a.m_end = min(a.M, full_rows * TM * 32);
-        ProfRec* pr = prof_begin(nw == 8 ? OG_CAT_IGEMM2_NW8(TM) : OG_CAT_IGEMM2(TM),
+        ProfRec* pr = prof_begin((nw == 8 ? OG_CAT_IGEMM2_NW8(TM) : OG_CAT_IGEMM2(TM)) + (a.math == 4 ? 48 : 0),
                                  2.0 * (a.m_end - a.m_begin) * (double)a.K * (double)Npix * nph, s);
         prof_meta(pr, 0, TM, a.m_end - a.m_begin, a.C, a.T, a.N, a.PH * nph, a.PW, a.stride * (a.osh > 1 ? -1 : 1), splits);
         rc = launch_igemm2(a, TM, dim3(full_rows * tiles_n * nph, splits, 1), s, nw);
@@ -2845,7 +3004,7 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed, float* ws, lo
     }
     if (rest > 0) {
         a.m_begin = full_rows * TM * 32; a.m_end = a.M;
-        ProfRec* pr = prof_begin(nw == 8 ? OG_CAT_IGEMM2_NW8(rest) : OG_CAT_IGEMM2(rest),
+        ProfRec* pr = prof_begin((nw == 8 ? OG_CAT_IGEMM2_NW8(rest) : OG_CAT_IGEMM2(rest)) + (a.math == 4 ? 48 : 0),
                                  2.0 * (a.m_end - a.m_begin) * (double)a.K * (double)Npix * nph, s);
         prof_meta(pr, 0, rest, a.m_end - a.m_begin, a.C, a.T, a.N, a.PH * nph, a.PW, a.stride * (a.osh > 1 ? -1 : 1), splits);
         rc = launch_igemm2(a, rest, dim3(tiles_n * nph, splits, 1), s, nw);
@@ -2872,7 +3031,7 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed, float* ws, lo
 // Row pitch of a packed bank in elements: fp32 Kpad floats; bf16 Kpad rounded up to 32 (one iteration = 32 k);
 // bf16x3 three bf16 per k (the h / m / l pieces of a 16-deep step back to back: 96 bytes).
 static inline int og_krow(int Kpad, int math) {
-    return math == 1 ? (Kpad + 31) / 32 * 32 : (math == 2 ? 3 * Kpad : Kpad);
+    return math == 1 ? (Kpad + 31) / 32 * 32 : (math == 2 ? 3 * Kpad : (math == 4 ? 2 * Kpad : Kpad));
 }
 
 // Chunks per K group (og_kstep) of a row-major bank / conv_igemm3_kernel launch: a function of what both the pack job
@@ -2904,7 +3063,7 @@ static int og_bank_layout(int N, int C, int H, int W, int M, int Tg, int PH, int
     const bool thin = !og_nothin() && M <= 32 && (Tg == 9 || Tg == 4) && (long)N * PH * PW >= 65536
                       && (MT <= 4 || (act != OG_ACT_TANH && act != OG_ACT_SIGMOID));
     if (thin) return 2;
-    return math == 1 ? 3 : (math == 2 ? 4 : 1);
+    return math == 1 ? 3 : (math == 2 ? 4 : (math == 4 ? 5 : 1));
 }
 
 // The PackArgs of objgan_conv_igemm for these arguments (single source of truth for the call itself and for
@@ -2934,12 +3093,39 @@ static void og_fill_pack_phase(PackArgs& p, const float* w, float* wt, int Cout,
     const long bank = math ? (long)M * Krow / 2 : (long)M * Krow;
     p.w = w; p.wt = wt + phase * bank; p.Cout = Cout; p.Cin = Cin; p.Torig = Torig; p.Tg = Tg;
     p.M = M; p.Mpad = (M + 127) / 128 * 128; p.Ck = C; p.Cp = Cp;
-    p.transpose = 1; p.m_major = math == 1 ? 3 : (math == 2 ? 4 : 1);
+    p.transpose = 1; p.m_major = math == 1 ? 3 : (math == 2 ? 4 : (math == 4 ? 5 : 1));
     p.kgroup = og_kgroup_phases(C);
     for (int t = 0; t < OG_MAX_TAPS; ++t) p.src_tap[t] = (signed char)(t < Tg ? src_tap_phase[t] : -1);
 }
 
+
+// Per-workgroup maxima of |x| over a tensor: out[0..255] (fp16x2's scale input; the consumers reduce the 256 values
+// themselves -- no zeroed accumulator, no atomics, one launch).
+__global__ __launch_bounds__(256) void absmax_partials_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float m = 0.f;
+    const long n4 = n >> 2;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += 256L * 256) {
+        const f32x4 v = x4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
+    m = og_wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
 extern "C" {
+
+// out[256] = per-workgroup maxima of |x[0..n)| (x 16-byte aligned): the scale input of the fp16x2 arithmetic (math 4).
+int objgan_absmax_partials(const float* x, long n, float* out256, void* stream) {
+    OG_ENTRY();
+    if (!x || !out256 || n <= 0 || ((size_t)x & 15)) return OG_BAD_ARGS;
+    hipLaunchKernelGGL(absmax_partials_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, x, n, out256);
+    return og_launch_status();
+}
 
 // ---- batched re-packing of cached filter banks ---------------------------------------------------
 // A job is an opaque blob of objgan_conv_pack_job_bytes() bytes describing "pack w into wt exactly as
@@ -3005,11 +3191,12 @@ long objgan_conv_packed_floats(int M, int C, int T) {
 static int og_igemm_setup(PackArgs& p, IgemmArgs& a, int& MT, const float* x, const float* w, const float* bias, float* y,
                           float* wt, int N, int C, int H, int W, int upsample, int pad_mode, int Cout, int Cin, int Torig,
                           int transpose, int Tg, const int* dh, const int* dw, const int* src_tap, int PH, int PW,
-                          int stride, int OHf, int OWf, int osh, int osw, int ooh, int oow, int act, int math, float* ring) {
+                          int stride, int OHf, int OWf, int osh, int osw, int ooh, int oow, int act, int math, float* ring,
+                          const float* xmax = nullptr) {
     if (Tg < 1 || Tg > OG_MAX_TAPS) return OG_BAD_ARGS;
     if (ring && !(osh == 1 && osw == 1 && ooh == 0 && oow == 0 && PH == OHf + 2 && PW == OWf + 2 && !bias && !act))
         return OG_BAD_ARGS;
-    if (math < 0 || math > 2) return OG_BAD_ARGS;
+    if (math < 0 || math > 4 || math == 3) return OG_BAD_ARGS;
     if (Torig < 1 || Torig > 127) return OG_BAD_ARGS;
     const int M = transpose ? Cin : Cout;
     const int Ck = transpose ? Cout : Cin;
@@ -3017,12 +3204,14 @@ static int og_igemm_setup(PackArgs& p, IgemmArgs& a, int& MT, const float* x, co
     if (N <= 0 || PH <= 0 || PW <= 0 || M <= 0) return 2;
     MT = 32;
     og_fill_pack(p, w, wt, N, C, H, W, Cout, Cin, Torig, transpose, Tg, src_tap, PH, PW, act, math, &MT);
-    const int kmath = p.m_major == 3 ? 1 : (p.m_major == 4 ? 2 : 0);       // arithmetic of the kernel that runs
+    const int kmath = p.m_major == 3 ? 1 : (p.m_major == 4 ? 2 : (p.m_major == 5 ? 4 : 0));   // arithmetic of the kernel that runs
     a.x = x; a.wt = wt; a.bias = bias; a.y = y;
     a.N = N; a.C = C; a.H = H; a.W = W;
     a.LH = upsample ? 2 * H : H; a.LW = upsample ? 2 * W : W;
     a.M = M; a.Mpad = p.Mpad; a.K = C * Tg; a.Kpad = Tg * p.Cp; a.T = Tg; a.Cp = p.Cp; a.kgroup = p.kgroup;
     a.math = kmath;
+    a.xmax = xmax;
+    if (kmath == 4 && x && !xmax) return OG_BAD_ARGS;      // fp16x2 needs the maxima of its pixel operand (x == NULL: size query)
     a.nhwc = igemm2_nhwc_floats(kmath, N, H, W, p.Cp) > 0 ? 1 : 0;
     a.Krow = og_krow(a.Kpad, kmath);
     a.m_begin = 0; a.m_end = M;
@@ -3041,7 +3230,7 @@ static int og_igemm_setup(PackArgs& p, IgemmArgs& a, int& MT, const float* x, co
         a.tap[t] = (int)(((unsigned)w_ << 16) | ((unsigned)h & 0xffffu));
     }
     if (!(osh == 1 && osw == 1 && PH == OHf && PW == OWf) && (bias || act)) return OG_BAD_ARGS;
-    if (ring && p.m_major != 1 && p.m_major != 3 && p.m_major != 4) return OG_BAD_ARGS;     // ring mode: conv_igemm3_kernel only (ask objgan_conv_bank_layout)
+    if (ring && p.m_major != 1 && p.m_major != 3 && p.m_major != 4 && p.m_major != 5) return OG_BAD_ARGS;     // ring mode: conv_igemm3_kernel only (ask objgan_conv_bank_layout)
     return OG_OK;
 }
 
@@ -3071,14 +3260,14 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
                       int Tg, const int* dh, const int* dw, const int* src_tap,
                       int PH, int PW, int stride,
                       int OHf, int OWf, int osh, int osw, int ooh, int oow,
-                      int act, int y_prezeroed, int wt_packed, int math, float* ring,
+                      int act, int y_prezeroed, int wt_packed, int math, float* ring, const float* xmax,
                       float* ws, long ws_floats, void* stream) {
     OG_ENTRY();
     PackArgs p;
     IgemmArgs a;
     int MT = 32;
     const int rc0 = og_igemm_setup(p, a, MT, x, w, bias, y, wt, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, transpose,
-                                   Tg, dh, dw, src_tap, PH, PW, stride, OHf, OWf, osh, osw, ooh, oow, act, math, ring);
+                                   Tg, dh, dw, src_tap, PH, PW, stride, OHf, OWf, osh, osw, ooh, oow, act, math, ring, xmax);
     if (rc0 == 2) return OG_OK;
     if (rc0 != OG_OK) return rc0;
     hipStream_t s = (hipStream_t)stream;
@@ -3101,10 +3290,11 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
 int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float* wt,
                                 int N, int Cout, int OH, int OW, int Cin, int Torig,
                                 int Tg, const int* dh, const int* dw, const int* src_tap,
-                                int PH, int PW, int wt_packed, int math, float* ws, long ws_floats, void* stream) {
+                                int PH, int PW, int wt_packed, int math, const float* xmax, float* ws, long ws_floats,
+                                void* stream) {
     OG_ENTRY();
     if (Tg < 1 || Tg > 8) return OG_BAD_ARGS;
-    if (math < 0 || math > 2) return OG_BAD_ARGS;
+    if (math < 0 || math > 4 || math == 3 || (math == 4 && !xmax)) return OG_BAD_ARGS;
     if (Torig < 1 || Torig > 127) return OG_BAD_ARGS;
     if (N <= 0 || PH <= 0 || PW <= 0 || Cin <= 0) return OG_OK;
     const int M = Cin, C = Cout;
@@ -3129,7 +3319,7 @@ int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float*
     a.N = N; a.C = C; a.H = OH; a.W = OW; a.LH = OH; a.LW = OW;
     a.M = M; a.Mpad = (M + 127) / 128 * 128; a.K = C * Tg; a.Kpad = Kpad; a.T = Tg; a.Cp = Cp;
     a.kgroup = og_kgroup_phases(C);
-    a.math = math; a.Krow = Krow;
+    a.math = math; a.Krow = Krow; a.xmax = xmax;
     a.nhwc = igemm2_nhwc_floats(math, N, OH, OW, Cp) > 0 ? 1 : 0;
     a.m_begin = 0; a.m_end = M;
     a.PH = PH; a.PW = PW; a.OHf = 2 * PH; a.OWf = 2 * PW;
@@ -3173,14 +3363,21 @@ int objgan_reflect_ring_fold(const float* ring, float* y, long planes, int H, in
 static int og_wgrad(const float* x, const float* dy, float* dw,
                     int N, int Cin, int H, int W, int upsample, int pad_mode,
                     int Cout, int OH, int OW, int ksize, int stride, int pad,
-                    int math, int accumulate, float* ws, long ws_floats, long* ws_need, hipStream_t s) {
+                    int math, int accumulate, float* ws, long ws_floats, long* ws_need, hipStream_t s,
+                    const float* xmax = nullptr, const float* dymax = nullptr) {
     const bool plan_only = ws_need != nullptr;
     long ws_used = 0;
     if (plan_only) *ws_need = 0;
     if (ksize != 1 && ksize != 3 && ksize != 4) return OG_BAD_ARGS;
-    if (math < 0 || math > 2) return OG_BAD_ARGS;
+    if (math < 0 || math > 4 || math == 3) return OG_BAD_ARGS;
+    if (math == 4 && !plan_only && (!xmax || !dymax)) return OG_BAD_ARGS;
     if (N <= 0 || Cout <= 0 || Cin <= 0) return OG_OK;
+    // fp16x2 lives in the register-fragment kernel; launches that plan the LDS-staged / first-generation kernels run
+    // bf16x3 (both are fp32-result arithmetics)
+    const bool h2 = math == 4;
+    if (h2) math = 2;
     WgradArgs a;
+    a.xmax = xmax; a.dymax = dymax;
     a.ws = nullptr; a.ws_stride = 0; a.accumulate = accumulate;
     a.x = x; a.dy = dy; a.dw = dw;
     a.N = N; a.Cin = Cin; a.H = H; a.W = W;
@@ -3299,7 +3496,8 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
                 fprintf(stderr, "OGTRACE wgrad TM=%d NW=%d form=%d Cout=%d Cin=%d k=%d N=%d OH=%d OW=%d stride=%d grid=%u,%u math=%d\n", tm, nw,
                         use3 ? 3 : 2, Cout, Cin, ksize, N, OH, OW, stride, grid.x, grid.y, math);
             ProfRec* pr = prof_begin(bfb ? OG_CAT_WGRAD2(tm)
-                                         : (use3 ? (nw == 8 ? OG_CAT_WGRAD3_NW8(tm) : OG_CAT_WGRAD3(tm)) : OG_CAT_WGRAD2(tm)),
+                                         : (use3 ? (nw == 8 ? OG_CAT_WGRAD3_NW8(tm) : OG_CAT_WGRAD3(tm)) + (h2 ? 48 : 0)
+                                                 : OG_CAT_WGRAD2(tm)),
                                      2.0 * (a.m_end - a.m_begin + a.xr_count) * (double)a.ncol * (double)Npix, s);
             prof_meta(pr, 1, tm, a.m_end - a.m_begin + a.xr_count, Cin, ksize * ksize, N, OH, OW,
                       stride * (upsample ? 10 : 1) * (pad_mode ? -1 : 1), splits);
@@ -3315,6 +3513,10 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
                      else hipLaunchKernelGGL((conv_wgrad2_kernel<TMv, 0, 4>), grid, dim3(256), 0, s, a, ksize);
 #define OG_WG2(TMv) if (bf && TMv <= 2) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, 1>), grid, dim3(256), 0, s, a, ksize); \
                     else if (bf) hipLaunchKernelGGL((conv_wgrad2_kernel<TMv, 1>), grid, dim3(256), 0, s, a, ksize); \
+                    else if (h2 && use3 && nw == 8 && b128) hipLaunchKernelGGL((conv_wgrad3_kernel<(TMv > 1 ? TMv : 2), 4, true, 0, 8>), grid, dim3(512), 0, s, a, ksize); \
+                    else if (h2 && use3 && nw == 8) hipLaunchKernelGGL((conv_wgrad3_kernel<(TMv > 1 ? TMv : 2), 4, false, 0, 8>), grid, dim3(512), 0, s, a, ksize); \
+                    else if (h2 && use3 && b128) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, 4, true>), grid, dim3(256), 0, s, a, ksize); \
+                    else if (h2 && use3) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, 4>), grid, dim3(256), 0, s, a, ksize); \
                     else if (sp && use3 && nw == 8 && b128) hipLaunchKernelGGL((conv_wgrad3_kernel<(TMv > 1 ? TMv : 2), 2, true, 0, 8>), grid, dim3(512), 0, s, a, ksize); \
                     else if (sp && use3 && nw == 8) hipLaunchKernelGGL((conv_wgrad3_kernel<(TMv > 1 ? TMv : 2), 2, false, 0, 8>), grid, dim3(512), 0, s, a, ksize); \
                     else if (sp && use3 && b128) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, 2, true>), grid, dim3(256), 0, s, a, ksize); \
@@ -3440,10 +3642,11 @@ long objgan_conv_wgrad_ws_floats(int N, int Cin, int H, int W, int upsample, int
 int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
                       int N, int Cin, int H, int W, int upsample, int pad_mode,
                       int Cout, int OH, int OW, int ksize, int stride, int pad,
-                      int math, int accumulate, float* ws, long ws_floats, void* stream) {
+                      int math, int accumulate, const float* xmax, const float* dymax, float* ws, long ws_floats,
+                      void* stream) {
     OG_ENTRY();
     return og_wgrad(x, dy, dw, N, Cin, H, W, upsample, pad_mode, Cout, OH, OW, ksize, stride, pad, math, accumulate ? 1 : 0,
-                    ws, ws_floats, nullptr, (hipStream_t)stream);
+                    ws, ws_floats, nullptr, (hipStream_t)stream, xmax, dymax);
 }
 
 // ---- profiling control (see the note above the host section) ---------------------------------

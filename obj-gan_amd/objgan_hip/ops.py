@@ -58,16 +58,22 @@ _ACT = {None: 0, "none": 0, "lrelu": 1, "tanh": 2, "sigmoid": 3, "relu": 4}
 #             (the dropped products are below 2^-24 of a product, 30x below the accumulation rounding both modes
 #             share) at 2.67x the native fp32 matrix rate -- csrc/conv_igemm.hip `og_split8`; the same scheme as
 #             oneMKL's BF16x3 / cuBLAS's BF16x9 fp32 emulation
+#   "fp16x2"  fp32 operands, each as TWO fp16 pieces of x * 2^s (s from the tensor's maximum: |x * 2^s - h - l| <= 2^-24 |x|
+#             for every element within 2^-10 of the maximum), the three products hh, hl, lh on v_mfma_f32_32x32x16_f16
+#             with fp32 accumulation, the scales undone exactly in the epilogue: fp32 results at HALF the matrix work of
+#             bf16x3 -- measured against fp64 its error is below bf16x3's and the fp32 MFMA's.  Taken by the large
+#             launches (>= _H2_MIN_FLOP: each needs a maximum pass over its pixel operand); the small ones, the
+#             LDS-staged weight-gradient kernels and the thin VALU kernels keep their arithmetic (bf16x3 / fp32).
 #   "bf16"    mixed precision (BASELINE config 5): operands ROUNDED to bf16 at the matrix-core inputs, fp32
 #             accumulation, fp32 tensors / master weights / norm statistics
 import os as _os
-_MATH_IDS = {"fp32": 0, "bf16": 1, "bf16x3": 2}
-# default: bf16x3 -- fp32 results at 1.5x the speed of the fp32 MFMA on the hot-path shapes; measured against fp64 its
-# error is at or below the fp32 MFMA's on every operator (tests/test_kernels_gpu.py, profiles/r03_parity.txt)
-if _os.environ.get("OBJGAN_CONV_MATH", "bf16x3") not in _MATH_IDS:      # a typo must not silently change the arithmetic
+_MATH_IDS = {"fp32": 0, "bf16": 1, "bf16x3": 2, "fp16x2": 4}
+# default: fp16x2 (round 4; rounds 1-2: fp32, round 3: bf16x3) -- fp32 results; measured against fp64 the error of both
+# split arithmetics is at or below the fp32 MFMA's on every operator (tests/test_kernels_gpu.py, profiles/r04_parity.txt)
+if _os.environ.get("OBJGAN_CONV_MATH", "fp16x2") not in _MATH_IDS:      # a typo must not silently change the arithmetic
     raise _lib.ObjganHipError("OBJGAN_CONV_MATH=%r: must be one of %s"
                               % (_os.environ["OBJGAN_CONV_MATH"], sorted(_MATH_IDS)))
-_MATH = {"mode": _MATH_IDS[_os.environ.get("OBJGAN_CONV_MATH", "bf16x3")]}
+_MATH = {"mode": _MATH_IDS[_os.environ.get("OBJGAN_CONV_MATH", "fp16x2")]}
 
 
 def set_conv_math(mode):
@@ -78,6 +84,34 @@ def set_conv_math(mode):
 
 def get_conv_math():
     return [k for k, v in _MATH_IDS.items() if v == _MATH["mode"]][0]
+
+
+_H2_MIN_FLOP = 1.0e9        # fp16x2: launches below this keep bf16x3 (the maximum pass would cost more than it saves)
+
+
+def _call_math(flop):
+    """arithmetic id of ONE matrix-kernel call under the current mode"""
+    m = _MATH["mode"]
+    if m == 4 and flop < _H2_MIN_FLOP:
+        return 2
+    return m
+
+
+def _absmax(t):
+    """the 256 per-workgroup maxima of |t| (fp16x2's scale input): one pass over t, no host sync.  Cached on the tensor
+    object for the duration of its life (a forward activation is the pixel operand of its convolution AND, in the
+    backward pass, the column operand of that layer's weight gradient)."""
+    got = getattr(t, "_og_absmax", None)
+    if got is not None and got[0] == t._version:
+        return got[1]
+    out = torch.empty(256, dtype=_F32, device=t.device)
+    src = t if (t.is_contiguous() and not (t.data_ptr() & 15)) else t.contiguous().clone()
+    _lib.call("objgan_absmax_partials", _p(src), src.numel(), _p(out), _stream())
+    try:
+        t._og_absmax = (t._version, out)
+    except (AttributeError, RuntimeError):
+        pass
+    return out
 
 
 
@@ -109,11 +143,11 @@ def invalidate_packed():
     _ARENA_BANKS.clear()
 
 
-def _pack_key(w, transpose, src_tap, big):
+def _pack_key(w, transpose, src_tap, big, math=None):
     ep = getattr(w, "_og_epoch", None)
     if (ep is None and w.requires_grad) or getattr(w, "_og_nocache", False):
         return None
-    return (w.data_ptr(), tuple(w.shape), int(transpose), tuple(src_tap), big, _MATH["mode"])
+    return (w.data_ptr(), tuple(w.shape), int(transpose), tuple(src_tap), big, _MATH["mode"] if math is None else math)
 
 
 def _epoch_of(w):
@@ -190,9 +224,14 @@ def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, tran
            dh, dw, src_tap, PH, PW, stride, OHf, OWf, osh, osw, ooh, oow, act, y_prezeroed=0, ring=None, cache=True):
     Tg = len(dh)
     M = Cin if transpose else Cout
+    math = _call_math(2.0 * M * C * Tg * N * PH * PW)
     # the library picks the kernel -- hence the bank layout -- from sizes, taps and math: ask it
-    layout = _lib.load().objgan_conv_bank_layout(N, C, H, W, M, Tg, PH, PW, act, _MATH["mode"])
-    key = _pack_key(w, transpose, src_tap, layout) if cache else None      # (temporaries: pack per call, keep nothing)
+    layout = _lib.load().objgan_conv_bank_layout(N, C, H, W, M, Tg, PH, PW, act, math)
+    if math == 4 and (layout & 255) != 5:
+        math = 2                              # thin / first-generation kernels: no fp16x2 form
+        layout = _lib.load().objgan_conv_bank_layout(N, C, H, W, M, Tg, PH, PW, act, math)
+    xmax = _absmax(x) if math == 4 else None
+    key = _pack_key(w, transpose, src_tap, layout, math) if cache else None      # (temporaries: pack per call, keep nothing)
     nfl = _lib.load().objgan_conv_packed_floats(int(M), int(C), int(Tg))
     if key is not None:
         ent, fresh = _bank_lookup(key, w, nfl, x.device)
@@ -200,7 +239,7 @@ def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, tran
         if ent.jobs is None:
             job = _job_blob()
             _lib.call("objgan_conv_pack_job", job, _p(w), _p(wt), N, C, H, W, Cout, Cin, Torig, int(transpose),
-                      Tg, _iarr(src_tap), PH, PW, act, _MATH["mode"])
+                      Tg, _iarr(src_tap), PH, PW, act, math)
             ent.jobs = [job.raw]
         _bank_mark(ent)
     else:
@@ -208,14 +247,14 @@ def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, tran
     # split-K launches (small grids, long reductions) go through a workspace: partial tiles, then an ordered sum
     nws = _lib.load().objgan_conv_igemm_ws_floats(N, C, H, W, int(upsample), int(pad_mode), Cout, Cin, Torig,
                                                    int(transpose), Tg, PH, PW, stride, OHf, OWf, osh, osw, act,
-                                                   int(y_prezeroed), _MATH["mode"], 0 if ring is None else 1)
+                                                   int(y_prezeroed), math, 0 if ring is None else 1)
     ws = torch.empty(nws, dtype=_F32, device=x.device) if nws > 0 else None
-    if not _BF16_CHANNELS_LAST and _MATH["mode"] == 1 and nws == _nhwc_floats(N, C, H, W):
+    if not _BF16_CHANNELS_LAST and math == 1 and nws == _nhwc_floats(N, C, H, W):
         ws, nws = None, 0                 # (tests) no workspace: the library gathers from the fp32 NCHW source instead
     _lib.call("objgan_conv_igemm", _p(x), _p(w), _p(bias), _p(y), _p(wt),
               N, C, H, W, int(upsample), int(pad_mode), Cout, Cin, Torig, int(transpose),
               Tg, _iarr(dh), _iarr(dw), _iarr(src_tap), PH, PW, stride,
-              OHf, OWf, osh, osw, ooh, oow, act, int(y_prezeroed), packed, _MATH["mode"], _p(ring),
+              OHf, OWf, osh, osw, ooh, oow, act, int(y_prezeroed), packed, math, _p(ring), _p(xmax),
               _p(ws), nws, _stream())
 
 
@@ -240,7 +279,9 @@ def _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad_h, pad_w, LH, LW, cachea
         return None
     dx = torch.empty((N, Cin, LH, LW), dtype=_F32, device=g.device)
     n = 4 * ((Cin * Tg * ((Cout + 15) // 16 * 16) * 3 + 1) // 2)      # bf16x3 banks: 6 bytes per element
-    key = _pack_key(w, 2, st, False) if cacheable else None
+    math = _call_math(2.0 * Cin * Cout * Tg * N * LH * LW)
+    xmax = _absmax(g) if math == 4 else None
+    key = _pack_key(w, 2, st, False, math) if cacheable else None
     if key is not None:
         ent, fresh = _bank_lookup(key, w, n, g.device)
         wt, packed = ent.wt, int(fresh)
@@ -249,16 +290,16 @@ def _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad_h, pad_w, LH, LW, cachea
             for ph in range(4):
                 job = _job_blob()
                 _lib.call("objgan_conv_pack_job_phase", job, _p(w), _p(wt), Cout, Cin, KH * KW, Tg,
-                          _iarr(st[ph * Tg:(ph + 1) * Tg]), ph, _MATH["mode"])
+                          _iarr(st[ph * Tg:(ph + 1) * Tg]), ph, math)
                 ent.jobs.append(job.raw)
         _bank_mark(ent)
     else:
         wt, packed = torch.empty(n, dtype=_F32, device=g.device), 0
-    nws = _lib.load().objgan_conv_dgrad_s2_phases_ws_floats(N, Cout, OH, OW, _MATH["mode"])
+    nws = _lib.load().objgan_conv_dgrad_s2_phases_ws_floats(N, Cout, OH, OW, math)
     ws = torch.empty(nws, dtype=_F32, device=g.device) if nws > 0 and _BF16_CHANNELS_LAST else None
     nws = nws if ws is not None else 0
     _lib.call("objgan_conv_dgrad_s2_phases", _p(g), _p(w), _p(dx), _p(wt), N, Cout, OH, OW, Cin, KH * KW,
-              Tg, _iarr(dh), _iarr(dw), _iarr(st), LH // 2, LW // 2, packed, _MATH["mode"], _p(ws), nws, _stream())
+              Tg, _iarr(dh), _iarr(dw), _iarr(st), LH // 2, LW // 2, packed, math, _p(xmax), _p(ws), nws, _stream())
     return dx
 
 
@@ -293,7 +334,7 @@ def _conv_dgrad(g, w, N, Cin, H, W, stride, pad, refl, upsample, cacheable=True)
         dw = [pe - kw for kh in range(k) for kw in range(k)]
         st = list(range(k * k))
         ring_ok = (refl and pad == 1 and LH >= 3 and LW >= 3 and
-                   (_lib.load().objgan_conv_bank_layout(N, Cout, OH, OW, Cin, k * k, TH, TW, 0, _MATH["mode"]) & 255) in (1, 3, 4))
+                   (_lib.load().objgan_conv_bank_layout(N, Cout, OH, OW, Cin, k * k, TH, TW, 0, _MATH["mode"]) & 255) in (1, 3, 4, 5))
         if ring_ok:
             # gradient of the reflect-padded conv without the padded intermediate: interior pixels go straight
             # into dX, the one-pixel border into a small ring buffer that is mirrored back afterwards
@@ -351,10 +392,13 @@ def _conv_wgrad(x, g, Cout, k, stride, pad, refl, upsample, sink=None):
         dw_ = sink[0]
     else:
         dw_ = torch.empty((Cout, Cin, k, k), dtype=_F32, device=x.device)      # fully written: no zero-fill
-    geo = (N, Cin, H, W, int(upsample), refl, Cout, g.shape[2], g.shape[3], k, stride, pad, _MATH["mode"])
+    math = _call_math(2.0 * Cout * Cin * k * k * N * g.shape[2] * g.shape[3])
+    geo = (N, Cin, H, W, int(upsample), refl, Cout, g.shape[2], g.shape[3], k, stride, pad, math)
     nws = _lib.load().objgan_conv_wgrad_ws_floats(*geo)
     ws = torch.empty(nws, dtype=_F32, device=x.device) if nws > 0 else None
-    _lib.call("objgan_conv_wgrad", _p(x), _p(g), _p(dw_), *geo, 0 if sink is None else 1, _p(ws), nws, _stream())
+    xmax, gmax = (_absmax(x), _absmax(g)) if math == 4 else (None, None)
+    _lib.call("objgan_conv_wgrad", _p(x), _p(g), _p(dw_), *geo, 0 if sink is None else 1, _p(xmax), _p(gmax), _p(ws), nws,
+              _stream())
     if sink is not None:
         sink[1]()
         return None

@@ -330,7 +330,7 @@ def test_bench_main_end_to_end_on_the_cpu_shim(monkeypatch, capsys):
             return 1
 
         def objgan_prof_collect(self, ms, fl, cnt):      # two recorded launches of one kernel instance
-            i = bench.cat_names("bf16x3").index("conv_igemm3_kernel<6, false, 2, 4>")
+            i = bench.cat_names("fp16x2").index("conv_igemm3_kernel<6, false, 4, 4>")
             ms[i], fl[i], cnt[i] = 2.0, 2.0e11, 2
             return 1
     fake = FakeLib()
@@ -360,8 +360,8 @@ def test_bench_main_end_to_end_on_the_cpu_shim(monkeypatch, capsys):
     assert res["n_gpus"] == 1 and res["steps"] == 1 and res["unit"] == "images/sec" and res["value"] > 0
     assert res["metric"].endswith("at 64x64, batch 2 per GPU") and res["config"]["workload"].startswith("stage1_64x64")
     roof = res["roofline"]
-    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["kernel"] == "conv_igemm3_kernel<6, false, 2, 4>"
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["kernel"] == "conv_igemm3_kernel<6, false, 4, 4>"
     assert abs(roof["achieved"] - 100.0) < 1e-6 and abs(roof["frac"] - 100.0 / roof["peak"]) < 1e-3
     assert roof["traffic"] is None or roof["traffic"] > 1e8             # committed PMC record of that kernel
     assert res["conv_total"]["tflops"] == roof["achieved"] and res["kernel_breakdown"][0]["launches_per_step"] == 2.0
-    assert "cpu_baseline" not in res and "side_configs" not in res and res["dtype"].startswith("fp32 (bf16x3")
+    assert "cpu_baseline" not in res and "side_configs" not in res and res["dtype"].startswith("fp32 (fp16x2")

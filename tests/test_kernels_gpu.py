@@ -61,15 +61,19 @@ CONV_CASES = [
 ]
 
 
-@pytest.fixture(params=["fp32", "bf16x3"])
+@pytest.fixture(params=["fp32", "bf16x3", "fp16x2"])
 def fp32_math(request):
-    """The two arithmetic modes that deliver fp32 results: fp32 operands on the fp32 MFMA, and fp32 operands split
-    exactly three ways on the bf16 MFMA (six partial products, fp32 accumulation).  Same tolerance for both."""
+    """The three arithmetic modes that deliver fp32 results: fp32 operands on the fp32 MFMA; fp32 operands split exactly
+    three ways on the bf16 MFMA (six partial products); fp32 operands as two fp16 pieces of x * 2^s on the fp16 MFMA
+    (three partial products) -- fp32 accumulation in all.  Same tolerance for all three.  (fp16x2 is taken by launches
+    above a FLOP threshold in production; the tests lower it to zero so that the small cases run its kernels too.)"""
     ops = _ops()
-    prev = ops.get_conv_math()
+    prev, prev_min = ops.get_conv_math(), ops._H2_MIN_FLOP
     ops.set_conv_math(request.param)
+    ops._H2_MIN_FLOP = 0.0
     yield request.param
     ops.set_conv_math(prev)
+    ops._H2_MIN_FLOP = prev_min
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
@@ -870,8 +874,9 @@ def test_bf16x3_math_is_as_accurate_as_the_fp32_mfma(dev, case):
     gy = torch.randn(yt.shape, generator=g)
     yt.backward(gy.double())
     errs = {}
-    prev = ops.get_conv_math()
-    for math in ("fp32", "bf16x3"):
+    prev, prev_min = ops.get_conv_math(), ops._H2_MIN_FLOP
+    ops._H2_MIN_FLOP = 0.0
+    for math in ("fp32", "bf16x3", "fp16x2"):
         ops.set_conv_math(math)
         try:
             xd, wd = x.to(dev).requires_grad_(), w.to(dev).requires_grad_()
@@ -881,11 +886,48 @@ def test_bf16x3_math_is_as_accurate_as_the_fp32_mfma(dev, case):
         finally:
             ops.set_conv_math(prev)
         errs[math] = (rel_l2(yd, yt), rel_l2(xd.grad, xt.grad), rel_l2(wd.grad, wt.grad))
-    note("bf16x3 vs fp32 MFMA, error against fp64 (fwd, dgrad, wgrad) %s" % (case,),
-         "fp32 %.3e %.3e %.3e | bf16x3 %.3e %.3e %.3e" % (errs["fp32"] + errs["bf16x3"]))
-    for e32, ex3, what in zip(errs["fp32"], errs["bf16x3"], ("fwd", "dgrad", "wgrad")):
+    ops._H2_MIN_FLOP = prev_min
+    note("split arithmetics vs fp32 MFMA, error against fp64 (fwd, dgrad, wgrad) %s" % (case,),
+         "fp32 %.3e %.3e %.3e | bf16x3 %.3e %.3e %.3e | fp16x2 %.3e %.3e %.3e" % (errs["fp32"] + errs["bf16x3"] + errs["fp16x2"]))
+    for e32, ex3, eh2, what in zip(errs["fp32"], errs["bf16x3"], errs["fp16x2"], ("fwd", "dgrad", "wgrad")):
         assert e32 < 2e-6, (what, e32)
         assert ex3 <= 1.25 * e32 + 2e-8, (what, "fp32", e32, "bf16x3", ex3)
+        # fp16x2: |x * 2^s - h - l| <= 2^-24 |x| per operand and the dropped l x l term below 2^-24 of a product, the
+        # MFMA adds 16 products before it rounds and there are three accumulations per K step instead of eight
+        assert eh2 <= 1.25 * e32 + 2e-8, (what, "fp32", e32, "fp16x2", eh2)
+
+
+@pytest.mark.parametrize("xscale,gscale,wscale", [(1.0, 1.0, 1.0), (3e-7, 1e-9, 1.0), (4e4, 2e6, 1.0), (1.0, 1e-6, 40.0),
+                                                   (1.0, 1.0, 1e-4)])
+def test_fp16x2_keeps_fp32_accuracy_over_the_dynamic_range(dev, xscale, gscale, wscale):
+    """fp16x2 scales every activation / gradient tensor by a power of two taken from its own maximum (the kernels read
+    the 256 per-workgroup maxima of objgan_absmax_partials) and the filter bank by 2^10: tensors at 3e-7 or 4e4,
+    gradients at 1e-9 or 2e6, filters up to +-40 or down at 1e-4, and inputs whose elements span five decades, all stay
+    within fp32 rounding of an fp64 evaluation -- forward, data gradient and weight gradient."""
+    ops = _ops()
+    N, Cin, H, W, Cout, k, s, p = 4, 96, 32, 32, 192, 4, 2, 1
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, Cin, H, W, generator=g) * xscale
+    x[:, ::3] *= 1e-5                                      # a third of the channels five decades below the rest
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5 * wscale
+    xt, wt = x.double().requires_grad_(), w.double().requires_grad_()
+    yt = torch.nn.functional.conv2d(xt, wt, None, s, p)
+    gy = torch.randn(yt.shape, generator=g) * gscale
+    gy[:, 1::2] *= 1e-4
+    yt.backward(gy.double())
+    prev, prev_min = ops.get_conv_math(), ops._H2_MIN_FLOP
+    ops.set_conv_math("fp16x2")
+    ops._H2_MIN_FLOP = 0.0
+    try:
+        xd, wd = x.to(dev).requires_grad_(), w.to(dev).requires_grad_()
+        yd = ops.conv2d(xd, wd, None, s, p, "zeros", False, None)
+        yd.backward(gy.to(dev))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_conv_math(prev)
+        ops._H2_MIN_FLOP = prev_min
+    e = (rel_l2(yd, yt), rel_l2(xd.grad, xt.grad), rel_l2(wd.grad, wt.grad))
+    assert max(e) < 1.5e-6, e
 
 
 @pytest.mark.parametrize("need", [(True, True), (True, False), (False, True)])
@@ -945,22 +987,24 @@ def test_conv_reductions_are_bit_reproducible(dev, fp32_math):
         OH, OW = yr.shape[2], yr.shape[3]
         xd, gy = x.to(dev), torch.ones_like(yr).to(dev)
         gact = torch.where(yr > 0, torch.ones_like(yr), torch.full_like(yr, 0.2)).to(dev).contiguous()
+        P_ = lambda t: ctypes.c_void_p(t.data_ptr())      # noqa: E731
         geo = (N, Cin, H, W, 0, 0, Cout, OH, OW, k, s, p, ops._MATH["mode"])
+        mx = (P_(ops._absmax(xd)), P_(ops._absmax(gact))) if ops._MATH["mode"] == 4 else (None, None)
         nws = _lib.load().objgan_conv_wgrad_ws_floats(*geo)
         ws = torch.full((max(nws, 1),), float("nan"), device=dev)
         dw = torch.full((Cout, Cin, k, k), float("nan"), device=dev)
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         P = lambda t: ctypes.c_void_p(t.data_ptr())       # noqa: E731
-        _lib.call("objgan_conv_wgrad", P(xd), P(gact), P(dw), *geo, 0, P(ws), nws, st)
+        _lib.call("objgan_conv_wgrad", P(xd), P(gact), P(dw), *geo, 0, mx[0], mx[1], P(ws), nws, st)
         assert torch.equal(dw, runs[0][2])
         base = torch.randn(Cout, Cin, k, k, generator=g).to(dev)
         dw2 = base.clone()
-        _lib.call("objgan_conv_wgrad", P(xd), P(gact), P(dw2), *geo, 1, P(ws), nws, st)
+        _lib.call("objgan_conv_wgrad", P(xd), P(gact), P(dw2), *geo, 1, mx[0], mx[1], P(ws), nws, st)
         torch.cuda.synchronize()
         assert rel_l2(dw2 - base, runs[0][2]) < 1e-5
         if nws > 0:                 # a call that needs the workspace and does not get it is refused
             with pytest.raises(_lib.ObjganHipError):
-                _lib.call("objgan_conv_wgrad", P(xd), P(gact), P(dw2), *geo, 0, None, 0, st)
+                _lib.call("objgan_conv_wgrad", P(xd), P(gact), P(dw2), *geo, 0, mx[0], mx[1], None, 0, st)
 
 
 def test_conv_never_consumes_memory_past_the_input_tensor(dev):

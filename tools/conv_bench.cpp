@@ -3,7 +3,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 tools/conv_bench.cpp -Iinclude -L obj-gan_amd/objgan_hip -lobjgan_hip \
 //         -Wl,-rpath,'$ORIGIN/../obj-gan_amd/objgan_hip' -o tools/conv_bench
-//   tools/conv_bench [filter] [iters] [math: 0 fp32 | 1 bf16 inputs | 2 bf16x3]
+//   tools/conv_bench [filter] [iters] [math: 0 fp32 | 1 bf16 inputs | 2 bf16x3 | 4 fp16x2]
 //
 // For every shape: forward, data gradient and weight gradient are timed with hipEvents and
 // reported as algorithmic TFLOP/s (2*N*OH*OW*Cout*Cin*k*k); a sample of output elements is
@@ -80,6 +80,8 @@ int main(int argc, char** argv) {
         float* wsb;
         const long nwsb = 96L << 20;      // 384 MB of floats
         CK(hipMalloc(&wsb, nwsb * 4));
+        float* mxx; float* mxg;          // math 4 (fp16x2): per-workgroup maxima of x and of dy (objgan_absmax_partials)
+        CK(hipMalloc(&mxx, 256 * 4)); CK(hipMalloc(&mxg, 256 * 4));
         CK(hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(dw, hw.data(), nw * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(dg, hg.data(), ny * 4, hipMemcpyHostToDevice));
@@ -90,17 +92,19 @@ int main(int argc, char** argv) {
             dh[kh * sh.k + kw] = kh - sh.p; dwv[kh * sh.k + kw] = kw - sh.p; stp[kh * sh.k + kw] = kh * sh.k + kw;
         }
         auto fwd = [&]() {
+            if (g_math == 4) objgan_absmax_partials(dx, (long)nx, mxx, st);       // (the weight gradient reuses it)
             int rc = objgan_conv_igemm(dx, dw, nullptr, dy, wt, sh.N, sh.Cin, sh.H, sh.W, sh.up, sh.refl, sh.Cout, sh.Cin, T, 0,
-                                       T, dh.data(), dwv.data(), stp.data(), OH, OW, sh.s, OH, OW, 1, 1, 0, 0, 0, 0, 0, g_math, nullptr, wsb, nwsb, st);
+                                       T, dh.data(), dwv.data(), stp.data(), OH, OW, sh.s, OH, OW, 1, 1, 0, 0, 0, 0, 0, g_math, nullptr, mxx, wsb, nwsb, st);
             if (rc != 1) { fprintf(stderr, "fwd rc=%d\n", rc); exit(1); }
         };
         auto dgrad = [&]() {
+            if (g_math == 4) objgan_absmax_partials(dg, (long)ny, mxg, st);       // (shared with the weight gradient)
             if (sh.s == 1) {
                 const int pe = sh.refl ? 0 : sh.p;
                 std::vector<int> h2(T), w2(T);
                 for (int kh = 0; kh < sh.k; ++kh) for (int kw = 0; kw < sh.k; ++kw) { h2[kh * sh.k + kw] = pe - kh; w2[kh * sh.k + kw] = pe - kw; }
                 int rc = objgan_conv_igemm(dg, dw, nullptr, dgx, wt, sh.N, sh.Cout, OH, OW, 0, 0, sh.Cout, sh.Cin, T, 1,
-                                           T, h2.data(), w2.data(), stp.data(), TH, TW, 1, TH, TW, 1, 1, 0, 0, 0, 0, 0, g_math, nullptr, wsb, nwsb, st);
+                                           T, h2.data(), w2.data(), stp.data(), TH, TW, 1, TH, TW, 1, 1, 0, 0, 0, 0, 0, g_math, nullptr, mxg, wsb, nwsb, st);
                 if (rc != 1) { fprintf(stderr, "dgrad rc=%d\n", rc); exit(1); }
             } else if (sh.k % 2 == 0 && LH % 2 == 0 && sh.Cin > 32) {
                 std::vector<int> h2, w2, s2;
@@ -110,7 +114,7 @@ int main(int argc, char** argv) {
                             h2.push_back((ph + sh.p - kh) / 2); w2.push_back((pw + sh.p - kw) / 2); s2.push_back(kh * sh.k + kw);
                         }
                 int rc = objgan_conv_dgrad_s2_phases(dg, dw, dgx, wt, sh.N, sh.Cout, OH, OW, sh.Cin, T, (int)h2.size() / 4,
-                                                     h2.data(), w2.data(), s2.data(), LH / 2, LW / 2, 0, g_math, wsb, nwsb, st);
+                                                     h2.data(), w2.data(), s2.data(), LH / 2, LW / 2, 0, g_math, mxg, wsb, nwsb, st);
                 if (rc != 1) { fprintf(stderr, "dgrad phases rc=%d\n", rc); exit(1); }
             } else {
                 CK(hipMemsetAsync(dgx, 0, ngx * 4, st));
@@ -122,14 +126,14 @@ int main(int argc, char** argv) {
                         }
                     const int PHg = (LH - ph + 1) / 2, PWg = (LW - pw + 1) / 2;
                     int rc = objgan_conv_igemm(dg, dw, nullptr, dgx, wt, sh.N, sh.Cout, OH, OW, 0, 0, sh.Cout, sh.Cin, T, 1,
-                                               (int)h2.size(), h2.data(), w2.data(), s2.data(), PHg, PWg, 1, LH, LW, 2, 2, ph, pw, 0, 1, 0, g_math, nullptr, wsb, nwsb, st);
+                                               (int)h2.size(), h2.data(), w2.data(), s2.data(), PHg, PWg, 1, LH, LW, 2, 2, ph, pw, 0, 1, 0, g_math, nullptr, mxg, wsb, nwsb, st);
                     if (rc != 1) { fprintf(stderr, "dgrad2 rc=%d\n", rc); exit(1); }
                 }
             }
         };
         auto wgrad = [&]() {
             int rc = objgan_conv_wgrad(dx, dg, dgw, sh.N, sh.Cin, sh.H, sh.W, sh.up, sh.refl, sh.Cout, OH, OW, sh.k, sh.s, sh.p, g_math,
-                                       0, wsb, nwsb, st);
+                                       0, mxx, mxg, wsb, nwsb, st);
             if (rc != 1) { fprintf(stderr, "wgrad rc=%d\n", rc); exit(1); }
         };
         auto timeit = [&](auto&& fn) {
@@ -215,7 +219,7 @@ int main(int argc, char** argv) {
                maxerr_f / (maxref_f + 1e-30), maxerr_d / (maxref_d + 1e-30), maxerr_w / (maxref_w + 1e-30),
                sqrt(se_f / (sr_f + 1e-300)), sqrt(se_d / (sr_d + 1e-300)), sqrt(se_w / (sr_w + 1e-300)));
         fflush(stdout);
-        hipFree(dx); hipFree(dw); hipFree(dy); hipFree(dg); hipFree(dgx); hipFree(dgw); hipFree(wt); hipFree(wsb);
+        hipFree(dx); hipFree(dw); hipFree(dy); hipFree(dg); hipFree(dgx); hipFree(dgw); hipFree(wt); hipFree(wsb); hipFree(mxx); hipFree(mxg);
     }
     return 0;
 }
