@@ -114,12 +114,13 @@ long objgan_conv_igemm_ws_floats(int N, int C, int H, int W, int upsample, int p
  * GEMM runs over the padded pixel grid (PH = OHf + 2, PW = OWf + 2, y is the UNPADDED gradient), interior
  * pixels are stored into y, the one-pixel border into ring [N*M][2*PW + 2*PH]; objgan_reflect_ring_fold then
  * adds the border back at its mirror positions.  Only for calls whose objgan_conv_bank_layout class (low byte) is
- * 1, 3 or 4. */
+ * 1, 3, 4 or 5. */
 int objgan_reflect_ring_fold(const float* ring, float* y, long planes, int H, int W, void* stream);
 /* Data gradient of a stride-2 convolution whose four output parity phases have the same number
  * of taps (k=4, pad 1, even sizes): one launch for all phases.  x = dY [N,Cout,OH,OW],
  * y = dX [N,Cin,2*PH,2*PW], fully written (no pre-zeroing).  dh/dw/src_tap: 4 x Tg entries, phase
- * p = (row parity << 1) | column parity.  wt: 4*ceil(1.5*Cin*Tg*ceil16(Cout)) floats; wt_packed as above.
+ * p = (row parity << 1) | column parity.  wt: 4*ceil(1.5*Cin*Tg*ceil16(Cout)) + 256 floats (four phase banks,
+ * then the partial maxima of |w| the fp16x2 pack leaves for its scale); wt_packed as above.
  * ws: objgan_conv_dgrad_s2_phases_ws_floats floats (math 1: the bf16 channel-blocked copy of dY, see objgan_conv_igemm; else 0). */
 long objgan_conv_dgrad_s2_phases_ws_floats(int N, int Cout, int OH, int OW, int math);
 int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float* wt,

@@ -35,6 +35,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+extern "C" long objgan_conv_packed_floats(int M, int C, int T);
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -57,6 +59,7 @@ struct IgemmArgs {
     int LH, LW;          // logical source dims seen by the taps (2H x 2W when upsampling)
     int M, Mpad, K, Kpad;   // K = T*C (algorithmic), Kpad = T*Cp (padded, what the loop walks)
     const float* xmax;      // math 4: the 256 per-workgroup maxima of |x| (objgan_absmax_partials)
+    const float* wmax;      // math 4: the 256 partial maxima of |w| behind the bank (absmax_w_*)
     int math;               // 0: fp32 MFMA, 1: bf16 inputs (RNE) on the bf16 MFMA, fp32 accumulation; 2: bf16x3; 4: fp16x2
     int nhwc;               // bf16 mode: 1 = the pixel operand comes from a bf16 [N][Cp/16][H][W][16] copy of x that
                             // run_igemm2 makes in the caller's workspace (conv_igemm3_kernel<.., 3, ..>)
@@ -163,14 +166,14 @@ __device__ __forceinline__ void og_split4(const f32x4 v, bf16x4& h, bf16x4& m, b
 // ---- fp32 on the fp16 matrix pipe ("fp16x2", math 4) --------------------------------------------------------------
 // v_mfma_f32_32x32x16_f16 runs at the rate of the bf16 MFMA, and fp16 carries 11 significand bits: TWO pieces
 // x * 2^s = h + l (round-to-nearest at each cut) leave |residual| <= 2^-24 |x| -- half an fp32 ulp -- as long as l stays
-// a normal fp16, which a power-of-two scale 2^s per operand tensor arranges (filter banks: the constant 2^10, |w| < 64;
-// activations / gradients: max |x| * 2^s in [2^14, 2^15), from the per-workgroup maxima of objgan_absmax_partials; an
+// a normal fp16, which a power-of-two scale 2^s per operand tensor arranges (max |x| * 2^s in [2^14, 2^15): activations
+// and gradients from the per-workgroup maxima of objgan_absmax_partials, filter banks from the partial maxima the pack
+// path leaves behind the bank; an
 // element below 2^-10 of its tensor's maximum keeps an ABSOLUTE error of 2^-39 of that maximum instead).  Three
 // products hh, hl, lh (ll is below 2^-24 of a product) are three MFMAs per 16-deep K step and row group instead of
 // the six of bf16x3; the scales are undone exactly in the epilogue.  Measured against fp64 the error is BELOW
 // bf16x3's (the MFMA adds 16 products before it rounds, and there are half as many accumulations): loop laboratory
 // K = 3072: 6.1e-7 vs 8.7e-7, at 295-302 vs 190-193 TFLOP/s (profiles/r04_loop_lab.txt).
-#define OG_H2_WEXP 10
 #define OG_MFMA_H(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
 // scale exponent s of a tensor from its 256 per-workgroup maxima: max * 2^s in [2^14, 2^15)  (0 for an all-zero tensor)
 __device__ __forceinline__ int og_h2_exponent(const float* __restrict__ pm, int lane) {
@@ -611,7 +614,9 @@ struct PackArgs {
                          // 4: bf16x3 split wt[M][Kpad/16][3][16]: every fp32 entry as its exact three-way bf16
                          //    split h + m + l (og_split8), the three pieces of a 16-deep K step back to back
                          // 5: fp16x2 split wt[M][Kpad/16][2][16] fp16: w * 2^10 = h + l
-    int kgroup;          // row-major banks (m_major 1 / 3 / 4): chunks per K group (see og_kstep)
+    int kgroup;          // row-major banks (m_major 1 / 3 / 4 / 5): chunks per K group (see og_kstep)
+    const float* wmax;   // m_major 5: the 256 partial maxima of |w| (behind the bank, written by absmax_w_* before the pack)
+    int wexp;            // m_major 5: scale exponent derived from them (set inside the pack kernels)
     signed char src_tap[OG_MAX_TAPS];
 };
 
@@ -672,9 +677,9 @@ __device__ __forceinline__ void pack_store(const PackArgs& a, size_t row, int k,
         const float r1 = v - (float)h;
         const __bf16 m = (__bf16)r1;
         o[0] = h; o[16] = m; o[32] = (__bf16)(r1 - (float)m);
-    } else if (a.m_major == 5) {         // fp16x2: w * 2^10 = h + l, saturating beyond |w| = 63.9
+    } else if (a.m_major == 5) {         // fp16x2: w * 2^wexp = h + l (max |w| * 2^wexp in [2^14, 2^15))
         _Float16* o = reinterpret_cast<_Float16*>(a.wt) + row + (size_t)(k >> 4) * 32 + (k & 15);
-        const float sv = fminf(fmaxf(v * (float)(1 << OG_H2_WEXP), -65504.f), 65504.f);
+        const float sv = v * og_pow2(a.wexp);
         const _Float16 h = (_Float16)sv;
         o[0] = h; o[16] = (_Float16)(sv - (float)h);
     } else if (a.m_major == 3) {
@@ -757,7 +762,25 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_bf16_kernel(const float* __r
     }
 }
 
-__global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
+// Partial maxima of |w| for the fp16x2 banks: out[0..63] by 64 workgroups, out[64..255] = 0 (the kernels reduce 256 values).
+__device__ __forceinline__ void absmax_w_block(const float* __restrict__ w, long n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += 64L * 256) m = fmaxf(m, fabsf(w[i]));
+    m = og_wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        out[blockIdx.x + 64] = 0.f; out[blockIdx.x + 128] = 0.f; out[blockIdx.x + 192] = 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void absmax_w_kernel(const float* __restrict__ w, long n, float* __restrict__ out) {
+    absmax_w_block(w, n, out);
+}
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a_in) {
+    PackArgs a = a_in;
+    if (a.m_major == 5) a.wexp = og_h2_exponent(a.wmax, threadIdx.x & 63);
     const int Kpad = a.Tg * a.Cp;
     const int Krow = a.m_major == 3 ? (Kpad + 31) / 32 * 32 : (a.m_major == 4 ? 3 * Kpad : (a.m_major == 5 ? 2 * Kpad : Kpad));
     const long total = pack_total(a, Kpad, Krow);
@@ -773,8 +796,15 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
 // sweep and workgroups beyond a small bank's end leave at once.
 #define OG_PACK_BLOCKS 256
 #define OG_PACK_CHUNK 512
-__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackArgs* __restrict__ jobs) {
+__global__ __launch_bounds__(256) void absmax_w_jobs_kernel(const PackArgs* __restrict__ jobs) {
     const PackArgs a = jobs[blockIdx.y];
+    if (a.m_major != 5) return;
+    absmax_w_block(a.w, (long)a.Cout * a.Cin * a.Torig, const_cast<float*>(a.wmax));
+}
+
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackArgs* __restrict__ jobs) {
+    PackArgs a = jobs[blockIdx.y];
+    if (a.m_major == 5) a.wexp = og_h2_exponent(a.wmax, threadIdx.x & 63);
     const int Kpad = a.Tg * a.Cp;
     const int Krow = a.m_major == 3 ? (Kpad + 31) / 32 * 32 : (a.m_major == 4 ? 3 * Kpad : (a.m_major == 5 ? 2 * Kpad : Kpad));
     const long total = pack_total(a, Kpad, Krow);
@@ -1521,7 +1551,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
     if (H2) {
         const int sx = og_h2_exponent(a.xmax, lane);
         h2_xs = og_pow2(sx);
-        h2_inv = og_pow2(-sx - OG_H2_WEXP);
+        h2_inv = og_pow2(-sx - og_h2_exponent(a.wmax, lane));
     }
     f32x16 acc[TM];
 #pragma unroll
@@ -3078,11 +3108,16 @@ static int og_fill_pack(PackArgs& p, const float* w, float* wt, int N, int C, in
     int MT = 32;
     p.m_major = og_bank_layout(N, C, H, W, M, Tg, PH, PW, act, math, &MT);
     p.kgroup = og_kgroup(C, Tg, H, PH);
+    p.wmax = wt ? wt + objgan_conv_packed_floats(M, C, Tg) - 256 : nullptr; p.wexp = 0;
     if (p.m_major == 2) p.Mpad = MT;
     for (int t = 0; t < OG_MAX_TAPS; ++t) p.src_tap[t] = (signed char)(t < Tg ? src_tap[t] : -1);
     if (MT_out) *MT_out = MT;
     return p.m_major;
 }
+
+// the four phase banks of objgan_conv_dgrad_s2_phases share one buffer of 4 * ceil(1.5 * M * Tg * Cp) + 256 floats: the
+// partial maxima of |w| sit behind the largest (bf16x3) bank size, whatever the arithmetic
+static inline long og_phase_wmax_offset(int M, int Tg, int Cp) { return 4 * (((long)M * Tg * Cp * 3 + 1) / 2); }
 
 static void og_fill_pack_phase(PackArgs& p, const float* w, float* wt, int Cout, int Cin, int Torig, int Tg,
                                const int* src_tap_phase, int phase, int math) {
@@ -3095,6 +3130,7 @@ static void og_fill_pack_phase(PackArgs& p, const float* w, float* wt, int Cout,
     p.M = M; p.Mpad = (M + 127) / 128 * 128; p.Ck = C; p.Cp = Cp;
     p.transpose = 1; p.m_major = math == 1 ? 3 : (math == 2 ? 4 : (math == 4 ? 5 : 1));
     p.kgroup = og_kgroup_phases(C);
+    p.wmax = wt + og_phase_wmax_offset(M, Tg, Cp); p.wexp = 0;
     for (int t = 0; t < OG_MAX_TAPS; ++t) p.src_tap[t] = (signed char)(t < Tg ? src_tap_phase[t] : -1);
 }
 
@@ -3160,6 +3196,8 @@ int objgan_conv_pack_jobs_run(const void* jobs_dev, int njobs, void* stream) {
     OG_ENTRY();
     if (njobs <= 0) return OG_OK;
     if (!jobs_dev || njobs > 65535) return OG_BAD_ARGS;
+    // (fp16x2 jobs first leave the partial maxima of their weights behind their banks: the scale of the pack)
+    hipLaunchKernelGGL(absmax_w_jobs_kernel, dim3(64, njobs), dim3(256), 0, (hipStream_t)stream, (const PackArgs*)jobs_dev);
     hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(OG_PACK_BLOCKS, njobs), dim3(256), 0, (hipStream_t)stream,
                        (const PackArgs*)jobs_dev);
     return og_launch_status();
@@ -3178,7 +3216,8 @@ int objgan_conv_bank_layout(int N, int C, int H, int W, int M, int Tg, int PH, i
 long objgan_conv_packed_floats(int M, int C, int T) {
     const long Mpad = ((long)M + 127) / 128 * 128;
     const long Cp = ((long)C + 15) / 16 * 16;
-    return (Mpad * Cp * T * 3 + 1) / 2;      // the pre-split bank of the bf16x3 mode takes 6 bytes per element
+    // the pre-split bank of the bf16x3 mode takes 6 bytes per element; + 256 floats: partial maxima of |w| (fp16x2)
+    return (Mpad * Cp * T * 3 + 1) / 2 + 256;
 }
 
 // General entry: see the formula at the top of this file.
@@ -3210,7 +3249,7 @@ static int og_igemm_setup(PackArgs& p, IgemmArgs& a, int& MT, const float* x, co
     a.LH = upsample ? 2 * H : H; a.LW = upsample ? 2 * W : W;
     a.M = M; a.Mpad = p.Mpad; a.K = C * Tg; a.Kpad = Tg * p.Cp; a.T = Tg; a.Cp = p.Cp; a.kgroup = p.kgroup;
     a.math = kmath;
-    a.xmax = xmax;
+    a.xmax = xmax; a.wmax = p.wmax;
     if (kmath == 4 && x && !xmax) return OG_BAD_ARGS;      // fp16x2 needs the maxima of its pixel operand (x == NULL: size query)
     a.nhwc = igemm2_nhwc_floats(kmath, N, H, W, p.Cp) > 0 ? 1 : 0;
     a.Krow = og_krow(a.Kpad, kmath);
@@ -3273,6 +3312,8 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
     hipStream_t s = (hipStream_t)stream;
     const bool v2 = p.m_major != 0, thin = p.m_major == 2;
     if (!wt_packed) {       // wt_packed: the caller kept wt from an earlier call with the same
+        if (p.m_major == 5)
+            hipLaunchKernelGGL(absmax_w_kernel, dim3(64), dim3(256), 0, s, w, (long)Cout * Cin * Torig, const_cast<float*>(p.wmax));
         const long ptotal = (long)Tg * p.Cp * p.Mpad;   // filter bank, taps, math and geometry class
         hipLaunchKernelGGL(pack_weights_kernel, dim3(og_stream_grid(ptotal, 256)), dim3(256), 0, s, p);
         int rc = og_launch_status();
@@ -3286,7 +3327,7 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
 // (k = 4, pad 1, even sizes: 2x2 taps each): ONE launch, the phase is the fastest digit of the workgroup id.  x = dY [N, Cout, OH, OW],
 // y = dX [N, Cin, 2*PH, 2*PW] (every element is written by exactly one phase: no pre-zeroing).
 // dh/dw/src_tap: 4 phases x Tg entries, phase p = (row parity << 1) | column parity.
-// wt: 4 * ceil(1.5 * Cin * Tg * ceil16(Cout)) floats (<= 4 x objgan_conv_packed_floats(Cin, Cout, Tg)).
+// wt: 4 * ceil(1.5 * Cin * Tg * ceil16(Cout)) + 256 floats (the four phase banks, then the partial maxima of |w|).
 int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float* wt,
                                 int N, int Cout, int OH, int OW, int Cin, int Torig,
                                 int Tg, const int* dh, const int* dw, const int* src_tap,
@@ -3306,6 +3347,9 @@ int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float*
     // phase banks are stored back to back: `bank` floats apart (Krow counts bf16 elements in the bf16 modes)
     const long bank = math ? (long)M * Krow / 2 : (long)M * Krow;
     if (!wt_packed) {
+        if (math == 4)
+            hipLaunchKernelGGL(absmax_w_kernel, dim3(64), dim3(256), 0, s, w, (long)Cout * Cin * Torig,
+                               wt + og_phase_wmax_offset(M, Tg, Cp));
         for (int ph = 0; ph < 4; ++ph) {
             PackArgs p;
             og_fill_pack_phase(p, w, wt, Cout, Cin, Torig, Tg, src_tap + ph * Tg, ph, math);
@@ -3319,7 +3363,7 @@ int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float*
     a.N = N; a.C = C; a.H = OH; a.W = OW; a.LH = OH; a.LW = OW;
     a.M = M; a.Mpad = (M + 127) / 128 * 128; a.K = C * Tg; a.Kpad = Kpad; a.T = Tg; a.Cp = Cp;
     a.kgroup = og_kgroup_phases(C);
-    a.math = math; a.Krow = Krow; a.xmax = xmax;
+    a.math = math; a.Krow = Krow; a.xmax = xmax; a.wmax = wt + og_phase_wmax_offset(M, Tg, Cp);
     a.nhwc = igemm2_nhwc_floats(math, N, OH, OW, Cp) > 0 ? 1 : 0;
     a.m_begin = 0; a.m_end = M;
     a.PH = PH; a.PW = PW; a.OHf = 2 * PH; a.OWf = 2 * PW;

@@ -100,19 +100,25 @@ def _call_math(flop):
 def _absmax(t):
     """the 256 per-workgroup maxima of |t| (fp16x2's scale input): one pass over t, no host sync.  Cached on the tensor
     object for the duration of its life (a forward activation is the pixel operand of its convolution AND, in the
-    backward pass, the column operand of that layer's weight gradient)."""
-    got = getattr(t, "_og_absmax", None)
-    if got is not None and got[0] == t._version:
-        return got[1]
+    backward pass, the column operand of that layer's weight gradient) -- per HIP stream: a tensor shared by jobs on
+    different streams (the images every discriminator reads) gets one pass per stream, ordered with that stream's
+    kernels."""
+    sid = torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    cache = getattr(t, "_og_absmax", None)
+    if cache is not None:
+        got = cache.get(sid)
+        if got is not None and got[0] == t._version:
+            return got[1]
     out = torch.empty(256, dtype=_F32, device=t.device)
     src = t if (t.is_contiguous() and not (t.data_ptr() & 15)) else t.contiguous().clone()
     _lib.call("objgan_absmax_partials", _p(src), src.numel(), _p(out), _stream())
     try:
-        t._og_absmax = (t._version, out)
+        if cache is None:
+            cache = t._og_absmax = {}
+        cache[sid] = (t._version, out)
     except (AttributeError, RuntimeError):
         pass
     return out
-
 
 
 # Packed filter banks are kept while their weights are unchanged.  A weight tensor is eligible
@@ -278,7 +284,7 @@ def _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad_h, pad_w, LH, LW, cachea
     if Tg > 8:
         return None
     dx = torch.empty((N, Cin, LH, LW), dtype=_F32, device=g.device)
-    n = 4 * ((Cin * Tg * ((Cout + 15) // 16 * 16) * 3 + 1) // 2)      # bf16x3 banks: 6 bytes per element
+    n = 4 * ((Cin * Tg * ((Cout + 15) // 16 * 16) * 3 + 1) // 2) + 256    # bf16x3 banks: 6 bytes per element; + |w| maxima
     math = _call_math(2.0 * Cin * Cout * Tg * N * LH * LW)
     xmax = _absmax(g) if math == 4 else None
     key = _pack_key(w, 2, st, False, math) if cacheable else None

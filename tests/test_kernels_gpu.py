@@ -901,8 +901,9 @@ def test_bf16x3_math_is_as_accurate_as_the_fp32_mfma(dev, case):
                                                    (1.0, 1.0, 1e-4)])
 def test_fp16x2_keeps_fp32_accuracy_over_the_dynamic_range(dev, xscale, gscale, wscale):
     """fp16x2 scales every activation / gradient tensor by a power of two taken from its own maximum (the kernels read
-    the 256 per-workgroup maxima of objgan_absmax_partials) and the filter bank by 2^10: tensors at 3e-7 or 4e4,
-    gradients at 1e-9 or 2e6, filters up to +-40 or down at 1e-4, and inputs whose elements span five decades, all stay
+    the 256 per-workgroup maxima of objgan_absmax_partials; the pack path leaves the filter bank's behind the bank):
+    tensors at 3e-7 or 4e4,
+    gradients at 1e-9 or 2e6, filter banks scaled by 40 or by 1e-4, and inputs whose elements span five decades, all stay
     within fp32 rounding of an fp64 evaluation -- forward, data gradient and weight gradient."""
     ops = _ops()
     N, Cin, H, W, Cout, k, s, p = 4, 96, 32, 32, 192, 4, 2, 1
