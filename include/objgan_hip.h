@@ -99,9 +99,10 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
 /* math: 0 fp32 operands on the fp32 MFMA; 1 operands rounded to bf16; 2 "bf16x3" (fp32 operands split exactly three ways
  * on the bf16 MFMA, six products); 4 "fp16x2" (fp32 operands as two fp16 pieces of x * 2^s on the fp16 MFMA, three
  * products: residual <= 2^-24 |x| for every element within 2^-10 of its tensor's maximum, 2^-39 of that maximum below;
- * filter entries must stay below 64 in magnitude).  xmax: math 4 only -- the 256 floats objgan_absmax_partials wrote
- * for x (the kernel derives the scale 2^s from them); NULL otherwise. */
-int objgan_absmax_partials(const float* x, long n, float* out256, void* stream);
+ * the filter bank's scale comes from partial maxima the pack path leaves behind the bank).  xmax: math 4 only -- the 1024
+ * partial maxima of |x| (the kernel derives 2^s from them), written by objgan_absmax_partials or by the producer of x
+ * itself (objgan_norm_forward / objgan_norm_backward / objgan_act_backward `amax`); NULL otherwise. */
+int objgan_absmax_partials(const float* x, long n, float* out1024, void* stream);
 /* ws: the bf16 channel-blocked copy of x (math 1), then the split-K workspace.  Small-grid / long-K launches are split along K: every split stores its partial output into
  * its own slot of ws and a second kernel sums the slots in split order (+ bias, activation) -- bit-reproducible, no
  * zero-fill of y, no atomics.  objgan_conv_igemm_ws_floats (host-only, same geometry arguments; ring != 0 when a ring
@@ -119,7 +120,7 @@ int objgan_reflect_ring_fold(const float* ring, float* y, long planes, int H, in
 /* Data gradient of a stride-2 convolution whose four output parity phases have the same number
  * of taps (k=4, pad 1, even sizes): one launch for all phases.  x = dY [N,Cout,OH,OW],
  * y = dX [N,Cin,2*PH,2*PW], fully written (no pre-zeroing).  dh/dw/src_tap: 4 x Tg entries, phase
- * p = (row parity << 1) | column parity.  wt: 4*ceil(1.5*Cin*Tg*ceil16(Cout)) + 256 floats (four phase banks,
+ * p = (row parity << 1) | column parity.  wt: 4*ceil(1.5*Cin*Tg*ceil16(Cout)) + 1024 floats (four phase banks,
  * then the partial maxima of |w| the fp16x2 pack leaves for its scale); wt_packed as above.
  * ws: objgan_conv_dgrad_s2_phases_ws_floats floats (math 1: the bf16 channel-blocked copy of dY, see objgan_conv_igemm; else 0). */
 long objgan_conv_dgrad_s2_phases_ws_floats(int N, int Cout, int OH, int OW, int math);
@@ -162,7 +163,11 @@ int objgan_norm_forward(const float* x, float* y, const float* residual,
                         float* running_mean, float* running_var,
                         float* sums, float* mean, float* rstd,
                         int N, int C, int HW, int per_channel, int mode,
-                        float eps, float momentum, void* stream);
+                        float eps, float momentum, float* amax, void* stream);
+/* amax (may be NULL; only where objgan_norm_amax_supported says 1): the 1024 partial maxima of |y| (forward) / |dx|
+ * (backward), filled inside the call's own launches -- the scale input of an fp16x2 convolution that reads the tensor
+ * next, instead of a separate pass over it (objgan_absmax_partials). */
+int objgan_norm_amax_supported(int N, int C, int HW, int per_channel, int affine);
 /* apply with given statistics (eval-mode BatchNorm: mean = running_mean, rstd = 1/sqrt(running_var+eps)) */
 int objgan_norm_apply(const float* x, float* y, const float* residual, const float* gamma, const float* beta,
                       const float* mean, const float* rstd, int N, int C, int HW, int per_channel, int mode,
@@ -170,8 +175,8 @@ int objgan_norm_apply(const float* x, float* y, const float* residual, const flo
 int objgan_norm_backward(const float* x, const float* dy, const float* mean, const float* rstd,
                          const float* gamma, const float* beta, float* bsums,
                          float* dx, float* dgamma, float* dbeta,
-                         int N, int C, int HW, int per_channel, int mode, void* stream);
-int objgan_act_backward(const float* dy, const float* y, float* dz, long total, int kind, void* stream);
+                         int N, int C, int HW, int per_channel, int mode, float* amax, void* stream);
+int objgan_act_backward(const float* dy, const float* y, float* dz, long total, int kind, float* amax, void* stream);
 /* out[c] = sum over (n, i) of x[n, c, i] (bias gradients); ws: objgan_channel_sum_ws_floats floats (ordered combine) */
 long objgan_channel_sum_ws_floats(int N, int C, int HW);
 int objgan_channel_sum(const float* x, float* out, int N, int C, int HW, float* ws, void* stream);

@@ -59,6 +59,35 @@ __device__ __forceinline__ float og_wave_max(float v) {
     return v;
 }
 
+// ---- partial maxima of |x| (scale input of the fp16x2 convolution arithmetic) ------------------------------------
+// A tensor's maximum travels as OG_AMAX_SLOTS non-negative floats whose maximum is max |x| (consumers reduce them in
+// their prologue: 16 loads per lane).  Producers fill them in one of two ways, both free of float atomics, of ordering
+// assumptions and of extra launches: a launch of G <= OG_AMAX_SLOTS workgroups OWNS its slots (og_amax_own: workgroup b
+// stores its maximum into slot b and zeroes slots b + G, b + 2G, ...); a launch with more workgroups adds its maxima with
+// integer atomicMax on the float's bit pattern (og_amax_atomic) into slots an EARLIER kernel of the same sequence zeroed.
+#define OG_AMAX_SLOTS 1024
+__device__ __forceinline__ float og_block_max(float m, float* red /* >= 4 floats of LDS */) {
+    m = og_wave_max(m);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = m;
+    __syncthreads();
+    const int nw = (blockDim.x + 63) >> 6;
+    float v = red[0];
+    for (int w = 1; w < nw; ++w) v = fmaxf(v, red[w]);
+    return v;
+}
+__device__ __forceinline__ void og_amax_own(float block_max, float* __restrict__ amax, int bid, int nblocks) {
+    if (threadIdx.x == 0) {
+        amax[bid] = block_max;
+        for (int k = bid + nblocks; k < OG_AMAX_SLOTS; k += nblocks) amax[k] = 0.f;
+    }
+}
+__device__ __forceinline__ void og_amax_atomic(float block_max, float* __restrict__ amax, unsigned bid) {
+    if (threadIdx.x == 0)
+        atomicMax(reinterpret_cast<unsigned*>(amax) + (bid & (OG_AMAX_SLOTS - 1)), __float_as_uint(block_max));
+}
+
 // Block-wide sum for blockDim.x <= 1024 (<= 16 waves); `red` is >= 16 floats of LDS.
 __device__ __forceinline__ float og_block_sum(float v, float* red) {
     v = og_wave_sum(v);

@@ -58,8 +58,8 @@ struct IgemmArgs {
     int N, C, H, W;      // physical source dims
     int LH, LW;          // logical source dims seen by the taps (2H x 2W when upsampling)
     int M, Mpad, K, Kpad;   // K = T*C (algorithmic), Kpad = T*Cp (padded, what the loop walks)
-    const float* xmax;      // math 4: the 256 per-workgroup maxima of |x| (objgan_absmax_partials)
-    const float* wmax;      // math 4: the 256 partial maxima of |w| behind the bank (absmax_w_*)
+    const float* xmax;      // math 4: the OG_AMAX_SLOTS partial maxima of |x| (objgan_absmax_partials or a producer)
+    const float* wmax;      // math 4: the OG_AMAX_SLOTS partial maxima of |w| behind the bank (absmax_w_*)
     int math;               // 0: fp32 MFMA, 1: bf16 inputs (RNE) on the bf16 MFMA, fp32 accumulation; 2: bf16x3; 4: fp16x2
     int nhwc;               // bf16 mode: 1 = the pixel operand comes from a bf16 [N][Cp/16][H][W][16] copy of x that
                             // run_igemm2 makes in the caller's workspace (conv_igemm3_kernel<.., 3, ..>)
@@ -175,9 +175,11 @@ __device__ __forceinline__ void og_split4(const f32x4 v, bf16x4& h, bf16x4& m, b
 // bf16x3's (the MFMA adds 16 products before it rounds, and there are half as many accumulations): loop laboratory
 // K = 3072: 6.1e-7 vs 8.7e-7, at 295-302 vs 190-193 TFLOP/s (profiles/r04_loop_lab.txt).
 #define OG_MFMA_H(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
-// scale exponent s of a tensor from its 256 per-workgroup maxima: max * 2^s in [2^14, 2^15)  (0 for an all-zero tensor)
+// scale exponent s of a tensor from its OG_AMAX_SLOTS partial maxima: max * 2^s in [2^14, 2^15)  (0 for an all-zero tensor)
 __device__ __forceinline__ int og_h2_exponent(const float* __restrict__ pm, int lane) {
-    float m = fmaxf(fmaxf(pm[lane], pm[lane + 64]), fmaxf(pm[lane + 128], pm[lane + 192]));
+    float m = 0.f;
+#pragma unroll
+    for (int k = 0; k < OG_AMAX_SLOTS / 64; ++k) m = fmaxf(m, pm[lane + 64 * k]);
     m = og_wave_max(m);
     const int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
     int sx = (e > 0 && e < 255) ? 127 + 14 - e : 0;
@@ -615,7 +617,7 @@ struct PackArgs {
                          //    split h + m + l (og_split8), the three pieces of a 16-deep K step back to back
                          // 5: fp16x2 split wt[M][Kpad/16][2][16] fp16: w * 2^10 = h + l
     int kgroup;          // row-major banks (m_major 1 / 3 / 4 / 5): chunks per K group (see og_kstep)
-    const float* wmax;   // m_major 5: the 256 partial maxima of |w| (behind the bank, written by absmax_w_* before the pack)
+    const float* wmax;   // m_major 5: the OG_AMAX_SLOTS partial maxima of |w| (behind the bank, written by absmax_w_* before the pack)
     int wexp;            // m_major 5: scale exponent derived from them (set inside the pack kernels)
     signed char src_tap[OG_MAX_TAPS];
 };
@@ -762,18 +764,12 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_bf16_kernel(const float* __r
     }
 }
 
-// Partial maxima of |w| for the fp16x2 banks: out[0..63] by 64 workgroups, out[64..255] = 0 (the kernels reduce 256 values).
+// Partial maxima of |w| for the fp16x2 banks: 64 workgroups own the OG_AMAX_SLOTS slots (common.h og_amax_own)
 __device__ __forceinline__ void absmax_w_block(const float* __restrict__ w, long n, float* __restrict__ out) {
     __shared__ float red[4];
     float m = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += 64L * 256) m = fmaxf(m, fabsf(w[i]));
-    m = og_wave_max(m);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        out[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        out[blockIdx.x + 64] = 0.f; out[blockIdx.x + 128] = 0.f; out[blockIdx.x + 192] = 0.f;
-    }
+    og_amax_own(og_block_max(m, red), out, blockIdx.x, 64);
 }
 __global__ __launch_bounds__(256) void absmax_w_kernel(const float* __restrict__ w, long n, float* __restrict__ out) {
     absmax_w_block(w, n, out);
@@ -3108,14 +3104,14 @@ static int og_fill_pack(PackArgs& p, const float* w, float* wt, int N, int C, in
     int MT = 32;
     p.m_major = og_bank_layout(N, C, H, W, M, Tg, PH, PW, act, math, &MT);
     p.kgroup = og_kgroup(C, Tg, H, PH);
-    p.wmax = wt ? wt + objgan_conv_packed_floats(M, C, Tg) - 256 : nullptr; p.wexp = 0;
+    p.wmax = wt ? wt + objgan_conv_packed_floats(M, C, Tg) - OG_AMAX_SLOTS : nullptr; p.wexp = 0;
     if (p.m_major == 2) p.Mpad = MT;
     for (int t = 0; t < OG_MAX_TAPS; ++t) p.src_tap[t] = (signed char)(t < Tg ? src_tap[t] : -1);
     if (MT_out) *MT_out = MT;
     return p.m_major;
 }
 
-// the four phase banks of objgan_conv_dgrad_s2_phases share one buffer of 4 * ceil(1.5 * M * Tg * Cp) + 256 floats: the
+// the four phase banks of objgan_conv_dgrad_s2_phases share one buffer of 4 * ceil(1.5 * M * Tg * Cp) + 1024 floats: the
 // partial maxima of |w| sit behind the largest (bf16x3) bank size, whatever the arithmetic
 static inline long og_phase_wmax_offset(int M, int Tg, int Cp) { return 4 * (((long)M * Tg * Cp * 3 + 1) / 2); }
 
@@ -3135,31 +3131,30 @@ static void og_fill_pack_phase(PackArgs& p, const float* w, float* wt, int Cout,
 }
 
 
-// Per-workgroup maxima of |x| over a tensor: out[0..255] (fp16x2's scale input; the consumers reduce the 256 values
-// themselves -- no zeroed accumulator, no atomics, one launch).
+// Partial maxima of |x| over a tensor: out[0..OG_AMAX_SLOTS) (fp16x2's scale input; the consumers reduce the slots
+// themselves -- no zeroed accumulator, no atomics, one launch; grid <= OG_AMAX_SLOTS workgroups own the slots).
 __global__ __launch_bounds__(256) void absmax_partials_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
     __shared__ float red[4];
     float m = 0.f;
     const long n4 = n >> 2;
     const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += 256L * 256) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += 256L * gridDim.x) {
         const f32x4 v = x4[i];
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
-    m = og_wave_max(m);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    og_amax_own(og_block_max(m, red), out, blockIdx.x, gridDim.x);
 }
 
 extern "C" {
 
-// out[256] = per-workgroup maxima of |x[0..n)| (x 16-byte aligned): the scale input of the fp16x2 arithmetic (math 4).
-int objgan_absmax_partials(const float* x, long n, float* out256, void* stream) {
+// out[1024] = partial maxima of |x[0..n)| (x 16-byte aligned): the scale input of the fp16x2 arithmetic (math 4).
+int objgan_absmax_partials(const float* x, long n, float* out, void* stream) {
     OG_ENTRY();
-    if (!x || !out256 || n <= 0 || ((size_t)x & 15)) return OG_BAD_ARGS;
-    hipLaunchKernelGGL(absmax_partials_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, x, n, out256);
+    if (!x || !out || n <= 0 || ((size_t)x & 15)) return OG_BAD_ARGS;
+    long g = (n / 4 + 255) / 256;                   // one float4 per thread and trip
+    g = g < 1 ? 1 : (g > OG_AMAX_SLOTS ? OG_AMAX_SLOTS : g);
+    hipLaunchKernelGGL(absmax_partials_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, n, out);
     return og_launch_status();
 }
 
@@ -3216,8 +3211,8 @@ int objgan_conv_bank_layout(int N, int C, int H, int W, int M, int Tg, int PH, i
 long objgan_conv_packed_floats(int M, int C, int T) {
     const long Mpad = ((long)M + 127) / 128 * 128;
     const long Cp = ((long)C + 15) / 16 * 16;
-    // the pre-split bank of the bf16x3 mode takes 6 bytes per element; + 256 floats: partial maxima of |w| (fp16x2)
-    return (Mpad * Cp * T * 3 + 1) / 2 + 256;
+    // the pre-split bank of the bf16x3 mode takes 6 bytes per element; + OG_AMAX_SLOTS floats: partial maxima of |w| (fp16x2)
+    return (Mpad * Cp * T * 3 + 1) / 2 + OG_AMAX_SLOTS;
 }
 
 // General entry: see the formula at the top of this file.
@@ -3327,7 +3322,7 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
 // (k = 4, pad 1, even sizes: 2x2 taps each): ONE launch, the phase is the fastest digit of the workgroup id.  x = dY [N, Cout, OH, OW],
 // y = dX [N, Cin, 2*PH, 2*PW] (every element is written by exactly one phase: no pre-zeroing).
 // dh/dw/src_tap: 4 phases x Tg entries, phase p = (row parity << 1) | column parity.
-// wt: 4 * ceil(1.5 * Cin * Tg * ceil16(Cout)) + 256 floats (the four phase banks, then the partial maxima of |w|).
+// wt: 4 * ceil(1.5 * Cin * Tg * ceil16(Cout)) + 1024 floats (the four phase banks, then the partial maxima of |w|).
 int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float* wt,
                                 int N, int Cout, int OH, int OW, int Cin, int Torig,
                                 int Tg, const int* dh, const int* dw, const int* src_tap,

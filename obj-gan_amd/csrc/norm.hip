@@ -38,7 +38,10 @@ __device__ __forceinline__ void og_store_partial2(const NormWs& ws, int g, int i
     float* slot = ws.part + ((size_t)g * ws.P + idx) * 2;
     slot[0] = s1; slot[1] = s2;
 }
-__global__ __launch_bounds__(256) void norm_partials_sum_kernel(NormWs ws, int G) {
+// (amax != nullptr: also zeroes the OG_AMAX_SLOTS maxima slots the apply kernel behind it fills with og_amax_atomic)
+__global__ __launch_bounds__(256) void norm_partials_sum_kernel(NormWs ws, int G, float* __restrict__ amax) {
+    if (amax && blockIdx.x == 0)
+        for (int k = threadIdx.x; k < OG_AMAX_SLOTS; k += 256) amax[k] = 0.f;
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
     const float* p = ws.part + (size_t)g * ws.P * 2;
@@ -274,7 +277,9 @@ template <int MODE>
 __global__ __launch_bounds__(256) void norm_apply_plane_kernel(
     const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ residual, float* __restrict__ y, NormGeom gm, NormFin fin) {
+    const float* __restrict__ residual, float* __restrict__ y, NormGeom gm, NormFin fin, float* __restrict__ amax) {
+    __shared__ float amax_red[4];
+    float vmax = 0.f;
     const int Co = MODE == OG_NORM_GLU ? gm.C / 2 : gm.C;
     const int plane = blockIdx.x;                       // n*Co + c
     const int n = plane / Co;
@@ -318,7 +323,9 @@ __global__ __launch_bounds__(256) void norm_apply_plane_kernel(
         }
         if (rp) { const float4 r = rp[i]; v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
         yp[i] = make_float4(v[0], v[1], v[2], v[3]);
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     }
+    if (amax) og_amax_atomic(og_block_max(vmax, amax_red), amax, blockIdx.x + blockIdx.y * gridDim.x);
 }
 
 // Backward, shared element math: from x (both halves for GLU) and dy produce dz and xhat of the
@@ -392,7 +399,9 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_plane_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ bsums, float* __restrict__ dx, NormGeom gm,
-    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ amax) {
+    __shared__ float amax_red[4];
+    float vmax = 0.f;
     const int Co = MODE == OG_NORM_GLU ? gm.C / 2 : gm.C;
     const int plane = blockIdx.x;
     const int n = plane / Co;
@@ -436,7 +445,10 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_plane_kernel(
         }
         oa[i] = make_float4(ra4[0], ra4[1], ra4[2], ra4[3]);
         if (MODE == OG_NORM_GLU) ob[i] = make_float4(rb4[0], rb4[1], rb4[2], rb4[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vmax = fmaxf(vmax, fmaxf(fabsf(ra4[j]), MODE == OG_NORM_GLU ? fabsf(rb4[j]) : 0.f));
     }
+    if (amax) og_amax_atomic(og_block_max(vmax, amax_red), amax, blockIdx.x + blockIdx.y * gridDim.x);
 }
 
 
@@ -592,7 +604,10 @@ __global__ void norm_affine_grad_kernel(const float* __restrict__ bsums, float* 
 // kind 1: LeakyReLU(0.2) from the OUTPUT y (sign(y) == sign(z));  2: tanh;  3: sigmoid;  4: ReLU
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy,
                                                       const float* __restrict__ y,
-                                                      float* __restrict__ dz, long total, int kind) {
+                                                      float* __restrict__ dz, long total, int kind,
+                                                      float* __restrict__ amax) {
+    __shared__ float amax_red[4];
+    float vmax = 0.f;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (long)gridDim.x * blockDim.x) {
         const float o = y[e], d = dy[e];
@@ -602,7 +617,9 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
         else if (kind == 3) r = d * o * (1.f - o);
         else r = o > 0.f ? d : 0.f;
         dz[e] = r;
+        vmax = fmaxf(vmax, fabsf(r));
     }
+    if (amax) og_amax_own(og_block_max(vmax, amax_red), amax, blockIdx.x, gridDim.x);      // grid <= OG_AMAX_SLOTS
 }
 
 // per-channel sum over (N, HW): out[c] = sum_n sum_i x[n, c, i]   (conv bias gradient); grid (C, S): S partial sums
@@ -657,11 +674,20 @@ static inline int norm_partials(int N, int C, int HW, int per_channel) {
     return norm_splits(G, per_channel ? (long)N * HW : HW);
 }
 static inline NormWs norm_ws(float* buf, int G, int P) { return NormWs{buf, buf + 2 * (size_t)G, P}; }
-static inline void norm_sum_partials(const NormWs& ws, int G, hipStream_t s) {
-    if (ws.P > 1) hipLaunchKernelGGL(norm_partials_sum_kernel, dim3(og_cdiv(G, 256)), dim3(256), 0, s, ws, G);
+static inline void norm_sum_partials(const NormWs& ws, int G, hipStream_t s, float* amax = nullptr) {
+    if (ws.P > 1) hipLaunchKernelGGL(norm_partials_sum_kernel, dim3(og_cdiv(G, 256)), dim3(256), 0, s, ws, G, amax);
 }
 
 extern "C" {
+
+// 1 if objgan_norm_forward / objgan_norm_backward with these sizes fill `amax` (the OG_AMAX_SLOTS = 1024 partial maxima of
+// |y| resp. |dx|: the scale input of the fp16x2 convolutions, see objgan_absmax_partials) inside their own launches: the
+// plane-structured statistics + apply path with more than one statistics workgroup per group.  Host-only.
+int objgan_norm_amax_supported(int N, int C, int HW, int per_channel, int affine) {
+    if (N <= 0 || C <= 0 || HW <= 0 || !norm_planes(N, C, HW)) return 0;
+    if (!per_channel && !affine && HW <= OG_IN_FUSED_MAX && !og_norm_nofuse()) return 0;      // one-kernel InstanceNorm
+    return norm_partials(N, C, HW, per_channel) > 1 ? 1 : 0;
+}
 
 // Floats of statistics workspace (`sums` of objgan_norm_forward, `bsums` of objgan_norm_backward) for these sizes:
 // [2G totals][2 * G * P partial pairs], P = workgroups per group of the statistics launch.  Host-only.
@@ -679,10 +705,11 @@ int objgan_norm_forward(const float* x, float* y, const float* residual,
                         float* running_mean, float* running_var,
                         float* sums, float* mean, float* rstd,
                         int N, int C, int HW, int per_channel, int mode,
-                        float eps, float momentum, void* stream) {
+                        float eps, float momentum, float* amax, void* stream) {
     OG_ENTRY();
     if (mode == OG_NORM_GLU && (C & 1)) return OG_BAD_ARGS;
     if (N <= 0 || C <= 0 || HW <= 0) return OG_OK;
+    if (amax && !objgan_norm_amax_supported(N, C, HW, per_channel, gamma != nullptr)) return OG_BAD_ARGS;
     hipStream_t s = (hipStream_t)stream;
     NormGeom gm{N, C, HW, per_channel};
     const int G = per_channel ? C : N * C;
@@ -708,16 +735,16 @@ int objgan_norm_forward(const float* x, float* y, const float* residual,
         dim3 grid(G, norm_splits(G, per_group));
         hipLaunchKernelGGL(norm_stats_kernel, grid, dim3(256), 0, s, x, ws, gm);
     }
-    norm_sum_partials(ws, G, s);
+    norm_sum_partials(ws, G, s, amax);          // (also zeroes the maxima slots the apply kernel fills)
     if (planes) {
         dim3 grid(N * Co, chunks);
         const NormFin fin{sums, mean, rstd, running_mean, running_var, eps, momentum};
         if (mode == OG_NORM_GLU)
-            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_GLU>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm, fin);
+            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_GLU>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm, fin, amax);
         else if (mode == OG_NORM_LRELU)
-            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_LRELU>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm, fin);
+            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_LRELU>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm, fin, amax);
         else
-            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_NONE>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm, fin);
+            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_NONE>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm, fin, amax);
         return og_launch_status();
     }
     hipLaunchKernelGGL(norm_finalize_kernel, dim3(og_cdiv(G, 256)), dim3(256), 0, s, x, sums, mean,
@@ -743,11 +770,11 @@ int objgan_norm_apply(const float* x, float* y, const float* residual, const flo
         dim3 grid(N * Co, og_cdiv(HW, OG_NORM_CHUNK));
         const NormFin fin{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f};
         if (mode == OG_NORM_GLU)
-            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_GLU>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm, fin);
+            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_GLU>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm, fin, (float*)nullptr);
         else if (mode == OG_NORM_LRELU)
-            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_LRELU>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm, fin);
+            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_LRELU>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm, fin, (float*)nullptr);
         else
-            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_NONE>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm, fin);
+            hipLaunchKernelGGL((norm_apply_plane_kernel<OG_NORM_NONE>), grid, dim3(256), 0, s, x, mean, rstd, gamma, beta, residual, y, gm, fin, (float*)nullptr);
         return og_launch_status();
     }
     const long total = (long)N * Co * HW;
@@ -761,10 +788,11 @@ int objgan_norm_apply(const float* x, float* y, const float* residual, const flo
 int objgan_norm_backward(const float* x, const float* dy, const float* mean, const float* rstd,
                          const float* gamma, const float* beta, float* bsums,
                          float* dx, float* dgamma, float* dbeta,
-                         int N, int C, int HW, int per_channel, int mode, void* stream) {
+                         int N, int C, int HW, int per_channel, int mode, float* amax, void* stream) {
     OG_ENTRY();
     if (mode == OG_NORM_GLU && (C & 1)) return OG_BAD_ARGS;
     if (N <= 0 || C <= 0 || HW <= 0) return OG_OK;
+    if (amax && !objgan_norm_amax_supported(N, C, HW, per_channel, gamma != nullptr)) return OG_BAD_ARGS;
     hipStream_t s = (hipStream_t)stream;
     NormGeom gm{N, C, HW, per_channel};
     const int G = per_channel ? C : N * C;
@@ -788,9 +816,9 @@ int objgan_norm_backward(const float* x, const float* dy, const float* mean, con
 #define OG_NB(MODE)                                                                                         \
         hipLaunchKernelGGL((norm_bwd_stats_plane_kernel<MODE>), grid, dim3(256), 0, s, x, dy, mean, rstd,   \
                            gamma, beta, ws, gm);                                                            \
-        norm_sum_partials(ws, G, s);                                                                        \
+        norm_sum_partials(ws, G, s, amax);                                                                  \
         hipLaunchKernelGGL((norm_bwd_apply_plane_kernel<MODE>), grid, dim3(256), 0, s, x, dy, mean, rstd,   \
-                           gamma, beta, bsums, dx, gm, dgamma, dbeta);
+                           gamma, beta, bsums, dx, gm, dgamma, dbeta, amax);
         if (mode == OG_NORM_GLU) { OG_NB(OG_NORM_GLU) } else if (mode == OG_NORM_LRELU) { OG_NB(OG_NORM_LRELU) } else { OG_NB(OG_NORM_NONE) }
 #undef OG_NB
         return og_launch_status();
@@ -809,13 +837,15 @@ int objgan_norm_backward(const float* x, const float* dy, const float* mean, con
     return og_launch_status();
 }
 
-int objgan_act_backward(const float* dy, const float* y, float* dz, long total, int kind,
+// amax (may be NULL): the OG_AMAX_SLOTS partial maxima of |dz| (see objgan_absmax_partials)
+int objgan_act_backward(const float* dy, const float* y, float* dz, long total, int kind, float* amax,
                         void* stream) {
     OG_ENTRY();
     if (kind < 1 || kind > 4) return OG_BAD_ARGS;
     if (total <= 0) return OG_OK;
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(og_stream_grid(total, 256)), dim3(256), 0,
-                       (hipStream_t)stream, dy, y, dz, total, kind);
+    int grid = og_stream_grid(total, 256);
+    if (amax && grid > OG_AMAX_SLOTS) grid = OG_AMAX_SLOTS;      // every workgroup owns a slot
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, y, dz, total, kind, amax);
     return og_launch_status();
 }
 

@@ -40,11 +40,12 @@ SIGNATURES = {
     "objgan_lstm_bidir_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                                   _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_norm_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
-                            _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _ptr],
+                            _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _ptr, _ptr],
+    "objgan_norm_amax_supported": [_c_int] * 5,
     "objgan_norm_apply": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_norm_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
-                             _c_int, _c_int, _c_int, _c_int, _c_int, _ptr],
-    "objgan_act_backward": [_ptr, _ptr, _ptr, _c_long, _c_int, _ptr],
+                             _c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr],
+    "objgan_act_backward": [_ptr, _ptr, _ptr, _c_long, _c_int, _ptr, _ptr],
     "objgan_channel_sum": [_ptr, _ptr, _c_int, _c_int, _c_int, _ptr, _ptr],
     "objgan_attn_general_forward": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_attn_general_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr],

@@ -86,7 +86,8 @@ def get_conv_math():
     return [k for k, v in _MATH_IDS.items() if v == _MATH["mode"]][0]
 
 
-_H2_MIN_FLOP = 1.0e9        # fp16x2: launches below this keep bf16x3 (the maximum pass would cost more than it saves)
+# fp16x2: launches below this keep bf16x3 (the maximum pass would cost more than it saves)
+_H2_MIN_FLOP = float(_os.environ.get("OBJGAN_H2_MIN_FLOP", "1.0e9"))
 
 
 def _call_math(flop):
@@ -97,19 +98,45 @@ def _call_math(flop):
     return m
 
 
+_AMAX_SLOTS = 1024          # csrc/common.h OG_AMAX_SLOTS
+
+
+def _amax_wanted(numel):
+    """does a producer of a tensor of this size emit its partial maxima?  (fp16x2 mode; tensors a launch above the
+    FLOP threshold could read: anything of a few hundred thousand elements up)"""
+    return _MATH["mode"] == 4 and numel >= 262144 and not _FAKE_ABSMAX
+
+
+def _amax_attach(t, amax):
+    """the producer of `t` filled `amax` (its partial maxima) on the current stream: what _absmax(t) returns from now on"""
+    sid = torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    try:
+        t._og_absmax = {sid: (t._version, amax)}
+    except (AttributeError, RuntimeError):
+        pass
+
+
+_FAKE_ABSMAX = {"on": 1} if _os.environ.get("OBJGAN_H2_FAKE_ABSMAX") == "1" else {}
+
+
 def _absmax(t):
-    """the 256 per-workgroup maxima of |t| (fp16x2's scale input): one pass over t, no host sync.  Cached on the tensor
+    """the 1024 partial maxima of |t| (fp16x2's scale input): one pass over t, no host sync.  Cached on the tensor
     object for the duration of its life (a forward activation is the pixel operand of its convolution AND, in the
     backward pass, the column operand of that layer's weight gradient) -- per HIP stream: a tensor shared by jobs on
     different streams (the images every discriminator reads) gets one pass per stream, ordered with that stream's
     kernels."""
+    if _FAKE_ABSMAX:                     # (development: timing without the maximum passes -- wrong scales)
+        one = _FAKE_ABSMAX.get(t.device)
+        if one is None:
+            one = _FAKE_ABSMAX[t.device] = torch.ones(_AMAX_SLOTS, dtype=_F32, device=t.device)
+        return one
     sid = torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
     cache = getattr(t, "_og_absmax", None)
     if cache is not None:
         got = cache.get(sid)
         if got is not None and got[0] == t._version:
             return got[1]
-    out = torch.empty(256, dtype=_F32, device=t.device)
+    out = torch.empty(_AMAX_SLOTS, dtype=_F32, device=t.device)
     src = t if (t.is_contiguous() and not (t.data_ptr() & 15)) else t.contiguous().clone()
     _lib.call("objgan_absmax_partials", _p(src), src.numel(), _p(out), _stream())
     try:
@@ -284,7 +311,7 @@ def _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad_h, pad_w, LH, LW, cachea
     if Tg > 8:
         return None
     dx = torch.empty((N, Cin, LH, LW), dtype=_F32, device=g.device)
-    n = 4 * ((Cin * Tg * ((Cout + 15) // 16 * 16) * 3 + 1) // 2) + 256    # bf16x3 banks: 6 bytes per element; + |w| maxima
+    n = 4 * ((Cin * Tg * ((Cout + 15) // 16 * 16) * 3 + 1) // 2) + _AMAX_SLOTS    # bf16x3 banks: 6 B per element; + |w| maxima
     math = _call_math(2.0 * Cin * Cout * Tg * N * LH * LW)
     xmax = _absmax(g) if math == 4 else None
     key = _pack_key(w, 2, st, False, math) if cacheable else None
@@ -473,7 +500,10 @@ class _Conv2dFn(torch.autograd.Function):
         _chk(dy)
         if act not in (None, "none"):
             g = torch.empty_like(dy)
-            _lib.call("objgan_act_backward", _p(dy), _p(y), _p(g), dy.numel(), _ACT[act], _stream())
+            am = torch.empty(_AMAX_SLOTS, dtype=_F32, device=dy.device) if _amax_wanted(dy.numel()) else None
+            _lib.call("objgan_act_backward", _p(dy), _p(y), _p(g), dy.numel(), _ACT[act], _p(am), _stream())
+            if am is not None:
+                _amax_attach(g, am)
         else:
             g = dy
         dx = dw_ = db = None
@@ -603,7 +633,10 @@ class _Conv2dCatFn(torch.autograd.Function):
         _chk(dy)
         if act not in (None, "none"):
             g = torch.empty_like(dy)
-            _lib.call("objgan_act_backward", _p(dy), _p(y), _p(g), dy.numel(), _ACT[act], _stream())
+            am = torch.empty(_AMAX_SLOTS, dtype=_F32, device=dy.device) if _amax_wanted(dy.numel()) else None
+            _lib.call("objgan_act_backward", _p(dy), _p(y), _p(g), dy.numel(), _ACT[act], _p(am), _stream())
+            if am is not None:
+                _amax_attach(g, am)
         else:
             g = dy
         n1, n2, nw = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
@@ -668,7 +701,10 @@ class _ConvFrozenFn(torch.autograd.Function):
         OH, OW = dy.shape[2], dy.shape[3]
         if act not in (None, "none"):
             g = torch.empty_like(dy)
-            _lib.call("objgan_act_backward", _p(dy), _p(y), _p(g), dy.numel(), _ACT[act], _stream())
+            am = torch.empty(_AMAX_SLOTS, dtype=_F32, device=dy.device) if _amax_wanted(dy.numel()) else None
+            _lib.call("objgan_act_backward", _p(dy), _p(y), _p(g), dy.numel(), _ACT[act], _p(am), _stream())
+            if am is not None:
+                _amax_attach(g, am)
         else:
             g = dy
         T = KH * KW
@@ -721,6 +757,9 @@ def linear(x, w, bias=None, act=None):
 _NORM_MODE = {None: 0, "none": 0, "lrelu": 1, "glu": 2}
 
 
+_LAST_AMAX = [None]         # partial maxima the last _NormActFn.forward left for its output (host-side hand-over)
+
+
 class _NormActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, per_channel, mode, eps,
@@ -736,10 +775,14 @@ class _NormActFn(torch.autograd.Function):
         ws = torch.empty(nst + 2 * G, dtype=_F32, device=x.device)
         sums, mean, rstd = ws[:nst], ws[nst:nst + G], ws[nst + G:]
         residual = _c(residual) if residual is not None else None
+        emit = _amax_wanted(y.numel()) and bool(
+            _lib.load().objgan_norm_amax_supported(N, C, HW, int(per_channel), int(gamma is not None)))
+        am = torch.empty(_AMAX_SLOTS, dtype=_F32, device=x.device) if emit else None
         _lib.call("objgan_norm_forward", _p(x), _p(y), _p(residual), _p(gamma), _p(beta),
                   _p(running_mean), _p(running_var), _p(sums), _p(mean), _p(rstd),
-                  N, C, HW, int(per_channel), _NORM_MODE[mode], float(eps), float(momentum), _stream())
-        ctx.cfg = (N, C, HW, int(per_channel), _NORM_MODE[mode])
+                  N, C, HW, int(per_channel), _NORM_MODE[mode], float(eps), float(momentum), _p(am), _stream())
+        _LAST_AMAX[0] = am                   # norm_act() attaches it to the tensor the caller receives
+        ctx.cfg = (N, C, HW, int(per_channel), _NORM_MODE[mode], emit)
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
         return y
@@ -747,7 +790,7 @@ class _NormActFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, mean, rstd, gamma, beta = ctx.saved_tensors
-        N, C, HW, per_channel, mode = ctx.cfg
+        N, C, HW, per_channel, mode, emit = ctx.cfg
         dy = _c(dy)
         _chk(dy)
         G = C if per_channel else N * C
@@ -757,8 +800,11 @@ class _NormActFn(torch.autograd.Function):
         if gamma is not None:
             dgamma = torch.empty_like(gamma)
             dbeta = torch.empty_like(beta)
+        am = torch.empty(_AMAX_SLOTS, dtype=_F32, device=x.device) if (emit and _amax_wanted(dx.numel())) else None
         _lib.call("objgan_norm_backward", _p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta),
-                  _p(bsums), _p(dx), _p(dgamma), _p(dbeta), N, C, HW, per_channel, mode, _stream())
+                  _p(bsums), _p(dx), _p(dgamma), _p(dbeta), N, C, HW, per_channel, mode, _p(am), _stream())
+        if am is not None:
+            _amax_attach(dx, am)             # (the convolution backward in front of this layer reads dx next)
         dres = dy if ctx.has_res else None
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None
 
@@ -767,8 +813,13 @@ def norm_act(x, gamma=None, beta=None, residual=None, running_mean=None, running
              per_channel=False, mode=None, eps=1e-5, momentum=0.1):
     """BatchNorm (per_channel=True, batch statistics) or InstanceNorm (per_channel=False)
     fused with GLU / LeakyReLU(0.2) and an optional residual add."""
-    return _NormActFn.apply(x, gamma, beta, residual, running_mean, running_var, per_channel, mode,
-                            eps, momentum)
+    _LAST_AMAX[0] = None
+    y = _NormActFn.apply(x, gamma, beta, residual, running_mean, running_var, per_channel, mode,
+                         eps, momentum)
+    if _LAST_AMAX[0] is not None:
+        _amax_attach(y, _LAST_AMAX[0])
+        _LAST_AMAX[0] = None
+    return y
 
 
 def norm_act_eval(x, gamma, beta, running_mean, running_var, mode=None, eps=1e-5):

@@ -931,6 +931,56 @@ def test_fp16x2_keeps_fp32_accuracy_over_the_dynamic_range(dev, xscale, gscale, 
     assert max(e) < 1.5e-6, e
 
 
+@pytest.mark.parametrize("case", [(4, 96, 64, 64, True, "glu", True), (16, 192, 32, 32, True, "lrelu", False),
+                                  (2, 388, 128, 128, True, "glu", False), (8, 64, 64, 64, True, None, True)])
+def test_producers_emit_the_maxima_a_separate_pass_would_find(dev, case):
+    """In fp16x2 mode the producers of large activations / gradients -- BatchNorm (+ GLU / LeakyReLU / residual) forward
+    and backward, the activation derivative of a convolution -- leave the partial maxima of their output next to it
+    (1024 slots, filled inside their own launches) so that the convolution reading the tensor needs no pass over it:
+    the maximum of the slots must equal max |tensor| exactly, forward and backward, and the conv results must not
+    depend on who computed the scale."""
+    ops = _ops()
+    N, C, H, W, per_channel, mode, with_res = case
+    g = torch.Generator().manual_seed(4)
+    prev, prev_min = ops.get_conv_math(), ops._H2_MIN_FLOP
+    ops.set_conv_math("fp16x2")
+    ops._H2_MIN_FLOP = 0.0
+    try:
+        x = (torch.randn(N, C, H, W, generator=g) * 3.0 + 0.5).to(dev).requires_grad_()
+        Co = C // 2 if mode == "glu" else C
+        gamma = (torch.rand(C, generator=g) + 0.5).to(dev).requires_grad_()
+        beta = torch.randn(C, generator=g).to(dev).requires_grad_()
+        res = torch.randn(N, Co, H, W, generator=g).to(dev).requires_grad_() if with_res else None
+        y = ops.norm_act(x, gamma, beta, res, None, None, per_channel=per_channel, mode=mode)
+        am = getattr(y, "_og_absmax", None)
+        assert am is not None, "the producer did not attach its maxima"
+        slots = list(am.values())[0][1]
+        assert slots.numel() == 1024 and float(slots.max()) == float(y.detach().abs().max())
+        assert torch.equal(ops._absmax(y), slots)
+        gy = (torch.randn(y.shape, generator=g) * 1e-4).to(dev)
+        got = {}
+
+        def grab(grad):                     # what the layer in front of the normalisation receives
+            got["dx"] = grad
+            got["am"] = getattr(grad, "_og_absmax", None)
+        x.register_hook(grab)
+        y.backward(gy)
+        torch.cuda.synchronize()
+        assert got["am"] is not None, "the backward producer did not attach its maxima"
+        slots = list(got["am"].values())[0][1]
+        assert float(slots.max()) == float(got["dx"].abs().max())
+        # activation derivative inside the convolution backward
+        w = (torch.randn(32 + Co, Co, 3, 3, generator=g) * 0.05).to(dev).requires_grad_()
+        xin = y.detach().requires_grad_()
+        z = ops.conv2d(xin, w, None, 1, 1, "zeros", False, "lrelu")
+        z.backward(torch.randn(z.shape, generator=g).to(dev) * 1e-3)
+        torch.cuda.synchronize()
+        assert torch.isfinite(xin.grad).all() and torch.isfinite(w.grad).all()
+    finally:
+        ops.set_conv_math(prev)
+        ops._H2_MIN_FLOP = prev_min
+
+
 @pytest.mark.parametrize("need", [(True, True), (True, False), (False, True)])
 def test_conv2d_cat_gives_per_input_gradients(dev, need):
     """conv2d_cat(x1, x2, w) = lrelu(conv(cat([x1, x2]), w)) (first layer of the shape / object discriminators): the

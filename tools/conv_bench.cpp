@@ -81,7 +81,7 @@ int main(int argc, char** argv) {
         const long nwsb = 96L << 20;      // 384 MB of floats
         CK(hipMalloc(&wsb, nwsb * 4));
         float* mxx; float* mxg;          // math 4 (fp16x2): per-workgroup maxima of x and of dy (objgan_absmax_partials)
-        CK(hipMalloc(&mxx, 256 * 4)); CK(hipMalloc(&mxg, 256 * 4));
+        CK(hipMalloc(&mxx, 1024 * 4)); CK(hipMalloc(&mxg, 1024 * 4));
         CK(hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(dw, hw.data(), nw * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(dg, hg.data(), ny * 4, hipMemcpyHostToDevice));
