@@ -94,14 +94,16 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
                       int Tg, const int* dh, const int* dw, const int* src_tap,
                       int PH, int PW, int stride,
                       int OHf, int OWf, int osh, int osw, int ooh, int oow,
-                      int act, int y_prezeroed, int wt_packed, int math, float* ring, const float* xmax,
+                      int act, int y_prezeroed, int wt_packed, int math, float* ring, const float* xmax, float* ymax,
                       float* ws, long ws_floats, void* stream);
 /* math: 0 fp32 operands on the fp32 MFMA; 1 operands rounded to bf16; 2 "bf16x3" (fp32 operands split exactly three ways
  * on the bf16 MFMA, six products); 4 "fp16x2" (fp32 operands as two fp16 pieces of x * 2^s on the fp16 MFMA, three
  * products: residual <= 2^-24 |x| for every element within 2^-10 of its tensor's maximum, 2^-39 of that maximum below;
  * the filter bank's scale comes from partial maxima the pack path leaves behind the bank).  xmax: math 4 only -- the 1024
  * partial maxima of |x| (the kernel derives 2^s from them), written by objgan_absmax_partials or by the producer of x
- * itself (objgan_norm_forward / objgan_norm_backward / objgan_act_backward `amax`); NULL otherwise. */
+ * itself (objgan_norm_forward / objgan_norm_backward / objgan_act_backward `amax`, this call's `ymax`); NULL otherwise.
+ * ymax (may be NULL): 1024 ZERO-FILLED floats that receive the partial maxima of |y| -- from the kernel's epilogue where the
+ * launch writes final values, from a pass over y otherwise. */
 int objgan_absmax_partials(const float* x, long n, float* out1024, void* stream);
 /* ws: the bf16 channel-blocked copy of x (math 1), then the split-K workspace.  Small-grid / long-K launches are split along K: every split stores its partial output into
  * its own slot of ws and a second kernel sums the slots in split order (+ bias, activation) -- bit-reproducible, no
@@ -164,7 +166,7 @@ int objgan_norm_forward(const float* x, float* y, const float* residual,
                         float* sums, float* mean, float* rstd,
                         int N, int C, int HW, int per_channel, int mode,
                         float eps, float momentum, float* amax, void* stream);
-/* amax (may be NULL; only where objgan_norm_amax_supported says 1): the 1024 partial maxima of |y| (forward) / |dx|
+/* amax (may be NULL; only where objgan_norm_amax_supported is non-zero -- 2: the caller passes the slots ZERO-FILLED): the 1024 partial maxima of |y| (forward) / |dx|
  * (backward), filled inside the call's own launches -- the scale input of an fp16x2 convolution that reads the tensor
  * next, instead of a separate pass over it (objgan_absmax_partials). */
 int objgan_norm_amax_supported(int N, int C, int HW, int per_channel, int affine);

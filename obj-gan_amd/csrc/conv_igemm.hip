@@ -36,6 +36,7 @@
 #include <string.h>
 
 extern "C" long objgan_conv_packed_floats(int M, int C, int T);
+static void og_absmax_launch(const float* x, long n, float* out, hipStream_t s);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -60,6 +61,8 @@ struct IgemmArgs {
     int M, Mpad, K, Kpad;   // K = T*C (algorithmic), Kpad = T*Cp (padded, what the loop walks)
     const float* xmax;      // math 4: the OG_AMAX_SLOTS partial maxima of |x| (objgan_absmax_partials or a producer)
     const float* wmax;      // math 4: the OG_AMAX_SLOTS partial maxima of |w| behind the bank (absmax_w_*)
+    float* ymax;            // != nullptr (unsplit conv_igemm3_kernel launches): OG_AMAX_SLOTS zero-filled slots that receive
+                            // the partial maxima of |y| (the scale input of an fp16x2 convolution that reads y next)
     int math;               // 0: fp32 MFMA, 1: bf16 inputs (RNE) on the bf16 MFMA, fp32 accumulation; 2: bf16x3; 4: fp16x2
     int nhwc;               // bf16 mode: 1 = the pixel operand comes from a bf16 [N][Cp/16][H][W][16] copy of x that
                             // run_igemm2 makes in the caller's workspace (conv_igemm3_kernel<.., 3, ..>)
@@ -1829,7 +1832,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
     if (kt < nk) mma(rb0, ad0, cur, [] {});            // odd step count: last step
 
     // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
-    if (!pix_ok) return;
+    if (!pix_ok && !a.ymax) return;         // (with ymax every lane of the wave stays for the maximum below)
     const int ppi = a.PH * a.PW;
     const int n = pix / ppi;
     const int rem = pix - n * ppi;
@@ -1859,12 +1862,13 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
         yb = a.ws + (size_t)blockIdx.y * a.ws_stride + off;
     }
     const bool to_ws = split && a.ws;
+    float vmax = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-            if (m < a.m_end) {
+            if (m < a.m_end && pix_ok) {
                 float v = H2 ? acc[i][r] * h2_inv : acc[i][r];
                 if (to_ws) {
                     yb[(size_t)m * plane] = v;
@@ -1874,9 +1878,15 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
                     if (a.bias) v += a.bias[m];
                     v = lrelu ? (v > 0.f ? v : 0.2f * v) : (relu ? fmaxf(v, 0.f) : v);
                     yb[(size_t)m * plane] = v;
+                    vmax = fmaxf(vmax, fabsf(v));
                 }
             }
         }
+    }
+    if (a.ymax) {       // partial maxima of |y| for an fp16x2 consumer: one integer atomicMax per wave into zeroed slots
+        const float wm = og_wave_max(vmax);
+        if (lane == 0)
+            atomicMax(reinterpret_cast<unsigned*>(a.ymax) + ((blockIdx.x * NW + wid) & (OG_AMAX_SLOTS - 1)), __float_as_uint(wm));
     }
 }
 
@@ -2982,7 +2992,8 @@ static long igemm2_ws_floats(const IgemmArgs& a, const Igemm2Plan& p) {
     return nh + seg * p.splits;
 }
 
-static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed, float* ws, long ws_floats) {
+static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed, float* ws, long ws_floats, float* ymax = nullptr) {
+    a.ymax = nullptr;
     if (a.nhwc && !ws) a.nhwc = 0;              // no workspace: fp32 NCHW gathers (conv_igemm3_kernel<.., 1, ..>)
     const Igemm2Plan p = igemm2_plan(a, y_prezeroed);
     if (a.nhwc) {                               // bf16 channel-blocked copy of the source: first part of the workspace
@@ -3018,6 +3029,9 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed, float* ws, lo
         a.ksplit_steps = 0;
         if (act_later) { a.bias = nullptr; a.act = OG_ACT_NONE; }
     }
+    // |y| maxima in the epilogue: unsplit launches that write their final values and cover y (else a pass over y below)
+    const bool emit = ymax && splits <= 1 && !act_later && full_cover && !a.ring;
+    if (emit) a.ymax = ymax;
     int rc = OG_OK;
     if (full_rows > 0) {
         a.m_begin = 0; a.m_end = min(a.M, full_rows * TM * 32);
@@ -3043,15 +3057,16 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed, float* ws, lo
         if (ring_elems > 0)
             hipLaunchKernelGGL(splitk_combine_kernel, dim3(og_stream_grid(ring_elems, 256)), dim3(256), 0, s, a.ws, splits,
                                a.ws_stride, y_elems, a.ring, ring_elems, (const float*)nullptr, 1, 1, OG_ACT_NONE);
+        if (ymax) og_absmax_launch(a.y, y_elems, ymax, s);
         return og_launch_status();
     }
     if ((splits > 1 || act_later) && (bias || act != OG_ACT_NONE) && full_cover) {
         const long total = y_elems;
         hipLaunchKernelGGL(bias_act_kernel, dim3(og_stream_grid(total, 256)), dim3(256), 0, s, a.y, bias,
                            total, a.M, a.OHf * a.OWf, act);
-        return og_launch_status();
     }
-    return OG_OK;
+    if (ymax && !emit) og_absmax_launch(a.y, y_elems, ymax, s);
+    return og_launch_status();
 }
 
 // Row pitch of a packed bank in elements: fp32 Kpad floats; bf16 Kpad rounded up to 32 (one iteration = 32 k);
@@ -3146,15 +3161,19 @@ __global__ __launch_bounds__(256) void absmax_partials_kernel(const float* __res
     og_amax_own(og_block_max(m, red), out, blockIdx.x, gridDim.x);
 }
 
+static void og_absmax_launch(const float* x, long n, float* out, hipStream_t s) {
+    long g = (n / 4 + 255) / 256;                   // one float4 per thread and trip
+    g = g < 1 ? 1 : (g > OG_AMAX_SLOTS ? OG_AMAX_SLOTS : g);
+    hipLaunchKernelGGL(absmax_partials_kernel, dim3((int)g), dim3(256), 0, s, x, n, out);
+}
+
 extern "C" {
 
 // out[1024] = partial maxima of |x[0..n)| (x 16-byte aligned): the scale input of the fp16x2 arithmetic (math 4).
 int objgan_absmax_partials(const float* x, long n, float* out, void* stream) {
     OG_ENTRY();
     if (!x || !out || n <= 0 || ((size_t)x & 15)) return OG_BAD_ARGS;
-    long g = (n / 4 + 255) / 256;                   // one float4 per thread and trip
-    g = g < 1 ? 1 : (g > OG_AMAX_SLOTS ? OG_AMAX_SLOTS : g);
-    hipLaunchKernelGGL(absmax_partials_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    og_absmax_launch(x, n, out, (hipStream_t)stream);
     return og_launch_status();
 }
 
@@ -3294,7 +3313,7 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
                       int Tg, const int* dh, const int* dw, const int* src_tap,
                       int PH, int PW, int stride,
                       int OHf, int OWf, int osh, int osw, int ooh, int oow,
-                      int act, int y_prezeroed, int wt_packed, int math, float* ring, const float* xmax,
+                      int act, int y_prezeroed, int wt_packed, int math, float* ring, const float* xmax, float* ymax,
                       float* ws, long ws_floats, void* stream) {
     OG_ENTRY();
     PackArgs p;
@@ -3314,8 +3333,13 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
         int rc = og_launch_status();
         if (rc != OG_OK) return rc;
     }
-    if (thin) return run_thin(a, MT, s);
-    return v2 ? run_igemm2(a, s, y_prezeroed, ws, ws_floats) : run_igemm(a, s, y_prezeroed);
+    if (thin || !v2) {
+        a.ymax = nullptr;
+        const int rc = thin ? run_thin(a, MT, s) : run_igemm(a, s, y_prezeroed);
+        if (rc == OG_OK && ymax) og_absmax_launch(y, (long)N * a.M * OHf * OWf, ymax, s);
+        return rc == OG_OK ? og_launch_status() : rc;
+    }
+    return run_igemm2(a, s, y_prezeroed, ws, ws_floats, ymax);
 }
 
 // Data gradient of a stride-2 convolution whose four output parity phases have the same tap count

@@ -473,8 +473,9 @@ __device__ __forceinline__ void og_block_sum2(float& a, float& b, float* red) {
 template <int MODE>
 __global__ __launch_bounds__(256) void in_fwd_fused_kernel(
     const float* __restrict__ x, const float* __restrict__ residual, float* __restrict__ y,
-    float* __restrict__ mean, float* __restrict__ rstd, NormGeom gm, float eps) {
+    float* __restrict__ mean, float* __restrict__ rstd, NormGeom gm, float eps, float* __restrict__ amax) {
     __shared__ float red[8];
+    float vmax = 0.f;
     const int Co = MODE == OG_NORM_GLU ? gm.C / 2 : gm.C;
     const int plane = blockIdx.x;                       // n*Co + c
     const int n = plane / Co;
@@ -536,14 +537,17 @@ __global__ __launch_bounds__(256) void in_fwd_fused_kernel(
         }
         if (rp) { const float4 r = rp[i]; v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
         yp[i] = make_float4(v[0], v[1], v[2], v[3]);
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     }
+    if (amax) og_amax_atomic(og_block_max(vmax, red), amax, blockIdx.x);      // (slots zeroed by the caller)
 }
 
 template <int MODE>
 __global__ __launch_bounds__(256) void in_bwd_fused_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
-    const float* __restrict__ rstd, float* __restrict__ dx, NormGeom gm) {
+    const float* __restrict__ rstd, float* __restrict__ dx, NormGeom gm, float* __restrict__ amax) {
     __shared__ float red[8];
+    float vmax = 0.f;
     const int Co = MODE == OG_NORM_GLU ? gm.C / 2 : gm.C;
     const int plane = blockIdx.x;
     const int n = plane / Co;
@@ -590,7 +594,10 @@ __global__ __launch_bounds__(256) void in_bwd_fused_kernel(
         }
         oa[i] = make_float4(ra4[0], ra4[1], ra4[2], ra4[3]);
         if (MODE == OG_NORM_GLU) ob[i] = make_float4(rb4[0], rb4[1], rb4[2], rb4[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vmax = fmaxf(vmax, fmaxf(fabsf(ra4[j]), MODE == OG_NORM_GLU ? fabsf(rb4[j]) : 0.f));
     }
+    if (amax) og_amax_atomic(og_block_max(vmax, red), amax, blockIdx.x);      // (slots zeroed by the caller)
 }
 
 // dgamma[c] = bsums[2c+1], dbeta[c] = bsums[2c]   (BatchNorm only)
@@ -680,12 +687,14 @@ static inline void norm_sum_partials(const NormWs& ws, int G, hipStream_t s, flo
 
 extern "C" {
 
-// 1 if objgan_norm_forward / objgan_norm_backward with these sizes fill `amax` (the OG_AMAX_SLOTS = 1024 partial maxima of
+// Non-zero if objgan_norm_forward / objgan_norm_backward with these sizes fill `amax` (the OG_AMAX_SLOTS = 1024 partial maxima of
 // |y| resp. |dx|: the scale input of the fp16x2 convolutions, see objgan_absmax_partials) inside their own launches: the
 // plane-structured statistics + apply path with more than one statistics workgroup per group.  Host-only.
+// Returns 2 for the one-kernel InstanceNorm path: its workgroups add their maxima with integer atomicMax and no
+// earlier launch of the call could zero the slots -- the caller passes them zero-filled.
 int objgan_norm_amax_supported(int N, int C, int HW, int per_channel, int affine) {
     if (N <= 0 || C <= 0 || HW <= 0 || !norm_planes(N, C, HW)) return 0;
-    if (!per_channel && !affine && HW <= OG_IN_FUSED_MAX && !og_norm_nofuse()) return 0;      // one-kernel InstanceNorm
+    if (!per_channel && !affine && HW <= OG_IN_FUSED_MAX && !og_norm_nofuse()) return 2;      // one-kernel InstanceNorm
     return norm_partials(N, C, HW, per_channel) > 1 ? 1 : 0;
 }
 
@@ -721,11 +730,11 @@ int objgan_norm_forward(const float* x, float* y, const float* residual,
         // InstanceNorm (no affine parameters on this path): one workgroup owns its plane(s) end to end
         dim3 grid(N * Co);
         if (mode == OG_NORM_GLU)
-            hipLaunchKernelGGL((in_fwd_fused_kernel<OG_NORM_GLU>), grid, dim3(256), 0, s, x, residual, y, mean, rstd, gm, eps);
+            hipLaunchKernelGGL((in_fwd_fused_kernel<OG_NORM_GLU>), grid, dim3(256), 0, s, x, residual, y, mean, rstd, gm, eps, amax);
         else if (mode == OG_NORM_LRELU)
-            hipLaunchKernelGGL((in_fwd_fused_kernel<OG_NORM_LRELU>), grid, dim3(256), 0, s, x, residual, y, mean, rstd, gm, eps);
+            hipLaunchKernelGGL((in_fwd_fused_kernel<OG_NORM_LRELU>), grid, dim3(256), 0, s, x, residual, y, mean, rstd, gm, eps, amax);
         else
-            hipLaunchKernelGGL((in_fwd_fused_kernel<OG_NORM_NONE>), grid, dim3(256), 0, s, x, residual, y, mean, rstd, gm, eps);
+            hipLaunchKernelGGL((in_fwd_fused_kernel<OG_NORM_NONE>), grid, dim3(256), 0, s, x, residual, y, mean, rstd, gm, eps, amax);
         return og_launch_status();
     }
     const NormWs ws = norm_ws(sums, G, norm_partials(N, C, HW, per_channel));
@@ -802,11 +811,11 @@ int objgan_norm_backward(const float* x, const float* dy, const float* mean, con
         const int Co = mode == OG_NORM_GLU ? C / 2 : C;
         dim3 grid(N * Co);
         if (mode == OG_NORM_GLU)
-            hipLaunchKernelGGL((in_bwd_fused_kernel<OG_NORM_GLU>), grid, dim3(256), 0, s, x, dy, mean, rstd, dx, gm);
+            hipLaunchKernelGGL((in_bwd_fused_kernel<OG_NORM_GLU>), grid, dim3(256), 0, s, x, dy, mean, rstd, dx, gm, amax);
         else if (mode == OG_NORM_LRELU)
-            hipLaunchKernelGGL((in_bwd_fused_kernel<OG_NORM_LRELU>), grid, dim3(256), 0, s, x, dy, mean, rstd, dx, gm);
+            hipLaunchKernelGGL((in_bwd_fused_kernel<OG_NORM_LRELU>), grid, dim3(256), 0, s, x, dy, mean, rstd, dx, gm, amax);
         else
-            hipLaunchKernelGGL((in_bwd_fused_kernel<OG_NORM_NONE>), grid, dim3(256), 0, s, x, dy, mean, rstd, dx, gm);
+            hipLaunchKernelGGL((in_bwd_fused_kernel<OG_NORM_NONE>), grid, dim3(256), 0, s, x, dy, mean, rstd, dx, gm, amax);
         return og_launch_status();
     }
     const NormWs ws = norm_ws(bsums, G, norm_partials(N, C, HW, per_channel));

@@ -30,7 +30,7 @@ SIGNATURES = {
                           _c_int, _ptr, _ptr, _ptr,
                           _c_int, _c_int, _c_int,
                           _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                          _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _c_long, _ptr],
+                          _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _c_long, _ptr],
     "objgan_absmax_partials": [_ptr, _c_long, _ptr, _ptr],
     "objgan_reflect_ring_fold": [_ptr, _ptr, _c_long, _c_int, _c_int, _ptr],
     "objgan_conv_dgrad_s2_phases": [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,

@@ -104,7 +104,7 @@ _AMAX_SLOTS = 1024          # csrc/common.h OG_AMAX_SLOTS
 def _amax_wanted(numel):
     """does a producer of a tensor of this size emit its partial maxima?  (fp16x2 mode; tensors a launch above the
     FLOP threshold could read: anything of a few hundred thousand elements up)"""
-    return _MATH["mode"] == 4 and numel >= 262144 and not _FAKE_ABSMAX
+    return _MATH["mode"] == 4 and numel >= 262144
 
 
 def _amax_attach(t, amax):
@@ -116,7 +116,15 @@ def _amax_attach(t, amax):
         pass
 
 
-_FAKE_ABSMAX = {"on": 1} if _os.environ.get("OBJGAN_H2_FAKE_ABSMAX") == "1" else {}
+_ABSMAX_LOG = {} if _os.environ.get("OBJGAN_H2_LOG") == "1" else None
+if _ABSMAX_LOG is not None:
+    import atexit
+
+    def _dump_absmax_log():
+        import sys
+        for (shape, where), n in sorted(_ABSMAX_LOG.items(), key=lambda kv: -kv[1] * max(1, int(torch.tensor(kv[0][0]).prod()))):
+            sys.stderr.write("ABSMAX %6d x %-24s %s\n" % (n, shape, where))
+    atexit.register(_dump_absmax_log)
 
 
 def _absmax(t):
@@ -125,17 +133,16 @@ def _absmax(t):
     backward pass, the column operand of that layer's weight gradient) -- per HIP stream: a tensor shared by jobs on
     different streams (the images every discriminator reads) gets one pass per stream, ordered with that stream's
     kernels."""
-    if _FAKE_ABSMAX:                     # (development: timing without the maximum passes -- wrong scales)
-        one = _FAKE_ABSMAX.get(t.device)
-        if one is None:
-            one = _FAKE_ABSMAX[t.device] = torch.ones(_AMAX_SLOTS, dtype=_F32, device=t.device)
-        return one
     sid = torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
     cache = getattr(t, "_og_absmax", None)
     if cache is not None:
         got = cache.get(sid)
         if got is not None and got[0] == t._version:
             return got[1]
+    if _ABSMAX_LOG is not None:          # (development: who still needs a pass?)
+        import traceback
+        key = (tuple(t.shape), " < ".join("%s:%d" % (f.name, f.lineno) for f in traceback.extract_stack(limit=7)[:-1][::-1][:5]))
+        _ABSMAX_LOG[key] = _ABSMAX_LOG.get(key, 0) + 1
     out = torch.empty(_AMAX_SLOTS, dtype=_F32, device=t.device)
     src = t if (t.is_contiguous() and not (t.data_ptr() & 15)) else t.contiguous().clone()
     _lib.call("objgan_absmax_partials", _p(src), src.numel(), _p(out), _stream())
@@ -254,7 +261,8 @@ def _nhwc_floats(N, C, H, W):
 
 
 def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, transpose,
-           dh, dw, src_tap, PH, PW, stride, OHf, OWf, osh, osw, ooh, oow, act, y_prezeroed=0, ring=None, cache=True):
+           dh, dw, src_tap, PH, PW, stride, OHf, OWf, osh, osw, ooh, oow, act, y_prezeroed=0, ring=None, cache=True,
+           ymax=None):
     Tg = len(dh)
     M = Cin if transpose else Cout
     math = _call_math(2.0 * M * C * Tg * N * PH * PW)
@@ -287,7 +295,7 @@ def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, tran
     _lib.call("objgan_conv_igemm", _p(x), _p(w), _p(bias), _p(y), _p(wt),
               N, C, H, W, int(upsample), int(pad_mode), Cout, Cin, Torig, int(transpose),
               Tg, _iarr(dh), _iarr(dw), _iarr(src_tap), PH, PW, stride,
-              OHf, OWf, osh, osw, ooh, oow, act, int(y_prezeroed), packed, math, _p(ring), _p(xmax),
+              OHf, OWf, osh, osw, ooh, oow, act, int(y_prezeroed), packed, math, _p(ring), _p(xmax), _p(ymax),
               _p(ws), nws, _stream())
 
 
@@ -350,8 +358,14 @@ def _conv_fwd(x, w, bias, stride, pad, refl, upsample, act):
     dh = [kh - pad for kh in range(k) for kw in range(k)]
     dw = [kw - pad for kh in range(k) for kw in range(k)]
     st = list(range(k * k))
+    # a convolution with a fused LeakyReLU / ReLU feeds the next convolution directly (discriminator encoders): its
+    # epilogue leaves the partial maxima of y for that consumer's fp16x2 scale
+    ym = (torch.zeros(_AMAX_SLOTS, dtype=_F32, device=x.device)
+          if (act in ("lrelu", "relu") and _amax_wanted(y.numel())) else None)
     _igemm(x, w, bias, y, N, Cin, H, W, upsample, refl, Cout, Cin, k * k, 0,
-           dh, dw, st, OH, OW, stride, OH, OW, 1, 1, 0, 0, _ACT[act])
+           dh, dw, st, OH, OW, stride, OH, OW, 1, 1, 0, 0, _ACT[act], ymax=ym)
+    if ym is not None:
+        _amax_attach(y, ym)
     return y
 
 
@@ -775,9 +789,10 @@ class _NormActFn(torch.autograd.Function):
         ws = torch.empty(nst + 2 * G, dtype=_F32, device=x.device)
         sums, mean, rstd = ws[:nst], ws[nst:nst + G], ws[nst + G:]
         residual = _c(residual) if residual is not None else None
-        emit = _amax_wanted(y.numel()) and bool(
-            _lib.load().objgan_norm_amax_supported(N, C, HW, int(per_channel), int(gamma is not None)))
-        am = torch.empty(_AMAX_SLOTS, dtype=_F32, device=x.device) if emit else None
+        emit = _lib.load().objgan_norm_amax_supported(N, C, HW, int(per_channel), int(gamma is not None)) \
+            if _amax_wanted(y.numel()) else 0
+        # (2: the one-kernel InstanceNorm adds its maxima atomically into slots the caller zeroed)
+        am = (torch.zeros if emit == 2 else torch.empty)(_AMAX_SLOTS, dtype=_F32, device=x.device) if emit else None
         _lib.call("objgan_norm_forward", _p(x), _p(y), _p(residual), _p(gamma), _p(beta),
                   _p(running_mean), _p(running_var), _p(sums), _p(mean), _p(rstd),
                   N, C, HW, int(per_channel), _NORM_MODE[mode], float(eps), float(momentum), _p(am), _stream())
@@ -800,7 +815,8 @@ class _NormActFn(torch.autograd.Function):
         if gamma is not None:
             dgamma = torch.empty_like(gamma)
             dbeta = torch.empty_like(beta)
-        am = torch.empty(_AMAX_SLOTS, dtype=_F32, device=x.device) if (emit and _amax_wanted(dx.numel())) else None
+        am = ((torch.zeros if emit == 2 else torch.empty)(_AMAX_SLOTS, dtype=_F32, device=x.device)
+              if (emit and _amax_wanted(dx.numel())) else None)
         _lib.call("objgan_norm_backward", _p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta),
                   _p(bsums), _p(dx), _p(dgamma), _p(dbeta), N, C, HW, per_channel, mode, _p(am), _stream())
         if am is not None:

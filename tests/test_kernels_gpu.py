@@ -973,6 +973,8 @@ def test_producers_emit_the_maxima_a_separate_pass_would_find(dev, case):
         w = (torch.randn(32 + Co, Co, 3, 3, generator=g) * 0.05).to(dev).requires_grad_()
         xin = y.detach().requires_grad_()
         z = ops.conv2d(xin, w, None, 1, 1, "zeros", False, "lrelu")
+        zm = getattr(z, "_og_absmax", None)             # a fused LeakyReLU output feeds the next convolution: epilogue maxima
+        assert zm is not None and float(list(zm.values())[0][1].max()) == float(z.detach().abs().max())
         z.backward(torch.randn(z.shape, generator=g).to(dev) * 1e-3)
         torch.cuda.synchronize()
         assert torch.isfinite(xin.grad).all() and torch.isfinite(w.grad).all()

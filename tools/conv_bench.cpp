@@ -94,7 +94,7 @@ int main(int argc, char** argv) {
         auto fwd = [&]() {
             if (g_math == 4) objgan_absmax_partials(dx, (long)nx, mxx, st);       // (the weight gradient reuses it)
             int rc = objgan_conv_igemm(dx, dw, nullptr, dy, wt, sh.N, sh.Cin, sh.H, sh.W, sh.up, sh.refl, sh.Cout, sh.Cin, T, 0,
-                                       T, dh.data(), dwv.data(), stp.data(), OH, OW, sh.s, OH, OW, 1, 1, 0, 0, 0, 0, 0, g_math, nullptr, mxx, wsb, nwsb, st);
+                                       T, dh.data(), dwv.data(), stp.data(), OH, OW, sh.s, OH, OW, 1, 1, 0, 0, 0, 0, 0, g_math, nullptr, mxx, nullptr, wsb, nwsb, st);
             if (rc != 1) { fprintf(stderr, "fwd rc=%d\n", rc); exit(1); }
         };
         auto dgrad = [&]() {
@@ -104,7 +104,7 @@ int main(int argc, char** argv) {
                 std::vector<int> h2(T), w2(T);
                 for (int kh = 0; kh < sh.k; ++kh) for (int kw = 0; kw < sh.k; ++kw) { h2[kh * sh.k + kw] = pe - kh; w2[kh * sh.k + kw] = pe - kw; }
                 int rc = objgan_conv_igemm(dg, dw, nullptr, dgx, wt, sh.N, sh.Cout, OH, OW, 0, 0, sh.Cout, sh.Cin, T, 1,
-                                           T, h2.data(), w2.data(), stp.data(), TH, TW, 1, TH, TW, 1, 1, 0, 0, 0, 0, 0, g_math, nullptr, mxg, wsb, nwsb, st);
+                                           T, h2.data(), w2.data(), stp.data(), TH, TW, 1, TH, TW, 1, 1, 0, 0, 0, 0, 0, g_math, nullptr, mxg, nullptr, wsb, nwsb, st);
                 if (rc != 1) { fprintf(stderr, "dgrad rc=%d\n", rc); exit(1); }
             } else if (sh.k % 2 == 0 && LH % 2 == 0 && sh.Cin > 32) {
                 std::vector<int> h2, w2, s2;
@@ -126,7 +126,7 @@ int main(int argc, char** argv) {
                         }
                     const int PHg = (LH - ph + 1) / 2, PWg = (LW - pw + 1) / 2;
                     int rc = objgan_conv_igemm(dg, dw, nullptr, dgx, wt, sh.N, sh.Cout, OH, OW, 0, 0, sh.Cout, sh.Cin, T, 1,
-                                               (int)h2.size(), h2.data(), w2.data(), s2.data(), PHg, PWg, 1, LH, LW, 2, 2, ph, pw, 0, 1, 0, g_math, nullptr, mxg, wsb, nwsb, st);
+                                               (int)h2.size(), h2.data(), w2.data(), s2.data(), PHg, PWg, 1, LH, LW, 2, 2, ph, pw, 0, 1, 0, g_math, nullptr, mxg, nullptr, wsb, nwsb, st);
                     if (rc != 1) { fprintf(stderr, "dgrad2 rc=%d\n", rc); exit(1); }
                 }
             }
