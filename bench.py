@@ -522,8 +522,10 @@ def main():
                 traffic = None          # HBM bytes / launch from the committed rocprofv3 --pmc passes
                 if os.path.exists(PMC_TRAFFIC_JSON):
                     try:
-                        kern = json.load(open(PMC_TRAFFIC_JSON)).get("kernels", {})
-                        ent = kern.get(name)
+                        pmc = json.load(open(PMC_TRAFFIC_JSON))
+                        same = (pmc.get("conv_math") == args.math and pmc.get("per_gpu_batch") == args.batch
+                                and args.workload == "stage3_obj")       # the run the counters were collected on
+                        ent = pmc.get("kernels", {}).get(name) if same else None
                         traffic = ent["hbm_bytes_per_launch"] if ent else None
                     except (ValueError, KeyError, OSError):
                         traffic = None

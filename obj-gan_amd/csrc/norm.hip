@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256) void norm_partials_sum_kernel(NormWs ws, int G
 }
 
 // ---- statistics ------------------------------------------------------------------------
-// grid = (G, S).  sums[g*2 + {0,1}] must be zero on entry.
+// grid = (G, S).  Every workgroup stores its partial pair into its own slot; norm_partials_sum_kernel adds the slots in
+// order (sums is fully written there: nothing to zero, no atomics).
 __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict__ x,
                                                          NormWs ws, NormGeom gm) {
     __shared__ float red[16];

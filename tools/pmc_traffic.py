@@ -52,7 +52,8 @@ def main(prefix, out):
         wb = fw * 1024.0 * w / max(nw, 1)
         kernels[name] = {"launches": max(nf, nw), "fetch_bytes_per_launch": round(fb),
                          "write_bytes_per_launch": round(wb), "hbm_bytes_per_launch": round(fb + wb)}
-    json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py "
+    json.dump({"conv_math": "fp16x2", "per_gpu_batch": 16,      # the bench defaults tools/pmc_bench.sh runs
+               "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py "
                          "(tools/pmc_bench.sh)",
                "calibration": {"known_bytes": KNOWN, "fetch_factor_stream_b128": f_stream,
                                "fetch_factor_gather_b32": f_gather, "write_factor_b32": f_write,
