@@ -2687,6 +2687,8 @@ OG_KNOB(og_ablate, "OG_ABLATE", 0)                 // development builds: IgemmA
 OG_KNOB(og_kgroup_s1, "OG_KGROUP_S1", 4)           // chunks per K group (og_kstep), stride-1 multi-tap launches (0: tap-major)
 OG_KNOB(og_kgroup_s2, "OG_KGROUP_S2", 0)           // ... stride-2 forward launches
 OG_KNOB(og_kgroup_ph, "OG_KGROUP_PH", 4)           // ... the four-phase stride-2 data gradient / up-convolution
+OG_KNOB(og_h2_nw8_tm, "OG_H2_NW8_TM", 4)           // fp16x2: 8-wave workgroups from this block-row height on
+OG_KNOB(og_h2_pen_pct, "OG_H2_PEN_PCT", 100)        // fp16x2: re-read penalty of short block rows in og_row_plan, % of the table
 OG_KNOB(og_x3_wgrad3_maxtm, "OG_X3_WGRAD3_MAXTM", 2)   // bf16x3: register-fragment weight gradient up to this tile height
 static int og_igemm_tmmax() { const int v = og_igemm_tmmax_raw(); return (v < 1 || v > 8) ? 8 : v; }
 
@@ -2780,7 +2782,8 @@ static double og_rounds(long blocks) {
     if (blocks < 1024) return (double)og_cdiv(blocks, 256);
     return (double)blocks / 256.0;
 }
-static void og_row_plan(int groups, int tiles_n, int tall, int* TM_out, int* full_rows_out, int* rest_out) {
+static void og_row_plan(int groups, int tiles_n, int tall, int* TM_out, int* full_rows_out, int* rest_out,
+                        int pen_pct = 100) {
     int tmmax = og_igemm_tmmax();
     if (tmmax > 7) tmmax = 7;
     int bt = 1;
@@ -2794,8 +2797,10 @@ static void og_row_plan(int groups, int tiles_n, int tall, int* TM_out, int* ful
         double best = -1;
         for (int tm = 1; tm <= tmmax && tm <= groups; ++tm) {
             const int full = groups / tm, rest = groups - full * tm;
-            double cost = og_rounds((long)full * tiles_n) * tm * pen[tm]
-                        + (rest ? og_rounds(tiles_n) * rest * pen[rest] + 0.3 : 0.0);
+            const double pt = 1.0 + (pen[tm] - 1.0) * pen_pct / 100.0;
+            const double pr = rest ? 1.0 + (pen[rest] - 1.0) * pen_pct / 100.0 : 0.0;
+            double cost = og_rounds((long)full * tiles_n) * tm * pt
+                        + (rest ? og_rounds(tiles_n) * rest * pr + 0.3 : 0.0);
             if (best < 0 || cost < best - 1e-9 || (cost < best + 1e-9 && tm > bt)) { best = cost; bt = tm; }
         }
     }
@@ -2945,13 +2950,14 @@ static Igemm2Plan igemm2_plan(const IgemmArgs& a, int y_prezeroed) {
     // layers 179 vs 158 TFLOP/s; with 8 waves the block rows are as tall as the row count allows)
     p.nw = 4;
     const int tm_tall = og_cdiv(groups, og_cdiv(groups, 7));
-    if ((a.math == 2 || a.math == 4 || (a.math == 1 && a.nhwc)) && tm_tall >= 4 && og_nw8_min() > 0 &&
+    if ((a.math == 2 || a.math == 4 || (a.math == 1 && a.nhwc)) && tm_tall >= (a.math == 4 ? og_h2_nw8_tm() : 4) &&
+        og_nw8_min() > 0 &&
         (long)og_cdiv(groups, 7) * og_cdiv(Npix, 256) * nph >= og_nw8_min()) p.nw = 8;
     p.tiles_n = og_cdiv(Npix, 32 * p.nw);
     // (Carrying the 2 / 4 rows that 194 / 388 channels have beyond a multiple of 32 on the VALU next to the
     // MFMA stream -- as the weight-gradient kernels do -- was measured here in round 2 and bought nothing:
     // 106.0 vs 107.8 TFLOP/s on res1_128; interleaving the FMAs with the MFMAs cost 20 %.)
-    og_row_plan(groups, p.tiles_n * nph, p.nw == 8, &p.TM, &p.full_rows, &p.rest);
+    og_row_plan(groups, p.tiles_n * nph, p.nw == 8, &p.TM, &p.full_rows, &p.rest, a.math == 4 ? og_h2_pen_pct() : 100);
     const int tiles = (p.full_rows + (p.rest ? 1 : 0)) * p.tiles_n;
     const int nk = a.math == 1 ? a.Krow / 32 : a.Kpad / 16;      // loop iterations of the kernel
     p.full_cover = ((a.osh == 1 && a.osw == 1 && a.PH == a.OHf && a.PW == a.OWf) || a.ring != nullptr) ? 1 : 0;

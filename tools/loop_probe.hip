@@ -256,11 +256,14 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel(const Args a) {
 // v_mfma_f32_32x32x16_f16 (same rate as the bf16 MFMA), fp32 accumulation, exact power-of-two scales undone in the epilogue.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define MFMAH(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
-struct Args16 { const float* B; const _Float16* A; float* C; int M, N, Cb, T, W; float sb, inv; };
+struct Args16 { const float* B; const _Float16* A; float* C; int M, N, Cb, T, W; float sb, inv; const _Float16* Bs; };
 
-template <int TM, int NW, int ABL = 0>
+// BSRC 1: the pixel operand arrives PRE-SPLIT and channel-blocked by 8, [Cb/8][h | l][N][8] fp16 (x * 2^s = h + l done by the
+// producer): per lane and K step two 16-byte loads, the 32 pixels of a half-wave read 512 contiguous bytes, no VALU work.
+// NG: 32-pixel groups per wave (every row fragment read from LDS feeds NG MFMAs).
+template <int TM, int NW, int NG = 1, int BSRC = 0>
 __global__ __launch_bounds__(64 * NW) void loop16_kernel(const Args16 a) {
-    constexpr int NT = 64 * NW, BM = 32 * TM, BN = 32 * NW, LD = 20, PIECES = 4, ABYTES = 64;
+    constexpr int NT = 64 * NW, BM = 32 * TM, BN = 32 * NW * NG, LD = 20, PIECES = 4, ABYTES = 64;
     constexpr int NA4 = BM * PIECES, NA_PER = (NA4 + NT - 1) / NT, TILE = BM * LD;
     __shared__ __attribute__((aligned(16))) float lds[3 * TILE];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -270,21 +273,35 @@ __global__ __launch_bounds__(64 * NW) void loop16_kernel(const Args16 a) {
     const int tile_m = wg % tiles_m, tile_n = wg / tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int K = a.T * a.Cb, Krow = 2 * K;
-    __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, (int)((unsigned)a.Cb * a.N * 4u), OG_BUF_FLAGS);
+    __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(BSRC ? (void*)a.Bs : (void*)a.B, 0, (int)((unsigned)a.Cb * a.N * 4u), OG_BUF_FLAGS);
     __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (int)((unsigned)a.M * Krow * 2u), OG_BUF_FLAGS);
-    const int pix = n0 + wid * 32 + lcol;
-    const int N4 = a.N * 4;
+    const int pix = n0 + wid * 32 * NG + lcol;
+    const int N4 = a.N * 4, N16 = a.N * 16;
     int t_ld = 0, cb_ld = 0;
-    unsigned bvoff;
+    unsigned bvoff[NG];
     auto tap_geometry = [&](int t) {
-        const int p = pix + ((t & 3) - 1) + ((t >> 2) - 1) * a.W;
-        bvoff = ((unsigned)p < (unsigned)a.N) ? (unsigned)(lrow * 8) * (unsigned)N4 + (unsigned)p * 4u : OG_OOB;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int p = pix + g * 32 + ((t & 3) - 1) + ((t >> 2) - 1) * a.W;
+            if (BSRC) bvoff[g] = ((unsigned)p < (unsigned)a.N) ? (unsigned)(lrow * 2) * (unsigned)N16 + (unsigned)p * 16u : OG_OOB;
+            else bvoff[g] = ((unsigned)p < (unsigned)a.N) ? (unsigned)(lrow * 8) * (unsigned)N4 + (unsigned)p * 4u : OG_OOB;
+        }
     };
     tap_geometry(0);
-    auto load_b = [&](float (&rb)[8]) {
+    struct BReg { f32x4 v[2]; };          // 8 fp32 values, or the h and l fragments (8 fp16 each)
+    auto load_b = [&](BReg (&rb)[NG]) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, bvoff, (cb_ld + i) * N4, 0));
+        for (int g = 0; g < NG; ++g) {
+            if (BSRC) {
+                const int so = __builtin_amdgcn_readfirstlane((cb_ld >> 3) * 2 * N16);
+                rb[g].v[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, bvoff[g], so, 0));
+                rb[g].v[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, bvoff[g], so + N16, 0));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    rb[g].v[i >> 2][i & 3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, bvoff[g], (cb_ld + i) * N4, 0));
+            }
+        }
         cb_ld += 16;
         if (cb_ld >= a.Cb) { cb_ld = 0; t_ld += 1; if (t_ld < a.T) tap_geometry(t_ld); }
     };
@@ -310,20 +327,28 @@ __global__ __launch_bounds__(64 * NW) void loop16_kernel(const Args16 a) {
             if (NA4 % NT == 0 || alds[i] >= 0) *reinterpret_cast<f32x4*>(As + alds[i]) = ra[i];
     };
     const int nk = K / 16;
-    f32x16 acc[TM];
+    f32x16 acc[NG][TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    float rb0[8], rb1[8], rb2[8];
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][i][r] = 0.f;
+    BReg rb0[NG], rb1[NG], rb2[NG];
     f16x8 ah[TM], al[TM];
     const int frag_off = lcol * (LD * 4) + lrow * 16;
     const float sb = a.sb;
-    auto mma = [&](const float (&rb)[8], int cur, auto&& mid) {
-        f16x8 bh, bl;
-        float sc[8];
+    auto mma = [&](const BReg (&rb)[NG], int cur, auto&& mid) {
+        f16x8 bh[NG], bl[NG];
+        float sc[NG][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { sc[j] = rb[j] * sb; bh[j] = (_Float16)sc[j]; }
+        for (int g = 0; g < NG; ++g) {
+            if (BSRC) { bh[g] = __builtin_bit_cast(f16x8, rb[g].v[0]); bl[g] = __builtin_bit_cast(f16x8, rb[g].v[1]); }
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { sc[g][j] = rb[g].v[j >> 2][j & 3] * sb; bh[g][j] = (_Float16)sc[g][j]; }
+            }
+        }
         const char* T = reinterpret_cast<const char*>(lds + cur * TILE) + frag_off;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -331,17 +356,27 @@ __global__ __launch_bounds__(64 * NW) void loop16_kernel(const Args16 a) {
             ah[i] = *reinterpret_cast<const f16x8*>(T + i * 32 * LD * 4);
         }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) MFMAH(al[i], bh, acc[i]);
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) MFMAH(al[i], bh[g], acc[g][i]);
         __builtin_amdgcn_sched_barrier(0);
         mid();
         __builtin_amdgcn_sched_barrier(0);
+        if (!BSRC) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bl[j] = (_Float16)og_sub(sc[j], (float)bh[j]);
+            for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) MFMAH(ah[i], bh, acc[i]);
-        interleave<TM, (16 + TM - 1) / TM>();
+                for (int j = 0; j < 8; ++j) bl[g][j] = (_Float16)og_sub(sc[g][j], (float)bh[g][j]);
+        }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) MFMAH(ah[i], bl, acc[i]);
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) MFMAH(ah[i], bh[g], acc[g][i]);
+        if (!BSRC) interleave<TM, (16 + TM - 1) / TM>();
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) MFMAH(ah[i], bl[g], acc[g][i]);
     };
     load_a(0); store_a(0); load_a(1);
     load_b(rb0); load_b(rb1);
@@ -360,14 +395,17 @@ __global__ __launch_bounds__(64 * NW) void loop16_kernel(const Args16 a) {
     }
     if (ks < nk) { mma(rb0, 0, [&]() { store_a(1); }); __syncthreads(); }
     if (ks + 1 < nk) mma(rb1, 1, [] {});
-    float* cb = a.C + pix;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int g = 0; g < NG; ++g) {
+        float* cb = a.C + pix + g * 32;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-            cb[(size_t)m * a.N] = acc[i][r] * a.inv;
-        }
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                cb[(size_t)m * a.N] = acc[g][i][r] * a.inv;
+            }
+    }
 }
 
 static unsigned g_seed = 12345u;
@@ -411,12 +449,12 @@ static void run(const char* name, const Args& a, const std::vector<float>& hA, c
     fflush(stdout);
 }
 
-template <int TM, int NW>
+template <int TM, int NW, int NG = 1, int BSRC = 0>
 static void run16(const char* name, const Args16& a, const std::vector<float>& hA, const std::vector<float>& hB, int iters) {
-    const int blocks = (a.M / (32 * TM)) * (a.N / (32 * NW));
+    const int blocks = (a.M / (32 * TM)) * (a.N / (32 * NW * NG));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipMemset(a.C, 0xff, (size_t)a.M * a.N * 4));
-    hipLaunchKernelGGL((loop16_kernel<TM, NW>), dim3(blocks), dim3(64 * NW), 0, 0, a);
+    hipLaunchKernelGGL((loop16_kernel<TM, NW, NG, BSRC>), dim3(blocks), dim3(64 * NW), 0, 0, a);
     CK(hipDeviceSynchronize());
     std::vector<float> hC((size_t)a.M * a.N);
     CK(hipMemcpy(hC.data(), a.C, hC.size() * 4, hipMemcpyDeviceToHost));
@@ -435,13 +473,13 @@ static void run16(const char* name, const Args16& a, const std::vector<float>& h
     float best = 1e30f, sum = 0;
     for (int rep = 0; rep < iters; ++rep) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((loop16_kernel<TM, NW>), dim3(blocks), dim3(64 * NW), 0, 0, a);
+        hipLaunchKernelGGL((loop16_kernel<TM, NW, NG, BSRC>), dim3(blocks), dim3(64 * NW), 0, 0, a);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep >= 2) { best = std::min(best, ms); sum += ms; }
     }
     const double fl = 2.0 * a.M * (double)K * a.N;
-    printf("%-34s TM %d NW %d fp16x2 (3 MFMAs)      avg %7.3f ms %6.1f TF  best %6.1f TF  rel-l2 err %.2e\n", name, TM, NW, sum / (iters - 2),
+    printf("%-34s TM %d NW %d NG %d BSRC %d fp16x2  avg %7.3f ms %6.1f TF  best %6.1f TF  rel-l2 err %.2e\n", name, TM, NW, NG, BSRC, sum / (iters - 2),
            fl / (sum / (iters - 2) * 1e-3) * 1e-12, fl / (best * 1e-3) * 1e-12, sqrt(num / den));
     fflush(stdout);
 }
@@ -490,6 +528,17 @@ int main(int argc, char** argv) {
     _Float16* dA16; CK(hipMalloc(&dA16, bank16.size() * 2)); CK(hipMemcpy(dA16, bank16.data(), bank16.size() * 2, hipMemcpyHostToDevice));
     Args16 a16; a16.B = dB; a16.A = dA16; a16.C = dC; a16.M = a.M; a16.N = a.N; a16.Cb = a.Cb; a16.T = a.T; a16.W = a.W;
     a16.sb = 8192.0f; a16.inv = 1.0f / (8192.0f * 262144.0f);
+    // pre-split pixel operand [Cb/8][h | l][N][8]: x * 2^13 = h + l
+    std::vector<_Float16> hBs16((size_t)a.Cb * a.N * 2);
+    for (int c = 0; c < a.Cb; ++c)
+        for (int n = 0; n < a.N; ++n) {
+            const float v = hB[(size_t)c * a.N + n] * 8192.0f;
+            const _Float16 h = (_Float16)v; const _Float16 l = (_Float16)(v - (float)h);
+            hBs16[(((size_t)(c >> 3) * 2 + 0) * a.N + n) * 8 + (c & 7)] = h;
+            hBs16[(((size_t)(c >> 3) * 2 + 1) * a.N + n) * 8 + (c & 7)] = l;
+        }
+    _Float16* dBs16; CK(hipMalloc(&dBs16, hBs16.size() * 2)); CK(hipMemcpy(dBs16, hBs16.data(), hBs16.size() * 2, hipMemcpyHostToDevice));
+    a16.Bs = dBs16;
     const int iters = argc > 1 ? atoi(argv[1]) : 12;
     for (int pass = 0; pass < 2; ++pass) {
         run<6, 8, 1, 0>("bf16x3 (6 MFMAs)", a, hA, hB, iters);
@@ -498,6 +547,18 @@ int main(int argc, char** argv) {
         run16<3, 4>("fp16x2", a16, hA, hB, iters);
         run16<3, 8>("fp16x2", a16, hA, hB, iters);
         run16<6, 4>("fp16x2", a16, hA, hB, iters);
+        run16<6, 8, 1, 1>("fp16x2 pre-split B", a16, hA, hB, iters);
+        run16<3, 4, 1, 1>("fp16x2 pre-split B", a16, hA, hB, iters);
+        run16<3, 8, 1, 1>("fp16x2 pre-split B", a16, hA, hB, iters);
+        run16<6, 4, 1, 1>("fp16x2 pre-split B", a16, hA, hB, iters);
+        run16<3, 4, 2, 0>("fp16x2 2 pixel groups", a16, hA, hB, iters);
+        run16<3, 4, 2, 1>("fp16x2 2 groups, pre-split B", a16, hA, hB, iters);
+        run16<3, 8, 2, 1>("fp16x2 2 groups, pre-split B", a16, hA, hB, iters);
+        run16<6, 4, 2, 1>("fp16x2 2 groups, pre-split B", a16, hA, hB, iters);
+        run16<2, 4, 2, 1>("fp16x2 2 groups, pre-split B", a16, hA, hB, iters);
+        run16<1, 4, 2, 1>("fp16x2 2 groups, pre-split B", a16, hA, hB, iters);
+        run16<1, 4, 1, 0>("fp16x2", a16, hA, hB, iters);
+        run16<1, 4, 1, 1>("fp16x2 pre-split B", a16, hA, hB, iters);
     }
     return 0;
 }
