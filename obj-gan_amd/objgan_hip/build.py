@@ -63,8 +63,22 @@ def needs_build():
 
 
 def build(force=False, verbose=True):
+    """Compile and link; concurrent callers (one process per GPU starting at once on a tree without the library)
+    serialise on a lock file -- the first builds, the others find the library fresh."""
     if not force and not needs_build():
         return LIB_PATH
+    import fcntl
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return LIB_PATH
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
     try:
         force = force or open(FLAGS_STAMP).read() != _flags_line()
     except OSError:
