@@ -107,6 +107,23 @@ def _amax_wanted(numel):
     return _MATH["mode"] == 4 and numel >= 262144
 
 
+_ZERO_ROWS = {}             # HIP stream -> [chunk of zeroed slot rows, rows handed out]
+_ZERO_CHUNK = 32
+
+
+def _amax_zeroed(device):
+    """1024 zeroed maximum slots for a producer that adds into them atomically: a row of a chunk zero-filled by ONE
+    launch per 32 rows (it was one fill launch per producer call).  Per HIP stream: the fill and the producers that use
+    its rows are ordered on the stream that asked; a row is handed out once and lives as long as its tensor does."""
+    sid = torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    ent = _ZERO_ROWS.get(sid)
+    if ent is None or ent[1] >= _ZERO_CHUNK or ent[0].device != device:
+        ent = _ZERO_ROWS[sid] = [torch.zeros((_ZERO_CHUNK, _AMAX_SLOTS), dtype=_F32, device=device), 0]
+    row = ent[0][ent[1]]
+    ent[1] += 1
+    return row
+
+
 def _amax_attach(t, amax):
     """the producer of `t` filled `amax` (its partial maxima) on the current stream: what _absmax(t) returns from now on"""
     sid = torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
@@ -360,8 +377,7 @@ def _conv_fwd(x, w, bias, stride, pad, refl, upsample, act):
     st = list(range(k * k))
     # a convolution with a fused LeakyReLU / ReLU feeds the next convolution directly (discriminator encoders): its
     # epilogue leaves the partial maxima of y for that consumer's fp16x2 scale
-    ym = (torch.zeros(_AMAX_SLOTS, dtype=_F32, device=x.device)
-          if (act in ("lrelu", "relu") and _amax_wanted(y.numel())) else None)
+    ym = _amax_zeroed(x.device) if (act in ("lrelu", "relu") and _amax_wanted(y.numel())) else None
     _igemm(x, w, bias, y, N, Cin, H, W, upsample, refl, Cout, Cin, k * k, 0,
            dh, dw, st, OH, OW, stride, OH, OW, 1, 1, 0, 0, _ACT[act], ymax=ym)
     if ym is not None:
@@ -792,7 +808,7 @@ class _NormActFn(torch.autograd.Function):
         emit = _lib.load().objgan_norm_amax_supported(N, C, HW, int(per_channel), int(gamma is not None)) \
             if _amax_wanted(y.numel()) else 0
         # (2: the one-kernel InstanceNorm adds its maxima atomically into slots the caller zeroed)
-        am = (torch.zeros if emit == 2 else torch.empty)(_AMAX_SLOTS, dtype=_F32, device=x.device) if emit else None
+        am = (_amax_zeroed(x.device) if emit == 2 else torch.empty(_AMAX_SLOTS, dtype=_F32, device=x.device)) if emit else None
         _lib.call("objgan_norm_forward", _p(x), _p(y), _p(residual), _p(gamma), _p(beta),
                   _p(running_mean), _p(running_var), _p(sums), _p(mean), _p(rstd),
                   N, C, HW, int(per_channel), _NORM_MODE[mode], float(eps), float(momentum), _p(am), _stream())
@@ -815,7 +831,7 @@ class _NormActFn(torch.autograd.Function):
         if gamma is not None:
             dgamma = torch.empty_like(gamma)
             dbeta = torch.empty_like(beta)
-        am = ((torch.zeros if emit == 2 else torch.empty)(_AMAX_SLOTS, dtype=_F32, device=x.device)
+        am = ((_amax_zeroed(x.device) if emit == 2 else torch.empty(_AMAX_SLOTS, dtype=_F32, device=x.device))
               if (emit and _amax_wanted(dx.numel())) else None)
         _lib.call("objgan_norm_backward", _p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta),
                   _p(bsums), _p(dx), _p(dgamma), _p(dbeta), N, C, HW, per_channel, mode, _p(am), _stream())

@@ -1,9 +1,11 @@
 #!/bin/bash
-# whole-step A/B of the number of HIP streams the discriminator updates / generator-loss terms run on
+# same-box A/B at the step level (development build): side-stream count and the split-K target of the small-map launches
 mkdir -p gpurun_out; export TMPDIR=/tmp
-for n in 1 2 3; do
-  ( timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-kernel-timing --d-streams $n ) > gpurun_out/r3o_bench_ds$n.log 2>&1
-  grep "^{" gpurun_out/r3o_bench_ds$n.log | python -c "
-import json,sys
-r=json.loads(sys.stdin.readline()); print('d_streams', r['config']['d_streams_timed_pass'], r['value'], r['ms_per_step'])"
-done
+run() { echo -n "[$*]  "; env $1 timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-side-configs $2 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'; }
+run X=0 ""
+run X=0 "--d-streams 4"
+run X=0 "--d-streams 5"
+run OG_SPLIT_TARGET=0 ""
+run OG_SPLIT_TARGET=256 ""
+run X=0 "--d-streams 2"
+run X=0 ""
