@@ -225,14 +225,16 @@ def cpu_baseline(sample_batch=16, timed_steps=3, timeout_s=630):
 
 
 def side_configs(steps=6, warmup=2, timeout_s=240):
-    """Three short side records of the default N = 1 run, each a child `bench.py` on the same GPU after the headline is
+    """Four short side records of the default N = 1 run, each a child `bench.py` on the same GPU after the headline is
     measured (they are NOT the metric): the same step on the true fp32 MFMA (`--math fp32`, the arithmetic of rounds
-    1-2), on the bf16 MFMA with exactly split operands (`--math bf16x3`, round 3's) and BASELINE config 5
-    (`--math bf16 --batch 32`: bf16 matrix-core inputs, fp32 accumulation)."""
+    1-2), on the bf16 MFMA with exactly split operands (`--math bf16x3`, round 3's), BASELINE config 5
+    (`--math bf16 --batch 32`: bf16 matrix-core inputs, fp32 accumulation), and the default step with every minibatch
+    crossing PCIe inside the timed region (`--host-batches`: the reference's host hand-over, prefetched)."""
     import subprocess
     out = {}
     for key, extra in (("fp32_mfma_b16", ["--math", "fp32"]), ("bf16x3_b16", ["--math", "bf16x3"]),
-                       ("config5_bf16_b32", ["--math", "bf16", "--batch", "32"])):
+                       ("config5_bf16_b32", ["--math", "bf16", "--batch", "32"]),
+                       ("pcie_inclusive_b16", ["--host-batches", "--no-kernel-timing"])):
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup),
                "--no-cpu-baseline", "--no-side-configs"] + extra
         try:
@@ -241,6 +243,8 @@ def side_configs(steps=6, warmup=2, timeout_s=240):
             r = json.loads(line)
             out[key] = {k: r.get(k) for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype")}
             out[key]["per_gpu_batch"] = r["config"]["per_gpu_batch"]
+            if "host_batches" in r["config"]:
+                out[key]["host_batches"] = r["config"]["host_batches"]
             if "roofline" in r:
                 out[key]["roofline"] = {k: r["roofline"].get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "traffic")}
             if "conv_total" in r:
@@ -364,6 +368,10 @@ def main():
     ap.add_argument("--no-side-configs", action="store_true",
                     help="skip the two short side records of the default N = 1 run (true fp32 MFMA arithmetic; BASELINE "
                          "config 5 = bf16 mixed precision at batch 32)")
+    ap.add_argument("--host-batches", action="store_true",
+                    help="PCIe-inclusive side measurement: the minibatches stay in pinned HOST memory in the reference's "
+                         "hand-over form (float32 images, 80-channel layout maps, box masks) and every step's batch is "
+                         "uploaded inside the timed region (copy stream, one step ahead).  Never the headline value.")
     ap.add_argument("--no-is-monitor", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--force-ddp", action="store_true",
@@ -416,9 +424,57 @@ def main():
     batches = [synth_batch.make_batch(args.batch, seed=1234 + rank + 1000 * i, device=device, branch_num=branch_num)
                for i in range(nb)]
     it = [0]
+    host_bytes = None
+    if args.host_batches:
+        # The reference's boundary hands HOST tensors over (prepare_data, trainDataset.py:79-127).  Four pinned host
+        # batches in rotation, two device-side batch buffers: while step t computes on buffer t % 2, batch t + 1 crosses
+        # PCIe into the other one on a copy stream (which first waits until step t - 1 has finished reading it).
+        from miscc.utils import attach_host
+
+        def tree(fn, a, b=None):
+            if torch.is_tensor(a):
+                return fn(a, b)
+            if isinstance(a, (list, tuple)):
+                return [tree(fn, x, None if b is None else b[i]) for i, x in enumerate(a)]
+            return a
+        host = [{k: tree(lambda t, _: t.pin_memory(), v) for k, v in
+                 synth_batch.make_batch(args.batch, seed=1234 + rank + 1000 * i, branch_num=branch_num).items()}
+                for i in range(nb)]
+        host_bytes = sum(t.numel() * t.element_size() for v in host[0].values()
+                         for t in (v if isinstance(v, (list, tuple)) else [v]) if torch.is_tensor(t))
+        bufs = batches[:2] if nb >= 2 else batches * 2
+        copy_stream = torch.cuda.Stream(device)
+        ready, free = [None, None], [None, None]
+
+        def refill(k, i):
+            src = host[i % nb]
+            with torch.cuda.stream(copy_stream):
+                if free[k] is not None:
+                    copy_stream.wait_event(free[k])
+
+                def cp(dst, s_):
+                    dst.copy_(s_, non_blocking=True)
+                    if getattr(dst, "_og_host", None) is not None:
+                        attach_host(dst, s_)
+                    return dst
+                for key, v in bufs[k].items():
+                    tree(cp, v, src[key])
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+                ready[k] = ev
+        refill(0, 0)
 
     def step():
-        out = tr.train_step(batches[it[0] % nb])
+        if args.host_batches:
+            k = it[0] % 2
+            torch.cuda.current_stream().wait_event(ready[k])
+            refill(1 - k, it[0] + 1)
+            out = tr.train_step(bufs[k])
+            ev = torch.cuda.Event()
+            ev.record()                   # (train_step has joined its side streams into this one when it returns)
+            free[k] = ev
+        else:
+            out = tr.train_step(batches[it[0] % nb])
         it[0] += 1
         return out
 
@@ -508,6 +564,12 @@ def main():
                                                "LDS-staged weight-gradient kernels run bf16x3 (six products on the bf16 MFMA)",
                                      "bf16": "operands rounded to bf16, fp32 accumulation"}[args.math]},
         }
+        if args.host_batches:
+            res["config"]["host_batches"] = {
+                "bytes_per_step_and_gpu": int(host_bytes),
+                "what": "PCIe-INCLUSIVE side measurement: every step's minibatch (the reference's prepare_data hand-over: "
+                        "float32 images at three scales, 80-channel layout maps, box masks, box tables, embeddings) is "
+                        "uploaded from pinned host memory inside the timed region, one step ahead on a copy stream"}
         if timing:
             ms = (ctypes.c_double * 96)()
             fl = (ctypes.c_double * 96)()
