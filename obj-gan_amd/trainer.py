@@ -400,8 +400,17 @@ class condGANTrainer(object):
 
     # ---- concurrency of the discriminator updates ---------------------------------------------------
     # Side streams for the eight discriminator updates and the nine generator-loss terms (1: everything on the
-    # caller's stream).  r03, one MI355X, B = 16: 205.6 / 192.7 / 190.0 / 198.5 ms per step with 1 / 2 / 3 / 4.
-    d_streams = 3
+    # caller's stream).  r03, one MI355X, B = 16: 205.6 / 192.7 / 190.0 / 198.5 ms per step with 1 / 2 / 3 / 4 streams,
+    # jobs round-robin.  r04 (fp16x2): 148.3 / 142.8 / 155.8 / 141.8 with 2 / 3 / 4 / 5 round-robin -- what matters is
+    # which jobs share a stream: the four heavy ones (the 256-px patch and shape discriminators, the two object
+    # discriminators) each on a stream of their own and the light ones spread behind them, 5 streams: 139.5
+    # (same box, same call: 141.5 with the round-robin three; profiles/r04_ab_rejected_variants.txt (e)).  The stream
+    # assignment changes the interleaving on the device, not the arithmetic (bit-identical, tested).
+    d_streams = 5
+    # side stream of each discriminator job, job order PatD0-2, ShpD0-2, ObjSSD, ObjLSD (None / short: round-robin);
+    # OBJGAN_D_STREAM_MAP="0,1,2,0,1,2,0,1" overrides it for experiments.
+    d_stream_map = ([int(v) for v in os.environ["OBJGAN_D_STREAM_MAP"].split(",")]
+                    if os.environ.get("OBJGAN_D_STREAM_MAP") else [2, 4, 3, 3, 4, 2, 1, 0])
 
     def _d_side_streams(self):
         n = int(self.d_streams)
@@ -529,7 +538,8 @@ class condGANTrainer(object):
         for s_ in side:
             s_.wait_stream(main)
         for j, (name, opt, loss_fn) in enumerate(jobs):
-            ctx = torch.cuda.stream(side[j % len(side)]) if side else _NullCtx()
+            sidx = self.d_stream_map[j] if (self.d_stream_map and j < len(self.d_stream_map)) else j
+            ctx = torch.cuda.stream(side[sidx % len(side)]) if side else _NullCtx()
             with ctx:
                 opt.zero_grad()
                 err = loss_fn()
