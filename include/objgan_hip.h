@@ -105,6 +105,15 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
  * ymax (may be NULL): 1024 ZERO-FILLED floats that receive the partial maxima of |y| -- from the kernel's epilogue where the
  * launch writes final values, from a pass over y otherwise. */
 int objgan_absmax_partials(const float* x, long n, float* out1024, void* stream);
+/* math 5: the arithmetic of math 4 with the pixel operand handed over as its PRE-SPLIT fp16 record instead of the fp32
+ * tensor: `x` points to rec[n][c / 16][h | l][pixel][c % 16] fp16 with x * 2^s = h + l (channels C..ceil16(C)-1 zero), s
+ * derived from the same `xmax` slots the call is given (they still undo the scale in the epilogue).  The kernel reads two
+ * 16-byte loads per lane and K step instead of eight channel-strided dwords + the split on the VALU, and short block rows run
+ * two 32-pixel groups per wave; results are bit-identical to math 4.  Only where objgan_conv_bank_layout answers class 5
+ * (the MFMA implicit-GEMM kernel); the filter bank is the math-4 bank.  objgan_h2_records writes a record in one pass
+ * (4 B read + 4 B written per element); objgan_h2_records_floats: its size in 4-byte units (= N * ceil16(C) * HW). */
+long objgan_h2_records_floats(int N, int C, long HW);
+int objgan_h2_records(const float* x, const float* xmax1024, void* rec, int N, int C, long HW, void* stream);
 /* ws: the bf16 channel-blocked copy of x (math 1), then the split-K workspace.  Small-grid / long-K launches are split along K: every split stores its partial output into
  * its own slot of ws and a second kernel sums the slots in split order (+ bias, activation) -- bit-reproducible, no
  * zero-fill of y, no atomics.  objgan_conv_igemm_ws_floats (host-only, same geometry arguments; ring != 0 when a ring

@@ -32,6 +32,7 @@ SIGNATURES = {
                           _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                           _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _c_long, _ptr],
     "objgan_absmax_partials": [_ptr, _c_long, _ptr, _ptr],
+    "objgan_h2_records": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_long, _ptr],
     "objgan_reflect_ring_fold": [_ptr, _ptr, _c_long, _c_int, _c_int, _ptr],
     "objgan_conv_dgrad_s2_phases": [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                     _c_int, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _c_long, _ptr],
@@ -89,6 +90,7 @@ LONG_RETURN = {"objgan_conv_packed_floats": [_c_int, _c_int, _c_int],
                "objgan_conv_igemm_ws_floats": [_c_int] * 22,
                "objgan_conv_wgrad_ws_floats": [_c_int] * 13,
                "objgan_conv_dgrad_s2_phases_ws_floats": [_c_int] * 5,
+               "objgan_h2_records_floats": [_c_int, _c_int, _c_long],
                "objgan_norm_ws_floats": [_c_int] * 4,
                "objgan_attn_general_backward_ws_floats": [_c_int] * 4,
                "objgan_masked_max_backward_ws_floats": [_c_int] * 4,

@@ -25,7 +25,7 @@ if os.environ.get("OBJGAN_DEV") == "1":
 # reference-signature objgan_roi_align_backward (unordered scatter, as the CUDA original) and the first-generation /
 # partial-coverage split-K path of conv_igemm.hip; the training step itself runs without fp32 atomics.
 PER_FILE_FLAGS = {"roi_align.hip": ["-ffp-contract=off", "-munsafe-fp-atomics"], "resize_pil.hip": ["-ffp-contract=off"],
-                  "conv_igemm.hip": ["-munsafe-fp-atomics"]}
+                  "conv_igemm.hip": ["-munsafe-fp-atomics"], "conv_igemm_rec.hip": ["-munsafe-fp-atomics"]}
 
 
 def _hipcc():
@@ -91,7 +91,7 @@ def _build_locked(force, verbose):
         obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         objs.append(obj)
         srcp = os.path.join(CSRC, src)
-        deps = [srcp, os.path.join(CSRC, "common.h")]
+        deps = [srcp] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
         if (not force and os.path.exists(obj)
                 and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in deps)):
             continue

@@ -172,6 +172,37 @@ def _absmax(t):
     return out
 
 
+# fp16x2 on records (round 5): the MFMA implicit-GEMM kernel reads its pixel operand as PRE-SPLIT fp16 pieces,
+# rec[n][c / 16][h | l][pixel][c % 16] with x * 2^s = h + l (csrc/conv_igemm_rec.hip), instead of gathering the fp32 NCHW
+# tensor and splitting it inside the loop -- same products in the same order, bit-identical results.  The record of a
+# tensor is a pure function of (tensor, partial maxima); it is written by one pass (objgan_h2_records) on first use and
+# kept on the tensor object like the maxima (per HIP stream, invalidated by the version counter).
+_REC = {"on": _os.environ.get("OBJGAN_H2_RECORDS", "1") != "0"}
+
+
+def set_h2_records(on):
+    _REC["on"] = bool(on)
+
+
+def _records(t, amax, N, C, HW):
+    """the fp16x2 record of the contiguous fp32 tensor t [N, C, HW] under the scale of `amax`"""
+    sid = torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    cache = getattr(t, "_og_rec", None)
+    if cache is not None:
+        got = cache.get(sid)
+        if got is not None and got[0] == t._version and got[2] is amax:
+            return got[1]
+    rec = torch.empty(N * ((C + 15) // 16 * 16) * HW, dtype=_F32, device=t.device)
+    _lib.call("objgan_h2_records", _p(t), _p(amax), _p(rec), N, C, HW, _stream())
+    try:
+        if cache is None:
+            cache = t._og_rec = {}
+        cache[sid] = (t._version, rec, amax)
+    except (AttributeError, RuntimeError):
+        pass
+    return rec
+
+
 # Packed filter banks are kept while their weights are unchanged.  A weight tensor is eligible
 # when something vouches for its contents: either it carries `_og_epoch` (a one-element list owned
 # by its optimizer arena, bumped by every ArenaAdam.step -- the fused Adam kernel writes through a
@@ -289,6 +320,9 @@ def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, tran
         math = 2                              # thin / first-generation kernels: no fp16x2 form
         layout = _lib.load().objgan_conv_bank_layout(N, C, H, W, M, Tg, PH, PW, act, math)
     xmax = _absmax(x) if math == 4 else None
+    kmath, xk = math, x
+    if math == 4 and _REC["on"] and not (x.data_ptr() & 15):
+        kmath, xk = 5, _records(x, xmax, N, C, H * W)     # same arithmetic, same bank; the pixel operand as its fp16 record
     key = _pack_key(w, transpose, src_tap, layout, math) if cache else None      # (temporaries: pack per call, keep nothing)
     nfl = _lib.load().objgan_conv_packed_floats(int(M), int(C), int(Tg))
     if key is not None:
@@ -305,14 +339,14 @@ def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, tran
     # split-K launches (small grids, long reductions) go through a workspace: partial tiles, then an ordered sum
     nws = _lib.load().objgan_conv_igemm_ws_floats(N, C, H, W, int(upsample), int(pad_mode), Cout, Cin, Torig,
                                                    int(transpose), Tg, PH, PW, stride, OHf, OWf, osh, osw, act,
-                                                   int(y_prezeroed), math, 0 if ring is None else 1)
+                                                   int(y_prezeroed), kmath, 0 if ring is None else 1)
     ws = torch.empty(nws, dtype=_F32, device=x.device) if nws > 0 else None
     if not _BF16_CHANNELS_LAST and math == 1 and nws == _nhwc_floats(N, C, H, W):
         ws, nws = None, 0                 # (tests) no workspace: the library gathers from the fp32 NCHW source instead
-    _lib.call("objgan_conv_igemm", _p(x), _p(w), _p(bias), _p(y), _p(wt),
+    _lib.call("objgan_conv_igemm", _p(xk), _p(w), _p(bias), _p(y), _p(wt),
               N, C, H, W, int(upsample), int(pad_mode), Cout, Cin, Torig, int(transpose),
               Tg, _iarr(dh), _iarr(dw), _iarr(src_tap), PH, PW, stride,
-              OHf, OWf, osh, osw, ooh, oow, act, int(y_prezeroed), packed, math, _p(ring), _p(xmax), _p(ymax),
+              OHf, OWf, osh, osw, ooh, oow, act, int(y_prezeroed), packed, kmath, _p(ring), _p(xmax), _p(ymax),
               _p(ws), nws, _stream())
 
 
@@ -356,8 +390,11 @@ def _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad_h, pad_w, LH, LW, cachea
     nws = _lib.load().objgan_conv_dgrad_s2_phases_ws_floats(N, Cout, OH, OW, math)
     ws = torch.empty(nws, dtype=_F32, device=g.device) if nws > 0 and _BF16_CHANNELS_LAST else None
     nws = nws if ws is not None else 0
-    _lib.call("objgan_conv_dgrad_s2_phases", _p(g), _p(w), _p(dx), _p(wt), N, Cout, OH, OW, Cin, KH * KW,
-              Tg, _iarr(dh), _iarr(dw), _iarr(st), LH // 2, LW // 2, packed, math, _p(xmax), _p(ws), nws, _stream())
+    kmath, gk = math, g
+    if math == 4 and _REC["on"] and not (g.data_ptr() & 15):
+        kmath, gk = 5, _records(g, xmax, N, Cout, OH * OW)
+    _lib.call("objgan_conv_dgrad_s2_phases", _p(gk), _p(w), _p(dx), _p(wt), N, Cout, OH, OW, Cin, KH * KW,
+              Tg, _iarr(dh), _iarr(dw), _iarr(st), LH // 2, LW // 2, packed, kmath, _p(xmax), _p(ws), nws, _stream())
     return dx
 
 

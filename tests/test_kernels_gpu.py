@@ -7,6 +7,8 @@ C restatement) on the same seeded inputs.  Tolerance: fp32 rel-L2 <= 1e-4 for si
 import os
 
 import numpy as np
+import math
+
 import pytest
 import torch
 
@@ -765,6 +767,77 @@ def test_bf16_blocked_operand_equals_the_fp32_gather_form(dev, case):
     assert torch.equal(outs[0][0], outs[1][0]), ("fwd", rel_l2(outs[0][0], outs[1][0]))
     assert torch.equal(outs[0][1], outs[1][1]), ("dgrad", rel_l2(outs[0][1], outs[1][1]))
     assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+
+
+REC_CASES = BF16_CASES + [
+    (1, 7, 13, 10, 130, 3, 2, 1, "zeros", False),          # odd sizes, stride 2, k3: per-phase launches into a pre-zeroed dX
+    (3, 200, 4, 4, 40, 4, 2, 0, "zeros", False),           # small grid: split-K through the workspace
+    (4, 96, 64, 64, 192, 4, 2, 1, "zeros", False),         # unsplit launches, 8-wave workgroups
+    (2, 194, 64, 64, 194, 3, 1, 1, "reflect", False),      # ring form of the reflect-pad data gradient
+    # large enough for two pixel groups per wave (>= 512 workgroups of 256 pixels at block-row heights <= 3)
+    (8, 64, 128, 128, 96, 3, 1, 1, "reflect", False),
+    (8, 96, 256, 256, 192, 4, 2, 1, "zeros", False),       # four-phase data gradient, 96-row tiles
+    (8, 194, 128, 128, 96, 3, 1, 1, "zeros", True),        # upBlock on the transposed 4x4 form, ragged channel chunk
+]
+
+
+@pytest.mark.parametrize("case", REC_CASES)
+def test_fp16x2_on_records_equals_the_gather_form_bit_for_bit(dev, case):
+    """Round 5: the fp16x2 kernels read their pixel operand as the tensor's pre-split fp16 record (two 16-byte loads per
+    lane and K step; short block rows with two pixel groups per wave) instead of gathering the fp32 NCHW tensor and
+    splitting it in the loop.  Same pieces, same products, same order: forward and data gradient are BIT-identical."""
+    ops = _ops()
+    N, Cin, H, W, Cout, k, s, p, pm, up = case
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(N, Cin, H, W, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(dev)
+    prev, prev_min = ops.get_conv_math(), ops._H2_MIN_FLOP
+    ops.set_conv_math("fp16x2")
+    ops._H2_MIN_FLOP = 0.0
+    outs = []
+    try:
+        for rec in (True, False):
+            ops.set_h2_records(rec)
+            xd, wd = x.clone().requires_grad_(), w.clone().requires_grad_()
+            yd = ops.conv2d(xd, wd, None, s, p, pm, up, "lrelu")
+            gy = torch.randn(yd.shape, generator=torch.Generator().manual_seed(5)).to(dev)
+            yd.backward(gy)
+            torch.cuda.synchronize()
+            outs.append((yd.detach().clone(), xd.grad.clone(), wd.grad.clone()))
+    finally:
+        ops.set_h2_records(True)
+        ops.set_conv_math(prev)
+        ops._H2_MIN_FLOP = prev_min
+    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+    assert torch.equal(outs[0][0], outs[1][0]), ("fwd", rel_l2(outs[0][0], outs[1][0]))
+    assert torch.equal(outs[0][1], outs[1][1]), ("dgrad", rel_l2(outs[0][1], outs[1][1]))
+    assert torch.equal(outs[0][2], outs[1][2]), ("wgrad", rel_l2(outs[0][2], outs[1][2]))
+
+
+def test_h2_records_layout_and_split(dev):
+    """objgan_h2_records: rec[n][c / 16][h | l][pixel][c % 16] fp16 with x * 2^s = h + l (round to nearest at each cut),
+    max |x| * 2^s in [2^14, 2^15), channels beyond C zero -- against a torch evaluation of exactly that."""
+    ops = _ops()
+    N, C, H, W = 3, 21, 9, 7
+    x = (torch.randn(N, C, H, W, generator=torch.Generator().manual_seed(3)) * 3.7).to(dev)
+    amax = ops._absmax(x)
+    rec = ops._records(x, amax, N, C, H * W)
+    torch.cuda.synchronize()
+    Cp = (C + 15) // 16 * 16
+    r = rec.view(torch.float16).view(N, Cp // 16, 2, H * W, 16).float().cpu()
+    m = float(x.abs().max())
+    e = math.frexp(m)[1] - 1                     # m = f * 2^(e+1), f in [0.5, 1): 2^e <= m < 2^(e+1)
+    sc = 2.0 ** (14 - e)
+    assert 2.0 ** 14 <= m * sc < 2.0 ** 15
+    xs = torch.zeros(N, Cp, H * W)
+    xs[:, :C] = x.cpu().reshape(N, C, H * W) * sc
+    h = xs.half().float()
+    l = (xs - h).half().float()
+    want_h = h.view(N, Cp // 16, 16, H * W).permute(0, 1, 3, 2)
+    want_l = l.view(N, Cp // 16, 16, H * W).permute(0, 1, 3, 2)
+    assert torch.equal(r[:, :, 0], want_h)
+    assert torch.equal(r[:, :, 1], want_l)
+    assert float((h + l - xs).abs().max()) <= 2.0 ** -24 * m * sc * 1.0001
 
 
 def test_gated_adam_divides_by_the_flag_on_request(dev):

@@ -3,7 +3,10 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 tools/conv_bench.cpp -Iinclude -L obj-gan_amd/objgan_hip -lobjgan_hip \
 //         -Wl,-rpath,'$ORIGIN/../obj-gan_amd/objgan_hip' -o tools/conv_bench
-//   tools/conv_bench [filter] [iters] [math: 0 fp32 | 1 bf16 inputs | 2 bf16x3 | 4 fp16x2]
+//   tools/conv_bench [filter] [iters] [math: 0 fp32 | 1 bf16 inputs | 2 bf16x3 | 4 fp16x2 | 5 fp16x2 on records]
+//   (math 5: forward / data gradient read the pre-split fp16 record of their pixel operand; the record passes are timed
+//    on their own line; the weight gradient runs math 4; `hash` columns: FNV-1a of the output bits -- equal between
+//    math 4 and math 5 when the two are bit-identical)
 //
 // For every shape: forward, data gradient and weight gradient are timed with hipEvents and
 // reported as algorithmic TFLOP/s (2*N*OH*OW*Cout*Cin*k*k); a sample of output elements is
@@ -82,6 +85,20 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&wsb, nwsb * 4));
         float* mxx; float* mxg;          // math 4 (fp16x2): per-workgroup maxima of x and of dy (objgan_absmax_partials)
         CK(hipMalloc(&mxx, 1024 * 4)); CK(hipMalloc(&mxg, 1024 * 4));
+        float *recx = nullptr, *recg = nullptr;   // math 5: the fp16 records of x and dy
+        const int kmath = g_math == 5 ? 4 : g_math;     // arithmetic of the calls that have no record form
+        if (g_math == 5) {
+            CK(hipMalloc(&recx, objgan_h2_records_floats(sh.N, sh.Cin, (long)sh.H * sh.W) * 4));
+            CK(hipMalloc(&recg, objgan_h2_records_floats(sh.N, sh.Cout, (long)OH * OW) * 4));
+        }
+        auto prep_x = [&]() {
+            objgan_absmax_partials(dx, (long)nx, mxx, st);
+            if (objgan_h2_records(dx, mxx, recx, sh.N, sh.Cin, (long)sh.H * sh.W, st) != 1) { fprintf(stderr, "records x\n"); exit(1); }
+        };
+        auto prep_g = [&]() {
+            objgan_absmax_partials(dg, (long)ny, mxg, st);
+            if (objgan_h2_records(dg, mxg, recg, sh.N, sh.Cout, (long)OH * OW, st) != 1) { fprintf(stderr, "records g\n"); exit(1); }
+        };
         CK(hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(dw, hw.data(), nw * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(dg, hg.data(), ny * 4, hipMemcpyHostToDevice));
@@ -93,17 +110,18 @@ int main(int argc, char** argv) {
         }
         auto fwd = [&]() {
             if (g_math == 4) objgan_absmax_partials(dx, (long)nx, mxx, st);       // (the weight gradient reuses it)
-            int rc = objgan_conv_igemm(dx, dw, nullptr, dy, wt, sh.N, sh.Cin, sh.H, sh.W, sh.up, sh.refl, sh.Cout, sh.Cin, T, 0,
+            int rc = objgan_conv_igemm(g_math == 5 ? recx : dx, dw, nullptr, dy, wt, sh.N, sh.Cin, sh.H, sh.W, sh.up, sh.refl, sh.Cout, sh.Cin, T, 0,
                                        T, dh.data(), dwv.data(), stp.data(), OH, OW, sh.s, OH, OW, 1, 1, 0, 0, 0, 0, 0, g_math, nullptr, mxx, nullptr, wsb, nwsb, st);
             if (rc != 1) { fprintf(stderr, "fwd rc=%d\n", rc); exit(1); }
         };
         auto dgrad = [&]() {
             if (g_math == 4) objgan_absmax_partials(dg, (long)ny, mxg, st);       // (shared with the weight gradient)
+            const float* dgk = g_math == 5 ? recg : dg;
             if (sh.s == 1) {
                 const int pe = sh.refl ? 0 : sh.p;
                 std::vector<int> h2(T), w2(T);
                 for (int kh = 0; kh < sh.k; ++kh) for (int kw = 0; kw < sh.k; ++kw) { h2[kh * sh.k + kw] = pe - kh; w2[kh * sh.k + kw] = pe - kw; }
-                int rc = objgan_conv_igemm(dg, dw, nullptr, dgx, wt, sh.N, sh.Cout, OH, OW, 0, 0, sh.Cout, sh.Cin, T, 1,
+                int rc = objgan_conv_igemm(dgk, dw, nullptr, dgx, wt, sh.N, sh.Cout, OH, OW, 0, 0, sh.Cout, sh.Cin, T, 1,
                                            T, h2.data(), w2.data(), stp.data(), TH, TW, 1, TH, TW, 1, 1, 0, 0, 0, 0, 0, g_math, nullptr, mxg, nullptr, wsb, nwsb, st);
                 if (rc != 1) { fprintf(stderr, "dgrad rc=%d\n", rc); exit(1); }
             } else if (sh.k % 2 == 0 && LH % 2 == 0 && sh.Cin > 32) {
@@ -113,7 +131,7 @@ int main(int argc, char** argv) {
                         for (int kw = 0; kw < sh.k; ++kw) if (((pw + sh.p - kw) % 2 + 2) % 2 == 0) {
                             h2.push_back((ph + sh.p - kh) / 2); w2.push_back((pw + sh.p - kw) / 2); s2.push_back(kh * sh.k + kw);
                         }
-                int rc = objgan_conv_dgrad_s2_phases(dg, dw, dgx, wt, sh.N, sh.Cout, OH, OW, sh.Cin, T, (int)h2.size() / 4,
+                int rc = objgan_conv_dgrad_s2_phases(dgk, dw, dgx, wt, sh.N, sh.Cout, OH, OW, sh.Cin, T, (int)h2.size() / 4,
                                                      h2.data(), w2.data(), s2.data(), LH / 2, LW / 2, 0, g_math, mxg, wsb, nwsb, st);
                 if (rc != 1) { fprintf(stderr, "dgrad phases rc=%d\n", rc); exit(1); }
             } else {
@@ -125,14 +143,14 @@ int main(int argc, char** argv) {
                             h2.push_back((ph + sh.p - kh) / 2); w2.push_back((pw + sh.p - kw) / 2); s2.push_back(kh * sh.k + kw);
                         }
                     const int PHg = (LH - ph + 1) / 2, PWg = (LW - pw + 1) / 2;
-                    int rc = objgan_conv_igemm(dg, dw, nullptr, dgx, wt, sh.N, sh.Cout, OH, OW, 0, 0, sh.Cout, sh.Cin, T, 1,
+                    int rc = objgan_conv_igemm(dgk, dw, nullptr, dgx, wt, sh.N, sh.Cout, OH, OW, 0, 0, sh.Cout, sh.Cin, T, 1,
                                                (int)h2.size(), h2.data(), w2.data(), s2.data(), PHg, PWg, 1, LH, LW, 2, 2, ph, pw, 0, 1, 0, g_math, nullptr, mxg, nullptr, wsb, nwsb, st);
                     if (rc != 1) { fprintf(stderr, "dgrad2 rc=%d\n", rc); exit(1); }
                 }
             }
         };
         auto wgrad = [&]() {
-            int rc = objgan_conv_wgrad(dx, dg, dgw, sh.N, sh.Cin, sh.H, sh.W, sh.up, sh.refl, sh.Cout, OH, OW, sh.k, sh.s, sh.p, g_math,
+            int rc = objgan_conv_wgrad(dx, dg, dgw, sh.N, sh.Cin, sh.H, sh.W, sh.up, sh.refl, sh.Cout, OH, OW, sh.k, sh.s, sh.p, kmath,
                                        0, mxx, mxg, wsb, nwsb, st);
             if (rc != 1) { fprintf(stderr, "wgrad rc=%d\n", rc); exit(1); }
         };
@@ -145,7 +163,15 @@ int main(int argc, char** argv) {
             float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
             return (double)ms / iters;
         };
+        double tpx = 0, tpg = 0;
+        if (g_math == 5) { tpx = timeit(prep_x); tpg = timeit(prep_g); }
         const double tf = timeit(fwd), td = timeit(dgrad), tw = timeit(wgrad);
+        auto fnv = [](const float* v, size_t n) {
+            unsigned long long h = 1469598103934665603ull;
+            const unsigned* u = reinterpret_cast<const unsigned*>(v);
+            for (size_t i = 0; i < n; ++i) { h ^= u[i]; h *= 1099511628211ull; }
+            return h;
+        };
 
         // ---- spot checks (double precision on the host)
         CK(hipMemcpy(hy.data(), dy, ny * 4, hipMemcpyDeviceToHost));
@@ -218,7 +244,16 @@ int main(int argc, char** argv) {
                sh.name, tf, flops / tf / 1e9, td, flops / td / 1e9, tw, flops / tw / 1e9,
                maxerr_f / (maxref_f + 1e-30), maxerr_d / (maxref_d + 1e-30), maxerr_w / (maxref_w + 1e-30),
                sqrt(se_f / (sr_f + 1e-300)), sqrt(se_d / (sr_d + 1e-300)), sqrt(se_w / (sr_w + 1e-300)));
+        {
+            std::vector<float> hgx2(ngx);
+            CK(hipMemcpy(hgx2.data(), dgx, ngx * 4, hipMemcpyDeviceToHost));
+            printf("    hash fwd %016llx dgrad %016llx", fnv(hy.data(), ny), fnv(hgx2.data(), ngx));
+            if (g_math == 5) printf("  | record passes (absmax + split): x %.3f ms  dy %.3f ms", tpx, tpg);
+            printf("\n");
+        }
         fflush(stdout);
+        if (recx) hipFree(recx);
+        if (recg) hipFree(recg);
         hipFree(dx); hipFree(dw); hipFree(dy); hipFree(dg); hipFree(dgx); hipFree(dgw); hipFree(wt); hipFree(wsb); hipFree(mxx); hipFree(mxg);
     }
     return 0;
