@@ -177,21 +177,31 @@ def _absmax(t):
 # tensor and splitting it inside the loop -- same products in the same order, bit-identical results.  The record of a
 # tensor is a pure function of (tensor, partial maxima); it is written by one pass (objgan_h2_records) on first use and
 # kept on the tensor object like the maxima (per HIP stream, invalidated by the version counter).
-_REC = {"on": _os.environ.get("OBJGAN_H2_RECORDS", "1") != "0"}
+_REC = {"on": _os.environ.get("OBJGAN_H2_RECORDS", "1") != "0",
+        # A record written by its own pass costs 8 bytes of HBM traffic per element of the tensor; the kernel that reads it
+        # gains ~15 % (tall 8-wave tiles) to ~30-55 % (block rows <= 96 rows with two pixel groups per wave).  The pass pays
+        # when the launch does enough arithmetic per element of its pixel operand: 2 * M * taps * (output / input pixels)
+        # flop per element (profiles/r05_records_convbench.txt).  A tensor that already carries its record is always read
+        # through it.
+        "min_i": float(_os.environ.get("OBJGAN_REC_MIN_I", "2500")),
+        "min_i_short": float(_os.environ.get("OBJGAN_REC_MIN_I_SHORT", "1200"))}
 
 
 def set_h2_records(on):
     _REC["on"] = bool(on)
 
 
-def _records(t, amax, N, C, HW):
-    """the fp16x2 record of the contiguous fp32 tensor t [N, C, HW] under the scale of `amax`"""
+def _records(t, amax, N, C, HW, intensity=None, rows=0):
+    """the fp16x2 record of the contiguous fp32 tensor t [N, C, HW] under the scale of `amax` (None: the launch that
+    asks does `intensity` flop per element of t with `rows` output rows -- not enough to pay for the pass)"""
     sid = torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
     cache = getattr(t, "_og_rec", None)
     if cache is not None:
         got = cache.get(sid)
         if got is not None and got[0] == t._version and got[2] is amax:
             return got[1]
+    if intensity is not None and intensity < (_REC["min_i_short"] if rows <= 96 else _REC["min_i"]):
+        return None
     rec = torch.empty(N * ((C + 15) // 16 * 16) * HW, dtype=_F32, device=t.device)
     _lib.call("objgan_h2_records", _p(t), _p(amax), _p(rec), N, C, HW, _stream())
     try:
@@ -322,7 +332,10 @@ def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, tran
     xmax = _absmax(x) if math == 4 else None
     kmath, xk = math, x
     if math == 4 and _REC["on"] and not (x.data_ptr() & 15):
-        kmath, xk = 5, _records(x, xmax, N, C, H * W)     # same arithmetic, same bank; the pixel operand as its fp16 record
+        # same arithmetic, same bank; the pixel operand as its fp16 record where that pays
+        rec = _records(x, xmax, N, C, H * W, 2.0 * M * Tg * PH * PW / float(H * W), M)
+        if rec is not None:
+            kmath, xk = 5, rec
     key = _pack_key(w, transpose, src_tap, layout, math) if cache else None      # (temporaries: pack per call, keep nothing)
     nfl = _lib.load().objgan_conv_packed_floats(int(M), int(C), int(Tg))
     if key is not None:
@@ -392,7 +405,9 @@ def _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad_h, pad_w, LH, LW, cachea
     nws = nws if ws is not None else 0
     kmath, gk = math, g
     if math == 4 and _REC["on"] and not (g.data_ptr() & 15):
-        kmath, gk = 5, _records(g, xmax, N, Cout, OH * OW)
+        rec = _records(g, xmax, N, Cout, OH * OW, 2.0 * Cin * Tg * LH * LW / float(OH * OW), Cin)
+        if rec is not None:
+            kmath, gk = 5, rec
     _lib.call("objgan_conv_dgrad_s2_phases", _p(gk), _p(w), _p(dx), _p(wt), N, Cout, OH, OW, Cin, KH * KW,
               Tg, _iarr(dh), _iarr(dw), _iarr(st), LH // 2, LW // 2, packed, kmath, _p(xmax), _p(ws), nws, _stream())
     return dx

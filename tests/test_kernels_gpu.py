@@ -71,11 +71,14 @@ def fp32_math(request):
     above a FLOP threshold in production; the tests lower it to zero so that the small cases run its kernels too.)"""
     ops = _ops()
     prev, prev_min = ops.get_conv_math(), ops._H2_MIN_FLOP
+    prev_rec = dict(ops._REC)
     ops.set_conv_math(request.param)
     ops._H2_MIN_FLOP = 0.0
+    ops._REC["min_i"] = ops._REC["min_i_short"] = 0.0          # (and every fp16x2 launch through its pre-split record)
     yield request.param
     ops.set_conv_math(prev)
     ops._H2_MIN_FLOP = prev_min
+    ops._REC.update(prev_rec)
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
@@ -791,9 +794,10 @@ def test_fp16x2_on_records_equals_the_gather_form_bit_for_bit(dev, case):
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(N, Cin, H, W, generator=g).to(dev)
     w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(dev)
-    prev, prev_min = ops.get_conv_math(), ops._H2_MIN_FLOP
+    prev, prev_min, prev_rec = ops.get_conv_math(), ops._H2_MIN_FLOP, dict(ops._REC)
     ops.set_conv_math("fp16x2")
     ops._H2_MIN_FLOP = 0.0
+    ops._REC["min_i"] = ops._REC["min_i_short"] = 0.0          # every launch through its record
     outs = []
     try:
         for rec in (True, False):
@@ -805,7 +809,7 @@ def test_fp16x2_on_records_equals_the_gather_form_bit_for_bit(dev, case):
             torch.cuda.synchronize()
             outs.append((yd.detach().clone(), xd.grad.clone(), wd.grad.clone()))
     finally:
-        ops.set_h2_records(True)
+        ops._REC.update(prev_rec)
         ops.set_conv_math(prev)
         ops._H2_MIN_FLOP = prev_min
     assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()

@@ -108,21 +108,29 @@ int main(int argc, char** argv) {
         for (int kh = 0; kh < sh.k; ++kh) for (int kw = 0; kw < sh.k; ++kw) {
             dh[kh * sh.k + kw] = kh - sh.p; dwv[kh * sh.k + kw] = kw - sh.p; stp[kh * sh.k + kw] = kh * sh.k + kw;
         }
+        // math 5 only where the MFMA implicit-GEMM kernel runs (bank layout class 5); the thin / first-generation kernels keep math 4
+        auto recm = [&](int C_, int H_, int W_, int M_, int Tg_, int PH_, int PW_) {
+            if (g_math != 5) return g_math;
+            return (objgan_conv_bank_layout(sh.N, C_, H_, W_, M_, Tg_, PH_, PW_, 0, 5) & 255) == 5 ? 5 : 4;
+        };
         auto fwd = [&]() {
+            const int fm = recm(sh.Cin, sh.H, sh.W, sh.Cout, T, OH, OW);
             if (g_math == 4) objgan_absmax_partials(dx, (long)nx, mxx, st);       // (the weight gradient reuses it)
-            int rc = objgan_conv_igemm(g_math == 5 ? recx : dx, dw, nullptr, dy, wt, sh.N, sh.Cin, sh.H, sh.W, sh.up, sh.refl, sh.Cout, sh.Cin, T, 0,
-                                       T, dh.data(), dwv.data(), stp.data(), OH, OW, sh.s, OH, OW, 1, 1, 0, 0, 0, 0, 0, g_math, nullptr, mxx, nullptr, wsb, nwsb, st);
+            int rc = objgan_conv_igemm(fm == 5 ? recx : dx, dw, nullptr, dy, wt, sh.N, sh.Cin, sh.H, sh.W, sh.up, sh.refl, sh.Cout, sh.Cin, T, 0,
+                                       T, dh.data(), dwv.data(), stp.data(), OH, OW, sh.s, OH, OW, 1, 1, 0, 0, 0, 0, 0, fm, nullptr, mxx, nullptr, wsb, nwsb, st);
             if (rc != 1) { fprintf(stderr, "fwd rc=%d\n", rc); exit(1); }
         };
         auto dgrad = [&]() {
             if (g_math == 4) objgan_absmax_partials(dg, (long)ny, mxg, st);       // (shared with the weight gradient)
-            const float* dgk = g_math == 5 ? recg : dg;
+            const float* dgk = dg;
             if (sh.s == 1) {
                 const int pe = sh.refl ? 0 : sh.p;
                 std::vector<int> h2(T), w2(T);
                 for (int kh = 0; kh < sh.k; ++kh) for (int kw = 0; kw < sh.k; ++kw) { h2[kh * sh.k + kw] = pe - kh; w2[kh * sh.k + kw] = pe - kw; }
+                const int dm = recm(sh.Cout, OH, OW, sh.Cin, T, TH, TW);
+                dgk = dm == 5 ? recg : dg;
                 int rc = objgan_conv_igemm(dgk, dw, nullptr, dgx, wt, sh.N, sh.Cout, OH, OW, 0, 0, sh.Cout, sh.Cin, T, 1,
-                                           T, h2.data(), w2.data(), stp.data(), TH, TW, 1, TH, TW, 1, 1, 0, 0, 0, 0, 0, g_math, nullptr, mxg, nullptr, wsb, nwsb, st);
+                                           T, h2.data(), w2.data(), stp.data(), TH, TW, 1, TH, TW, 1, 1, 0, 0, 0, 0, 0, dm, nullptr, mxg, nullptr, wsb, nwsb, st);
                 if (rc != 1) { fprintf(stderr, "dgrad rc=%d\n", rc); exit(1); }
             } else if (sh.k % 2 == 0 && LH % 2 == 0 && sh.Cin > 32) {
                 std::vector<int> h2, w2, s2;
@@ -131,6 +139,7 @@ int main(int argc, char** argv) {
                         for (int kw = 0; kw < sh.k; ++kw) if (((pw + sh.p - kw) % 2 + 2) % 2 == 0) {
                             h2.push_back((ph + sh.p - kh) / 2); w2.push_back((pw + sh.p - kw) / 2); s2.push_back(kh * sh.k + kw);
                         }
+                dgk = g_math == 5 ? recg : dg;
                 int rc = objgan_conv_dgrad_s2_phases(dgk, dw, dgx, wt, sh.N, sh.Cout, OH, OW, sh.Cin, T, (int)h2.size() / 4,
                                                      h2.data(), w2.data(), s2.data(), LH / 2, LW / 2, 0, g_math, mxg, wsb, nwsb, st);
                 if (rc != 1) { fprintf(stderr, "dgrad phases rc=%d\n", rc); exit(1); }
@@ -143,8 +152,10 @@ int main(int argc, char** argv) {
                             h2.push_back((ph + sh.p - kh) / 2); w2.push_back((pw + sh.p - kw) / 2); s2.push_back(kh * sh.k + kw);
                         }
                     const int PHg = (LH - ph + 1) / 2, PWg = (LW - pw + 1) / 2;
+                    const int dm = recm(sh.Cout, OH, OW, sh.Cin, (int)h2.size(), PHg, PWg);
+                    dgk = dm == 5 ? recg : dg;
                     int rc = objgan_conv_igemm(dgk, dw, nullptr, dgx, wt, sh.N, sh.Cout, OH, OW, 0, 0, sh.Cout, sh.Cin, T, 1,
-                                               (int)h2.size(), h2.data(), w2.data(), s2.data(), PHg, PWg, 1, LH, LW, 2, 2, ph, pw, 0, 1, 0, g_math, nullptr, mxg, nullptr, wsb, nwsb, st);
+                                               (int)h2.size(), h2.data(), w2.data(), s2.data(), PHg, PWg, 1, LH, LW, 2, 2, ph, pw, 0, 1, 0, dm, nullptr, mxg, nullptr, wsb, nwsb, st);
                     if (rc != 1) { fprintf(stderr, "dgrad2 rc=%d\n", rc); exit(1); }
                 }
             }
