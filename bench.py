@@ -57,17 +57,18 @@ FP16X2_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3.0
 def cat_names(math):
     """rocprofv3's names of the kernel instances behind the library's timing categories (leading template
     arguments: tile height, LDS-free form / arithmetic), indexed by category id."""
-    def names(mi, m, bfb=False):
-        return (["conv_igemm3_kernel<%d, false, %d, 4>" % (tm, mi) for tm in range(1, 8)] +
+    def names(mi, m, bfb=False, ng=1):
+        return (["conv_igemm3_kernel<%d, false, %d, 4, %d>" % (tm, mi, ng) for tm in range(1, 8)] +
                 # (bf16 mode: the bf16-operand weight-gradient kernel reports in the slots of the LDS-staged one)
                 [("conv_wgrad_bfb_kernel<%d," % tm) if bfb else ("conv_wgrad2_kernel<%d, %d" % (tm, min(m, 2))) for tm in range(1, 8)] +
                 ["conv_thin_kernel", "conv_thin3x3_kernel", "conv_igemm_kernel", "conv_wgrad_kernel",
-                 "conv_igemm3_kernel<1, true, %d, 4>" % m] + ["conv_wgrad3_kernel<%d, %d" % (tm, m) for tm in range(1, 8)] +
-                ["conv_igemm3_kernel<%d, false, %d, 8>" % (tm, mi) for tm in range(1, 8)] +
+                 "conv_igemm3_kernel<1, true, %d, 4, 1>" % m] + ["conv_wgrad3_kernel<%d, %d" % (tm, m) for tm in range(1, 8)] +
+                ["conv_igemm3_kernel<%d, false, %d, 8, %d>" % (tm, mi, ng) for tm in range(1, 8)] +
                 ["conv_wgrad3_kernel<%d, %d, *, 0, 8>" % (tm, m) for tm in range(1, 8)])
     if math == "fp16x2":       # categories 0..47: this mode's bf16x3 launches (small ones, LDS-staged weight gradients);
-        base = names(2, 2)               # 48..95: the fp16x2 instances of the same kernel families
-        return base + [""] * (48 - len(base)) + names(4, 4)
+        base = names(2, 2)               # 48..95: the fp16x2 instances of the same kernel families; 96..143 / 144..191:
+        pad = [""] * (48 - len(base))    # the forward / data-gradient kernel on pre-split records, one / two pixel groups
+        return base + pad + names(4, 4) + pad + names(5, 5) + pad + names(5, 5, ng=2)
     m = MATH_IDS[math]
     # bf16 mode: the matrix kernels read the bf16 channel-blocked copy (template value 3)
     return names(3 if m == 1 else m, m, bfb=(m == 1))
@@ -254,8 +255,17 @@ def side_configs(steps=6, warmup=2, timeout_s=240):
     return out
 
 
+def respawn_command(n, argv, port):
+    """the launcher command of `python bench.py --gpus N ...` outside a launcher: N ranks of THIS script with EVERY flag
+    of the original call (--math / --batch / --d-streams / --workload ... travel to the ranks verbatim)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def _respawn_under_torchrun(n):
-    """`python bench.py --gpus N` (N > 1) outside a launcher: start N ranks, one per GPU, over RCCL."""
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start N ranks, one per GPU, over RCCL.  A rank that dies
+    takes the job down: torch.distributed.run terminates the other ranks and returns non-zero, which is this process's
+    exit code (no line is printed); a rank that stops answering trips the process-group timeout (init_dist)."""
     import socket
     import subprocess
     s = socket.socket()
@@ -263,9 +273,80 @@ def _respawn_under_torchrun(n):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    return subprocess.call(respawn_command(n, sys.argv[1:], port), env=env)
+
+
+def init_dist(backend, rank, world, device=None):
+    """The process group of a data-parallel run, with a finite timeout (OBJGAN_DIST_TIMEOUT_S, default 600 s): a peer
+    that died or hangs makes the next collective / barrier RAISE instead of waiting for ever -- the rank exits non-zero
+    and the launcher reports the job as failed."""
+    import datetime
+    kw = {"timeout": datetime.timedelta(seconds=float(os.environ.get("OBJGAN_DIST_TIMEOUT_S", "600")))}
+    if device is not None and backend == "nccl":
+        kw["device_id"] = device
+    dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+
+
+def parse_cpulist(text):
+    """'0-15,128-143' -> [0..15, 128..143]"""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def numa_slice(node_cpus, gpu_nodes, local_rank):
+    """CPUs for the rank that drives GPU `local_rank`: the cores of the GPU's NUMA node (node_cpus: {node: [cpu ids]},
+    gpu_nodes: [node of GPU 0, 1, ...]), split evenly among the ranks whose GPUs hang off the same node.  Eight ranks each
+    issue ~4 900 launches per step from five streams; pinned to NUMA-local cores they neither migrate across sockets nor
+    compete for the same cores."""
+    node = gpu_nodes[local_rank]
+    if node not in node_cpus or not node_cpus[node]:
+        return None
+    peers = [r for r, nd in enumerate(gpu_nodes) if nd == node]
+    cpus = sorted(node_cpus[node])
+    k, i = len(peers), peers.index(local_rank)
+    per = len(cpus) // k
+    if per < 1:
+        return None
+    return cpus[i * per:(i + 1) * per]
+
+
+def pin_rank_to_numa(local_rank, world):
+    """-> the CPU list this rank was pinned to (None: single rank, or the topology could not be read)"""
+    if world <= 1 or os.environ.get("OBJGAN_NO_PIN") == "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        gpu_nodes = []
+        for i in range(torch.cuda.device_count()):
+            bdf = torch.cuda.get_device_properties(i).pci_bus_id if hasattr(
+                torch.cuda.get_device_properties(i), "pci_bus_id") else None
+            node = -1
+            if bdf is not None:
+                dom = getattr(torch.cuda.get_device_properties(i), "pci_domain_id", 0)
+                dev = getattr(torch.cuda.get_device_properties(i), "pci_device_id", 0)
+                path = "/sys/bus/pci/devices/%04x:%02x:%02x.0/numa_node" % (dom, bdf, dev)
+                if os.path.exists(path):
+                    node = int(open(path).read().strip())
+            gpu_nodes.append(node)
+        allowed = set(os.sched_getaffinity(0))
+        node_cpus = {}
+        base = "/sys/devices/system/node"
+        for d in sorted(os.listdir(base)) if os.path.isdir(base) else []:
+            if d.startswith("node") and d[4:].isdigit():
+                node_cpus[int(d[4:])] = [c for c in parse_cpulist(open(os.path.join(base, d, "cpulist")).read())
+                                         if c in allowed]
+        if any(n < 0 for n in gpu_nodes):           # no NUMA information: even slices of the allowed cores, in rank order
+            node_cpus, gpu_nodes = {0: sorted(allowed)}, [0] * max(world, len(gpu_nodes))
+        cpus = numa_slice(node_cpus, gpu_nodes, local_rank)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+        return cpus
+    except (OSError, ValueError, IndexError, RuntimeError):
+        return None
 
 
 def _write_shape_table(lib, path, steps):
@@ -401,11 +482,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     device = _rank_device(local_rank)
+    pinned = pin_rank_to_numa(local_rank, world)
     use_dist = world > 1 or args.force_ddp
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        init_dist("nccl", rank, world, device)
 
     import synth_batch
     from objgan_hip import _lib, ops
@@ -415,7 +497,7 @@ def main():
     if args.d_streams is not None:
         tr.d_streams = args.d_streams
     if os.environ.get("OG_DIRECT_WGRAD") == "0":      # development A/B
-        ops.direct_wgrad(False)
+        tr.direct_wgrad = False
     branch_num, _, workload_name = WORKLOADS[args.workload]
     side = 64 << (branch_num - 1)
     # a new minibatch every step, like training: four distinct per-rank batches in rotation (the trainer
@@ -571,9 +653,9 @@ def main():
                         "float32 images at three scales, 80-channel layout maps, box masks, box tables, embeddings) is "
                         "uploaded from pinned host memory inside the timed region, one step ahead on a copy stream"}
         if timing:
-            ms = (ctypes.c_double * 96)()
-            fl = (ctypes.c_double * 96)()
-            cnt = (ctypes.c_long * 96)()
+            ms = (ctypes.c_double * 192)()
+            fl = (ctypes.c_double * 192)()
+            cnt = (ctypes.c_long * 192)()
             lib.objgan_prof_collect(ms, fl, cnt)
             CAT_NAMES = cat_names(args.math)
             cats = [(CAT_NAMES[i], ms[i], fl[i], cnt[i], i) for i in range(len(CAT_NAMES)) if cnt[i] > 0]
@@ -581,7 +663,7 @@ def main():
             if cats:
                 name, tms, tfl, n, cat_index = cats[0]
                 ach = tfl / (tms * 1e-3) / 1e12
-                traffic = None          # HBM bytes / launch from the committed rocprofv3 --pmc passes
+                traffic, traffic_source = None, None          # HBM bytes / launch from the committed rocprofv3 --pmc passes
                 if os.path.exists(PMC_TRAFFIC_JSON):
                     try:
                         pmc = json.load(open(PMC_TRAFFIC_JSON))
@@ -589,6 +671,7 @@ def main():
                                 and args.workload == "stage3_obj")       # the run the counters were collected on
                         ent = pmc.get("kernels", {}).get(name) if same else None
                         traffic = ent["hbm_bytes_per_launch"] if ent else None
+                        traffic_source = "profiles/pmc_traffic.json (%s)" % pmc.get("source", "committed rocprofv3 --pmc passes")
                     except (ValueError, KeyError, OSError):
                         traffic = None
                 peak = {"fp32": FP32_MFMA_PEAK_TFLOPS, "bf16": BF16_MFMA_PEAK_TFLOPS,
@@ -598,6 +681,8 @@ def main():
                 res["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2),
                                    "peak": peak, "unit": "TFLOP/s",
                                    "frac": round(ach / peak, 4), "traffic": traffic,
+                                   # (a lookup in the committed counter passes, not a counter read of this run)
+                                   "traffic_source": (traffic_source if traffic is not None else None),
                                    "algorithmic_gflop_per_launch": round(tfl / n / 1e9, 2),
                                    "launches": int(n), "avg_launch_ms": round(tms / n, 4),
                                    "share_of_step": round(tms / prof_steps / (1000.0 * prof_dt), 4),
@@ -631,6 +716,8 @@ def main():
                                      "tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
                                      "frac_of_peak": round(conv_fl / (conv_ms * 1e-3) / 1e12 / peak, 4)}
         if host is not None:
+            if pinned:
+                host["pinned_cpus_per_rank"] = len(pinned)
             res["host_step"] = host
         if comm is not None:
             comm["world_size"] = dist.get_world_size()

@@ -315,7 +315,7 @@ int objgan_mask_resize(const double* src, int count, int n, int nsizes, const in
 
 /* ---- measurement aid (bench.py roofline leg): hipEvent-bracketed conv launches ------------------ */
 int objgan_prof_enable(int on);
-int objgan_prof_collect(double* ms, double* flops, long* count);   /* arrays of 96 categories (48..95: fp16x2 instances) */
+int objgan_prof_collect(double* ms, double* flops, long* count);   /* arrays of 192 categories (48..95: fp16x2 instances; 96..191: fp16x2 on records, one / two pixel groups) */
 /* per-launch records of the current window (call before objgan_prof_collect, which resets it):
  * meta[10*i..] = {kind 0 GEMM / 1 weight gradient / 2 thin, tile height, rows, K channels, taps, images,
  * pixel-grid rows, pixel-grid columns, stride (negative: strided output phases), K splits} */

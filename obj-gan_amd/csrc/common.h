@@ -59,6 +59,13 @@ __device__ __forceinline__ float og_wave_max(float v) {
     return v;
 }
 
+// fp16x2 kernels convert fp32 -> fp16 under a scale derived from the tensor's maximum.  With a correct maximum nothing
+// overflows (max |x| * 2^s < 2^15); MODE.FP16_OVFL (hwreg 1, bit 23) makes an overflowing conversion clamp to +-65504
+// instead of producing inf, so that a STALE / too-small maximum degrades the result gracefully (saturated operands,
+// finite outputs) instead of poisoning it with inf / NaN.  Per-wave state, set in the kernel prologue, one scalar
+// instruction (tools/ovfl_probe.hip; tests/test_kernels_gpu.py::test_fp16x2_survives_wrong_maxima).
+__device__ __forceinline__ void og_fp16_saturate() { __builtin_amdgcn_s_setreg(1 | (23 << 6), 1); }
+
 // ---- partial maxima of |x| (scale input of the fp16x2 convolution arithmetic) ------------------------------------
 // A tensor's maximum travels as OG_AMAX_SLOTS non-negative floats whose maximum is max |x| (consumers reduce them in
 // their prologue: 16 loads per lane).  Producers fill them in one of two ways, both free of float atomics, of ordering

@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void absmax_w_kernel(const float* __restrict__
 }
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a_in) {
     PackArgs a = a_in;
-    if (a.m_major == 5) a.wexp = og_h2_exponent(a.wmax, threadIdx.x & 63);
+    if (a.m_major == 5) { og_fp16_saturate(); a.wexp = og_h2_exponent(a.wmax, threadIdx.x & 63); }
     const int Kpad = a.Tg * a.Cp;
     const int Krow = a.m_major == 3 ? (Kpad + 31) / 32 * 32 : (a.m_major == 4 ? 3 * Kpad : (a.m_major == 5 ? 2 * Kpad : Kpad));
     const long total = pack_total(a, Kpad, Krow);
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256) void absmax_w_jobs_kernel(const PackArgs* __re
 
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackArgs* __restrict__ jobs) {
     PackArgs a = jobs[blockIdx.y];
-    if (a.m_major == 5) a.wexp = og_h2_exponent(a.wmax, threadIdx.x & 63);
+    if (a.m_major == 5) { og_fp16_saturate(); a.wexp = og_h2_exponent(a.wmax, threadIdx.x & 63); }
     const int Kpad = a.Tg * a.Cp;
     const int Krow = a.m_major == 3 ? (Kpad + 31) / 32 * 32 : (a.m_major == 4 ? 3 * Kpad : (a.m_major == 5 ? 2 * Kpad : Kpad));
     const long total = pack_total(a, Kpad, Krow);
@@ -1241,7 +1241,8 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad3_kernel(const WgradArgs a,
     float h2_xs = 1.f, h2_dys = 1.f, h2_inv = 1.f;
     if (H2) {
         const int sx = og_h2_exponent(a.xmax, lane), sd = og_h2_exponent(a.dymax, lane);
-        h2_xs = og_pow2(sx); h2_dys = og_pow2(sd); h2_inv = og_pow2(-sx - sd);
+        og_fp16_saturate();
+        h2_xs = og_pow2(sx); h2_dys = og_pow2(sd); h2_inv = og_pow2_sum(-sx, -sd);
     }
 
     // ---- column of this lane
@@ -1916,7 +1917,8 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bfb_kernel(const WgradArgs
 // When enabled, every conv launch is bracketed by hipEvents on its own stream and tagged with a
 // category (kind, taps / ksize, tile config) and its ALGORITHMIC flops 2*M*K*Npix.  Off by default;
 // the only mutable global state of the library, touched by the host thread only.
-#define OG_PROF_CATS 96          // 0..47: see OG_CAT_*; 48..95: the same kernel families in their fp16x2 instances
+#define OG_PROF_CATS 192         // 0..47: see OG_CAT_*; 48..95: the same kernel families in their fp16x2 instances;
+                                 // 96..143 / 144..191: conv_igemm3_kernel on records (math 5), one / two pixel groups per wave
 #define OG_PROF_MAX 65536
 // meta: {kind (0 forward / data-gradient GEMM, 1 weight gradient, 2 thin VALU), tile height TM, rows M,
 //        K channels C, taps T, images N, pixel-grid rows, pixel-grid columns, stride, grid.y splits}
@@ -1980,7 +1982,10 @@ OG_KNOB(og_h2_nw8_tm, "OG_H2_NW8_TM", 4)           // fp16x2: 8-wave workgroups 
 OG_KNOB(og_h2_pen_pct, "OG_H2_PEN_PCT", 100)        // fp16x2: re-read penalty of short block rows in og_row_plan, % of the table
 OG_KNOB(og_x3_wgrad3_maxtm, "OG_X3_WGRAD3_MAXTM", 2)   // bf16x3: register-fragment weight gradient up to this tile height
 OG_KNOB(og_rec_ng2_maxtm, "OG_REC_NG2_MAXTM", 3)    // fp16x2 on records: two pixel groups per wave up to this block-row height (0: never)
-OG_KNOB(og_rec_ng2_min, "OG_REC_NG2_MIN", 512)      // ... while the grid keeps this many workgroups
+OG_KNOB(og_rec_ng2_min, "OG_REC_NG2_MIN", 1024)     // ... while the grid keeps this many workgroups (r5c_tileplans: 256 loses on 32x32 maps, 1024 >= 512)
+OG_KNOB(og_rec_nw8_tm, "OG_REC_NW8_TM", 4)          // fp16x2 on records: 8-wave workgroups from this block-row height on
+OG_KNOB(og_rec_tmmax, "OG_REC_TMMAX", 7)            // ... tallest block row
+OG_KNOB(og_rec_ng2_nw8, "OG_REC_NG2_NW8", 0)        // ... 1: two pixel groups per wave also in 8-wave workgroups
 static int og_igemm_tmmax() { const int v = og_igemm_tmmax_raw(); return (v < 1 || v > 8) ? 8 : v; }
 
 // ---- host side ---------------------------------------------------------------------------
@@ -2074,9 +2079,10 @@ static double og_rounds(long blocks) {
     return (double)blocks / 256.0;
 }
 static void og_row_plan(int groups, int tiles_n, int tall, int* TM_out, int* full_rows_out, int* rest_out,
-                        int pen_pct = 100) {
+                        int pen_pct = 100, int tm_cap = 7) {
     int tmmax = og_igemm_tmmax();
     if (tmmax > 7) tmmax = 7;
+    if (tmmax > tm_cap && tm_cap >= 1) tmmax = tm_cap;
     int bt = 1;
     if (tall) {
         const int brows = og_cdiv(groups, tmmax);
@@ -2248,20 +2254,23 @@ static Igemm2Plan igemm2_plan(const IgemmArgs& a, int y_prezeroed) {
     p.nw = 4;
     p.ng = 1;
     const int tm_tall = og_cdiv(groups, og_cdiv(groups, 7));
-    if ((a.math == 2 || a.math >= 4 || (a.math == 1 && a.nhwc)) && tm_tall >= (a.math >= 4 ? og_h2_nw8_tm() : 4) &&
+    const int tm_cap = a.math == 5 ? og_rec_tmmax() : 7;
+    if ((a.math == 2 || a.math >= 4 || (a.math == 1 && a.nhwc)) &&
+        tm_tall >= (a.math == 5 ? og_rec_nw8_tm() : (a.math == 4 ? og_h2_nw8_tm() : 4)) &&
         og_nw8_min() > 0 &&
         (long)og_cdiv(groups, 7) * og_cdiv(Npix, 256) * nph >= og_nw8_min()) p.nw = 8;
     p.tiles_n = og_cdiv(Npix, 32 * p.nw);
     // (Carrying the 2 / 4 rows that 194 / 388 channels have beyond a multiple of 32 on the VALU next to the
     // MFMA stream -- as the weight-gradient kernels do -- was measured here in round 2 and bought nothing:
     // 106.0 vs 107.8 TFLOP/s on res1_128; interleaving the FMAs with the MFMAs cost 20 %.)
-    og_row_plan(groups, p.tiles_n * nph, p.nw == 8, &p.TM, &p.full_rows, &p.rest, a.math >= 4 ? og_h2_pen_pct() : 100);
-    if (a.math == 5 && p.nw == 4 && og_rec_ng2_maxtm() > 0) {
+    og_row_plan(groups, p.tiles_n * nph, p.nw == 8, &p.TM, &p.full_rows, &p.rest, a.math >= 4 ? og_h2_pen_pct() : 100, tm_cap);
+    if (a.math == 5 && (p.nw == 4 || og_rec_ng2_nw8()) && og_rec_ng2_maxtm() > 0) {
         // record form, short block rows: two 32-pixel groups per wave (every LDS row fragment feeds two MFMAs per
         // product) while the grid still fills the chip
         const int tn2 = og_cdiv(Npix, 64 * p.nw);
         int TM2, full2, rest2;
-        og_row_plan(groups, tn2 * nph, 0, &TM2, &full2, &rest2, og_h2_pen_pct());
+        const int cap2 = og_rec_ng2_maxtm() < 4 ? og_rec_ng2_maxtm() : 4;
+        og_row_plan(groups, tn2 * nph, p.nw == 8, &TM2, &full2, &rest2, og_h2_pen_pct(), p.nw == 8 ? cap2 : tm_cap);
         if (TM2 <= og_rec_ng2_maxtm() && TM2 <= 4 && (long)(full2 + (rest2 ? 1 : 0)) * tn2 * nph >= og_rec_ng2_min()) {
             p.ng = 2; p.tiles_n = tn2; p.TM = TM2; p.full_rows = full2; p.rest = rest2;
         }
@@ -2349,7 +2358,7 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed, float* ws, lo
     int rc = OG_OK;
     if (full_rows > 0) {
         a.m_begin = 0; a.m_end = min(a.M, full_rows * TM * 32);
-        ProfRec* pr = prof_begin((nw == 8 ? OG_CAT_IGEMM2_NW8(TM) : OG_CAT_IGEMM2(TM)) + (a.math >= 4 ? 48 : 0),
+        ProfRec* pr = prof_begin((nw == 8 ? OG_CAT_IGEMM2_NW8(TM) : OG_CAT_IGEMM2(TM)) + (a.math == 5 ? (ng == 2 ? 144 : 96) : (a.math == 4 ? 48 : 0)),
                                  2.0 * (a.m_end - a.m_begin) * (double)a.K * (double)Npix * nph, s);
         prof_meta(pr, 0, TM, a.m_end - a.m_begin, a.C, a.T, a.N, a.PH * nph, a.PW, a.stride * (a.osh > 1 ? -1 : 1), splits);
         rc = launch_igemm2(a, TM, dim3(full_rows * tiles_n * nph, splits, 1), s, nw, ng);
@@ -2358,7 +2367,7 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed, float* ws, lo
     }
     if (rest > 0) {
         a.m_begin = full_rows * TM * 32; a.m_end = a.M;
-        ProfRec* pr = prof_begin((nw == 8 ? OG_CAT_IGEMM2_NW8(rest) : OG_CAT_IGEMM2(rest)) + (a.math >= 4 ? 48 : 0),
+        ProfRec* pr = prof_begin((nw == 8 ? OG_CAT_IGEMM2_NW8(rest) : OG_CAT_IGEMM2(rest)) + (a.math == 5 ? (ng == 2 ? 144 : 96) : (a.math == 4 ? 48 : 0)),
                                  2.0 * (a.m_end - a.m_begin) * (double)a.K * (double)Npix * nph, s);
         prof_meta(pr, 0, rest, a.m_end - a.m_begin, a.C, a.T, a.N, a.PH * nph, a.PW, a.stride * (a.osh > 1 ? -1 : 1), splits);
         rc = launch_igemm2(a, rest, dim3(tiles_n * nph, splits, 1), s, nw, ng);
@@ -3046,7 +3055,7 @@ int objgan_prof_enable(int on) {
 }
 
 // Sums the recorded launches per category (the caller must have synchronised the device).
-// ms, flops, count: arrays of 32.  Categories = kernel instances (see OG_CAT_* above).
+// ms, flops, count: arrays of OG_PROF_CATS = 192.  Categories = kernel instances (see OG_CAT_* above).
 int objgan_prof_collect(double* ms, double* flops, long* count) {
     OG_ENTRY();
     for (int i = 0; i < OG_PROF_CATS; ++i) { ms[i] = 0; flops[i] = 0; count[i] = 0; }

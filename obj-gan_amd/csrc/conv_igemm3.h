@@ -156,6 +156,10 @@ __device__ __forceinline__ int og_h2_exponent(const float* __restrict__ pm, int 
     return __builtin_amdgcn_readfirstlane(sx);
 }
 __device__ __forceinline__ float og_pow2(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }
+// 2^(a + b) for two exponents that are each within +-100 but whose sum may leave the normal range (two vanishing
+// tensors): the exponent field must not wrap into the sign bit -- the product of two in-range powers underflows to a
+// subnormal / zero or overflows to inf like any other float product
+__device__ __forceinline__ float og_pow2_sum(int a, int b) { return og_pow2(a) * og_pow2(b); }
 __device__ __forceinline__ void og_h2_split_h(const float* v, float xs, float* sc, f16x8& h) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sc[j] = v[j] * xs; h[j] = (_Float16)sc[j]; }
@@ -409,9 +413,10 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
 
     float h2_xs = 1.f, h2_inv = 1.f;                  // H2: scale of the pixel operand, inverse of both scales
     if (H2) {
+        if (!HR) og_fp16_saturate();                  // (the in-loop split converts to fp16: clamp, never inf)
         const int sx = og_h2_exponent(a.xmax, lane);
         h2_xs = og_pow2(sx);
-        h2_inv = og_pow2(-sx - og_h2_exponent(a.wmax, lane));
+        h2_inv = og_pow2_sum(-sx, -og_h2_exponent(a.wmax, lane));
     }
     f32x16 acc[TM * NG];                               // row group i, pixel group g: acc[i * NG + g]
 #pragma unroll

@@ -22,6 +22,7 @@
 __global__ __launch_bounds__(256) void h2_records_kernel(const float* __restrict__ x, const float* __restrict__ xmax,
                                                          _Float16* __restrict__ out, int C, int HW, int Cp) {
     __shared__ float tile[64][65];
+    og_fp16_saturate();
     const float xs = og_pow2(og_h2_exponent(xmax, threadIdx.x & 63));
     const int n = blockIdx.z;
     const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;

@@ -155,6 +155,8 @@ def _absmax(t):
     if cache is not None:
         got = cache.get(sid)
         if got is not None and got[0] == t._version:
+            if _H2_VERIFY["on"]:
+                _verify_amax(t, got[1])
             return got[1]
     if _ABSMAX_LOG is not None:          # (development: who still needs a pass?)
         import traceback
@@ -304,6 +306,63 @@ def repack_arena(epoch_cell):
     return grp["n"]
 
 
+# Census of the fp16x2 operands (tests; `ops._H2_CENSUS = {}` switches it on, host syncs included).  fp16x2's scale is per
+# tensor: a GEMM row / column whose operand entries sit 2^-k below the tensor maximum keeps a relative error of ~2^(k-38)
+# (tests/test_kernels_gpu.py::test_fp16x2_per_row_error_follows_the_documented_bound).  The census records, per kind of
+# operand, the largest spread log2(max over channels / min over non-zero channels of the per-channel maximum) seen.
+_H2_CENSUS = None
+
+
+def _census(kind, t, dim):
+    if _H2_CENSUS is None:
+        return
+    m = t.detach().abs().amax(dim=[d for d in range(t.dim()) if d != dim])
+    nz = m[m > 0]
+    if nz.numel() == 0:
+        return
+    spread = float(torch.log2(nz.max() / nz.min()))
+    ent = _H2_CENSUS.setdefault(kind, [0.0, None, 0])
+    ent[2] += 1
+    if spread > ent[0]:
+        ent[0], ent[1] = spread, tuple(t.shape)
+
+
+# Debug mode OBJGAN_H2_VERIFY=1: every maximum handed to a kernel from the per-tensor cache / a producer's
+# attachment is re-derived by a pass over the tensor and compared on the host -- the cache is keyed on torch's version
+# counter, which a kernel writing through a raw pointer does not bump; a stale entry would scale wrongly.  The GPU suite
+# runs one training step in this mode (tests/test_modules_gpu.py::test_train_step_hands_no_stale_maxima_to_the_kernels).
+_H2_VERIFY = {"on": _os.environ.get("OBJGAN_H2_VERIFY") == "1", "checked": 0}
+
+
+def _verify_amax(t, amax):
+    fresh = torch.empty(_AMAX_SLOTS, dtype=_F32, device=t.device)
+    src = t if (t.is_contiguous() and not (t.data_ptr() & 15)) else t.contiguous().clone()
+    _lib.call("objgan_absmax_partials", _p(src), src.numel(), _p(fresh), _stream())
+    a, b = float(amax.max()), float(fresh.max())
+    _H2_VERIFY["checked"] += 1
+    if a != b:
+        raise _lib.ObjganHipError("stale maximum: cached %.9g, tensor has %.9g (shape %s)" % (a, b, tuple(t.shape)))
+
+
+_PACK_LOG = {} if _os.environ.get("OBJGAN_PACK_LOG") == "1" else None
+if _PACK_LOG is not None:
+    import atexit as _atexit
+
+    def _dump_pack_log():
+        import sys
+        for key, n in sorted(_PACK_LOG.items(), key=lambda kv: -kv[1]):
+            sys.stderr.write("PACKLOG %6d x %s\n" % (n, key))
+    _atexit.register(_dump_pack_log)
+
+
+def _pack_log(kind, w, cached):
+    """development: which calls still pack their bank themselves (a pack_weights_kernel launch per call)?"""
+    import traceback
+    where = " < ".join("%s:%d" % (f.name, f.lineno) for f in traceback.extract_stack(limit=9)[:-2][::-1][:6])
+    key = "%s %s cached=%s  %s" % (kind, tuple(w.shape), cached, where)
+    _PACK_LOG[key] = _PACK_LOG.get(key, 0) + 1
+
+
 def _job_blob():
     return ctypes.create_string_buffer(_lib.load().objgan_conv_pack_job_bytes())
 
@@ -330,6 +389,9 @@ def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, tran
         math = 2                              # thin / first-generation kernels: no fp16x2 form
         layout = _lib.load().objgan_conv_bank_layout(N, C, H, W, M, Tg, PH, PW, act, math)
     xmax = _absmax(x) if math == 4 else None
+    if math == 4 and _H2_CENSUS is not None:
+        _census("data gradient: filter columns (input channels)" if transpose else "forward: filter rows (output channels)",
+                w, 1 if transpose else 0)
     kmath, xk = math, x
     if math == 4 and _REC["on"] and not (x.data_ptr() & 15):
         # same arithmetic, same bank; the pixel operand as its fp16 record where that pays
@@ -349,6 +411,8 @@ def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, tran
         _bank_mark(ent)
     else:
         wt, packed = torch.empty(nfl, dtype=_F32, device=x.device), 0
+    if _PACK_LOG is not None and not packed:
+        _pack_log("igemm", w, key is not None)
     # split-K launches (small grids, long reductions) go through a workspace: partial tiles, then an ordered sum
     nws = _lib.load().objgan_conv_igemm_ws_floats(N, C, H, W, int(upsample), int(pad_mode), Cout, Cin, Torig,
                                                    int(transpose), Tg, PH, PW, stride, OHf, OWf, osh, osw, act,
@@ -386,6 +450,8 @@ def _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad_h, pad_w, LH, LW, cachea
     n = 4 * ((Cin * Tg * ((Cout + 15) // 16 * 16) * 3 + 1) // 2) + _AMAX_SLOTS    # bf16x3 banks: 6 B per element; + |w| maxima
     math = _call_math(2.0 * Cin * Cout * Tg * N * LH * LW)
     xmax = _absmax(g) if math == 4 else None
+    if math == 4 and _H2_CENSUS is not None:
+        _census("data gradient: filter columns (input channels)", w, 1)
     key = _pack_key(w, 2, st, False, math) if cacheable else None
     if key is not None:
         ent, fresh = _bank_lookup(key, w, n, g.device)
@@ -400,6 +466,8 @@ def _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad_h, pad_w, LH, LW, cachea
         _bank_mark(ent)
     else:
         wt, packed = torch.empty(n, dtype=_F32, device=g.device), 0
+    if _PACK_LOG is not None and not packed:
+        _pack_log("phases", w, key is not None)
     nws = _lib.load().objgan_conv_dgrad_s2_phases_ws_floats(N, Cout, OH, OW, math)
     ws = torch.empty(nws, dtype=_F32, device=g.device) if nws > 0 and _BF16_CHANNELS_LAST else None
     nws = nws if ws is not None else 0
@@ -512,6 +580,9 @@ def _conv_wgrad(x, g, Cout, k, stride, pad, refl, upsample, sink=None):
     nws = _lib.load().objgan_conv_wgrad_ws_floats(*geo)
     ws = torch.empty(nws, dtype=_F32, device=x.device) if nws > 0 else None
     xmax, gmax = (_absmax(x), _absmax(g)) if math == 4 else (None, None)
+    if math == 4 and _H2_CENSUS is not None:
+        _census("weight gradient: x channels (filter columns)", x, 1)
+        _census("weight gradient: dy channels (filter rows)", g, 1)
     _lib.call("objgan_conv_wgrad", _p(x), _p(g), _p(dw_), *geo, 0 if sink is None else 1, _p(xmax), _p(gmax), _p(ws), nws,
               _stream())
     if sink is not None:
@@ -526,11 +597,27 @@ def _conv_wgrad(x, g, Cout, k, stride, pad, refl, upsample, sink=None):
 # launch: 537 of them per training step in round 3) and calls notify() in AccumulateGrad's place (the arena's
 # "gradient is final" bookkeeping for the bucketed all-reduce).  Only under .backward() into .grad -- the arena's
 # owner switches the sinks off (`direct_wgrad(False)`) around anything else.
-_DIRECT_WGRAD = {"on": True}
+_DIRECT_WGRAD = {"on": False}       # off by default: the arena's owner enables it around its backward passes
 
 
 def direct_wgrad(on):
     _DIRECT_WGRAD["on"] = bool(on)
+
+
+class direct_wgrad_scope(object):
+    """with ops.direct_wgrad_scope(): weight gradients of arena parameters accumulate straight into their arena views"""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = _DIRECT_WGRAD["on"]
+        _DIRECT_WGRAD["on"] = self.on
+        return self
+
+    def __exit__(self, *exc):
+        _DIRECT_WGRAD["on"] = self.prev
+        return False
 
 
 def _grad_sink(w, shape):
@@ -687,6 +774,31 @@ class _UpConv3x3Fn(torch.autograd.Function):
         return dx, dw_
 
 
+_WSLICE = {}        # (weight address, shape, lo, hi) -> [w, _version, epoch, slice copy]
+
+
+def _w_slice(w, lo, hi):
+    """contiguous copy of w[:, lo:hi] kept while the weights are unchanged (rebuilt IN PLACE when they changed, so that
+    its packed banks stay cached as well -- `_up_bank` does the same for the pre-summed up-convolution bank): the
+    per-input data gradients of conv2d_cat packed their slice's bank on every call (80 pack launches per training step).
+    -> (slice, cacheable)"""
+    ep = getattr(w, "_og_epoch", None)
+    if ep is None and w.requires_grad:
+        return w[:, lo:hi].contiguous(), False
+    key = (w.data_ptr(), tuple(w.shape), lo, hi)
+    ent = _WSLICE.get(key)
+    epv = ep[0] if ep is not None else -1
+    if ent is not None and ent[0] is w and ent[1] == w._version and ent[2] == epv:
+        return ent[3], True
+    ws = ent[3] if ent is not None and ent[0] is w else torch.empty(
+        (w.shape[0], hi - lo) + tuple(w.shape[2:]), dtype=_F32, device=w.device)
+    ws.copy_(w.detach()[:, lo:hi])                      # in place: bumps ws._version
+    if len(_WSLICE) >= 256:
+        _WSLICE.clear()
+    _WSLICE[key] = [w, w._version, epv, ws]
+    return ws, True
+
+
 class _Conv2dCatFn(torch.autograd.Function):
     """conv2d(cat([x1, x2], 1), w) with per-input data gradients: the first convolution of the shape / object
     discriminators sees [image (3) | encoded layout (12)] (reference model.py:1121-1128, 1217-1220).  A discriminator
@@ -727,9 +839,11 @@ class _Conv2dCatFn(torch.autograd.Function):
             dx = _conv_dgrad(g, w, N, C, H, W, stride, pad, 0, False)
             dx1, dx2 = dx[:, :c1], dx[:, c1:]
         elif n1:
-            dx1 = _conv_dgrad(g, w[:, :c1].contiguous(), N, c1, H, W, stride, pad, 0, False, cacheable=False)
+            ws, ok = _w_slice(w, 0, c1)
+            dx1 = _conv_dgrad(g, ws, N, c1, H, W, stride, pad, 0, False, cacheable=ok)
         elif n2:
-            dx2 = _conv_dgrad(g, w[:, c1:].contiguous(), N, C - c1, H, W, stride, pad, 0, False, cacheable=False)
+            ws, ok = _w_slice(w, c1, C)
+            dx2 = _conv_dgrad(g, ws, N, C - c1, H, W, stride, pad, 0, False, cacheable=ok)
         if nw:
             dw_ = _conv_wgrad(x, g, w.shape[0], k, stride, pad, 0, False, sink=_grad_sink(w, tuple(w.shape)))
         return dx1, dx2, dw_, None, None, None
@@ -766,8 +880,12 @@ class _ConvFrozenFn(torch.autograd.Function):
         y = torch.empty((N, Cout, OH, OW), dtype=_F32, device=x.device)
         dh = [kh - ph for kh in range(KH) for kw in range(KW)]
         dw = [kw - pw for kh in range(KH) for kw in range(KW)]
+        # (the frozen encoder's convolutions feed each other through a fused ReLU: the epilogue leaves the maxima)
+        ym = _amax_zeroed(x.device) if (act in ("lrelu", "relu") and _amax_wanted(y.numel())) else None
         _igemm(x, w, bias, y, N, Cin, H, W, 0, 0, Cout, Cin, KH * KW, 0, dh, dw, list(range(KH * KW)),
-               OH, OW, stride, OH, OW, 1, 1, 0, 0, _ACT[act])
+               OH, OW, stride, OH, OW, 1, 1, 0, 0, _ACT[act], ymax=ym)
+        if ym is not None:
+            _amax_attach(y, ym)
         ctx.cfg = (stride, ph, pw, act, KH, KW, (N, Cin, H, W))
         ctx.save_for_backward(w, y if act not in (None, "none") else None)
         return y

@@ -114,8 +114,10 @@ def prepare_data(data, device=None, num_classes=None):
     out_rois = [take_small(rois[b]) for b in branches]
     out_masks, out_hmaps = [], []
     fm_masks = None
-    if len(bt_masks) > 1 and bt_masks[1].shape[1] == 0:
+    if fm_bt_masks.dim() >= 2 and fm_bt_masks.shape[1] == 0 and bt_masks[0].shape[1] > 0:
         # `device_masks` hand-over: bt_masks[0] holds the raw 64 x 64 instance masks, everything else is made here
+        # (detected on the feature-map masks, which are ALWAYS empty in that mode -- also with one branch, where no
+        # bt_masks[1] exists to look at)
         if device is None:
             raise ValueError("prepare_data: raw instance masks are resized on the device; pass `device`")
         raw = take(bt_masks[0]).to(torch.float64)

@@ -74,7 +74,7 @@ class ParamArena(object):
             p.grad = gview
             # ops' convolution backward accumulates a weight gradient straight into this view and reports here in
             # AccumulateGrad's place (ops._grad_sink)
-            p._og_grad_sink = (gview, lambda i=len(self._views): self._mark(i))
+            p._og_grad_sink = (gview, lambda i=len(self._views): self._mark(i, True))
             self._views.append(gview)
             off += k
 
@@ -120,10 +120,28 @@ class ParamArena(object):
         collectives identical on every rank even when a rank's batch prunes a branch of its graph."""
         self.make_buckets()
         self._armed = (on_bucket, [set(mem) for (_, _, mem) in self.buckets], [len(self.buckets) - 1])
+        self._sink_marked = set()
+        self._grad_versions = [p.grad._version if p.grad is not None else -1 for p in self.params]
 
-    def _mark(self, i):
+    def _mark(self, i, from_sink=False):
         if self._armed is None:
             return
+        # AccumulateGrad's post-hook fires once per backward pass and parameter, after ALL contributions were summed (also
+        # when the only contribution went through the sink and autograd was handed None).  The direct weight-gradient
+        # sink of ops (`_grad_sink`) reports once per USE of the weight, from inside that use's backward: a weight used
+        # twice per forward -- two sink reports, or a sink report followed by a contribution through autograd (the hook
+        # then finds the gradient view's version counter moved: autograd's in-place accumulation bumps it, the sink's
+        # raw-pointer add does not) -- would hand its bucket to the all-reduce before its gradient is complete.  Refuse.
+        late = (not from_sink and i in self._sink_marked and self.params[i].grad is not None
+                and self.params[i].grad._version != self._grad_versions[i])
+        if (from_sink and i in self._sink_marked) or late:
+            names = [k for k, p_ in self.module.named_parameters() if p_.requires_grad]
+            raise RuntimeError("ParamArena: parameter %d (%s) is used more than once per forward (its gradient arrived "
+                               "in two pieces during one armed backward pass): the bucketed all-reduce would ship a "
+                               "partial gradient -- switch the trainer's direct_wgrad off for this network"
+                               % (i, names[i] if i < len(names) else "?"))
+        if from_sink:
+            self._sink_marked.add(i)
         on_bucket, waiting, nxt = self._armed
         waiting[self._bucket_of[i]].discard(i)
         while nxt[0] >= 0 and not waiting[nxt[0]]:
@@ -407,10 +425,28 @@ class condGANTrainer(object):
     # (same box, same call: 141.5 with the round-robin three; profiles/r04_ab_rejected_variants.txt (e)).  The stream
     # assignment changes the interleaving on the device, not the arithmetic (bit-identical, tested).
     d_streams = 5
-    # side stream of each discriminator job, job order PatD0-2, ShpD0-2, ObjSSD, ObjLSD (None / short: round-robin);
-    # OBJGAN_D_STREAM_MAP="0,1,2,0,1,2,0,1" overrides it for experiments.
-    d_stream_map = ([int(v) for v in os.environ["OBJGAN_D_STREAM_MAP"].split(",")]
-                    if os.environ.get("OBJGAN_D_STREAM_MAP") else [2, 4, 3, 3, 4, 2, 1, 0])
+    # side stream of each discriminator job BY NAME (a job without an entry -- another BRANCH_NUM, no object
+    # discriminators -- takes the next stream round-robin); OBJGAN_D_STREAM_MAP="0,1,2,0,1,2,0,1" (job order PatD0-2,
+    # ShpD0-2, ObjSSD, ObjLSD) overrides it for experiments.
+    _D_JOB_NAMES = ("errPatD0", "errPatD1", "errPatD2", "errShpD0", "errShpD1", "errShpD2", "errObjSSD", "errObjLSD")
+    d_stream_map = dict(zip(_D_JOB_NAMES, (2, 4, 3, 3, 4, 2, 1, 0)))
+    direct_wgrad = True             # weight gradients straight into the arenas during train_step (ops._grad_sink)
+    debug_after_d_updates = None    # tests: callable(trainer) between the discriminator updates and the generator loss
+
+    @classmethod
+    def _stream_map_from_env(cls):
+        """the OBJGAN_D_STREAM_MAP override, validated (a malformed value raises here with a message, not as a bare
+        ValueError while the class body is executed at import)"""
+        raw = os.environ.get("OBJGAN_D_STREAM_MAP")
+        if not raw:
+            return None
+        try:
+            vals = [int(v) for v in raw.split(",")]
+        except ValueError:
+            raise ValueError("OBJGAN_D_STREAM_MAP=%r: expected comma-separated stream indices" % raw)
+        if any(v < 0 for v in vals):
+            raise ValueError("OBJGAN_D_STREAM_MAP=%r: negative stream index" % raw)
+        return dict(zip(cls._D_JOB_NAMES, vals))
 
     def _d_side_streams(self):
         n = int(self.d_streams)
@@ -468,7 +504,10 @@ class condGANTrainer(object):
         """batch: dict with imgs[3], hmaps[3], rois[3], fm_rois, num_rois, bt_masks[2], fm_bt_masks,
         words_embs, sent_emb, glove_words_embs, mask, clabels_emb, cap_lens, class_ids (see
         synth_batch.py).  Returns a dict of loss tensors (no host sync unless want_logs)."""
-        with M.deferred_bn_counters():
+        # weight gradients go straight into the optimizer arenas (ops._grad_sink) for the duration of the step only: under
+        # `.backward()` into `.grad`, every arena weight used once per forward.  Anything else (torch.autograd.grad, a
+        # weight shared between two uses) keeps autograd's own accumulation.
+        with M.deferred_bn_counters(), ops.direct_wgrad_scope(self.direct_wgrad):
             return self._train_step(batch, noise, want_logs)
 
     def _train_step(self, batch, noise, want_logs):
@@ -508,9 +547,8 @@ class condGANTrainer(object):
         bt_c_codes = [c.detach() for c in bt_c_codes]
 
         # (3) the eight discriminator updates (reference trainer.py:398-443).  They are independent of
-        # each other (own weights, the real batch, the detached fake images); issuing them on separate
-        # HIP streams was measured and bought nothing (the step is MFMA-bound, 317.5 vs 319.6 ms), so
-        # they run in the reference's order on the current stream.
+        # each other (own weights, the real batch, the detached fake images): the host issues them in the
+        # reference's order, each on one of the side streams (`d_stream_map`, below).
         jobs = []
         for i, opt in enumerate(self.optimizersPatD):
             jobs.append(("errPatD%d" % i, opt,
@@ -537,8 +575,15 @@ class condGANTrainer(object):
         main = torch.cuda.current_stream() if side else None
         for s_ in side:
             s_.wait_stream(main)
+        smap = self._stream_map_from_env() or self.d_stream_map or {}
+        if isinstance(smap, (list, tuple)):             # (older callers: positional list in job order)
+            smap = dict(zip(self._D_JOB_NAMES, smap))
+        rr = 0
         for j, (name, opt, loss_fn) in enumerate(jobs):
-            sidx = self.d_stream_map[j] if (self.d_stream_map and j < len(self.d_stream_map)) else j
+            if name in smap:
+                sidx = smap[name]
+            else:
+                sidx, rr = rr, rr + 1
             ctx = torch.cuda.stream(side[sidx % len(side)]) if side else _NullCtx()
             with ctx:
                 opt.zero_grad()
@@ -564,6 +609,8 @@ class condGANTrainer(object):
             elif active:
                 opt.step(grad_scale=inv_world)
 
+        if self.debug_after_d_updates is not None:      # (tests: e.g. put the oracle's updated discriminators in place)
+            self.debug_after_d_updates(self)
         # (4) generator: maximise log(D(G(z))) + DAMSM + KL, discriminators frozen
         d_opts = self._d_optimizers()
         for opt in d_opts:

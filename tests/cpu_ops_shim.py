@@ -164,6 +164,20 @@ def resize_masks(masks, sizes):
             .to(masks.device) for S in sizes]
 
 
+class direct_wgrad_scope(object):
+    """the product's switch for weight gradients straight into the arena: nothing to switch on the CPU definitions
+    (autograd accumulates)"""
+
+    def __init__(self, on=True):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
 def set_conv_math(mode):
     pass
 
@@ -190,6 +204,7 @@ def install(monkeypatch):
     from miscc import losses, utils
     shim = types.SimpleNamespace(**{k: globals()[k] for k in API})
     shim.set_conv_math, shim.get_conv_math = set_conv_math, get_conv_math
+    shim.direct_wgrad_scope = direct_wgrad_scope
     for mod in (model, GlobalAttention, trainer, losses, utils, encoders, trainDataset):
         if hasattr(mod, "ops"):
             monkeypatch.setattr(mod, "ops", shim)

@@ -147,7 +147,7 @@ def _trainer_worker(rank, world, port, q):
     from miscc.config import cfg
     from oracle import ref_harness as rh
     cpu_ops_shim.install_plain()
-    torch.set_num_threads(4 if world <= 2 else 2)
+    torch.set_num_threads(4 if world <= 2 else (2 if world <= 4 else 1))
     cfg.TREE.BRANCH_NUM = 2
     cfg.TRAIN.BATCH_SIZE = 2
     cfg.TRAIN.NET_G = ''
@@ -185,13 +185,14 @@ def _trainer_worker(rank, world, port, q):
     tr.setup()
     init_ls = tr.optimizerObjLSD.arena.flat.clone()
     b = synth_batch.make_batch(B, seed=300 + rank, branch_num=2)
-    if rank == 1:                                   # no box reaches the large-scale threshold on this rank
+    # box populations by rank % 4: 0 both scales, 1 only small boxes, 2 and 3 only large ones (world size 8: ranks 4-7 repeat)
+    if rank % 4 == 1:                               # no box reaches the large-scale threshold on this rank
         for r in b["rois"]:
             r[:, :, 2:4] = r[:, :, 2:4].clamp(max=6.0 * r[:, :, 2:4].max() / 64.0)
         b["rois"][0][:, :, 2:4] = b["rois"][0][:, :, 2:4].clamp(max=6.0)
         b["rois"][1][:, :, 2:4] = b["rois"][1][:, :, 2:4].clamp(max=12.0)
         b["fm_rois"][:, :, 2:4] = b["fm_rois"][:, :, 2:4].clamp(max=3.0)
-    if rank >= 2:                                   # every box of this rank is large (>= 16 of the 32-px feature map)
+    if rank % 4 >= 2:                               # every box of this rank is large (>= 16 of the 32-px feature map)
         b["fm_rois"][:, :, 2:4] = b["fm_rois"][:, :, 2:4].clamp(min=17.0)
         b["rois"][0][:, :, 2:4] = b["rois"][0][:, :, 2:4].clamp(min=34.0)
         b["rois"][1][:, :, 2:4] = b["rois"][1][:, :, 2:4].clamp(min=68.0)
@@ -275,6 +276,43 @@ def test_four_rank_trainer_step_with_a_rank_without_large_boxes_and_a_rank_witho
         assert r[7] == 1 and r[8] == 1, "a gated object-discriminator update was skipped"
         assert r[10][0] >= 3, r[10]           # generator buckets reduced inside the backward on every rank
     assert not np.array_equal(res[0][3][-1], res[0][9]), "the large-scale object discriminator was not updated"
+
+
+@pytest.mark.timeout(1500)
+def test_eight_rank_trainer_step_with_uneven_box_populations():
+    """World size 8, the driver's SCALE configuration: ranks 0 and 4 hold boxes of both scales, ranks 1
+    and 5 only small ones, ranks 2, 3, 6, 7 only large ones.  Every rank issues the same collectives in the same order
+    (a mismatch hangs into the queue timeout), all eight replicas end bit-identical, and the gated Adam divided by the
+    number of contributing ranks: 6 for the large-scale object discriminator, 4 for the small-scale one."""
+    import numpy as np
+    world = 8
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(world):
+            res.append(q.get(timeout=1200))
+    finally:
+        if len(res) < world:
+            for p in procs:
+                p.terminate()
+    res.sort(key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [True, False, True, True] * 2 and [r[2] for r in res] == [True, True, False, False] * 2
+    for r in res[1:]:
+        for a0, a1 in zip(res[0][3], r[3]):
+            assert np.array_equal(a0, a1), "replicas diverged (rank %d)" % r[0]
+        assert np.array_equal(res[0][4], r[4])
+    for r in res:
+        assert r[5] == 6.0 and r[6] == 4.0, ("contributing-rank counts", r[5], r[6])
+        assert r[7] == 1 and r[8] == 1, "a gated object-discriminator update was skipped"
+        assert r[10][0] >= 3, r[10]
 
 
 def _bench_protocol_worker(rank, world, port, q):
@@ -442,3 +480,38 @@ def test_two_ranks_without_manual_seed_agree_on_one_seed_and_read_disjoint_shard
     assert s0 == s1
     assert not (set(o0) & set(o1)) and sorted(o0 + o1) == list(range(64))
     assert r0 != r1
+
+
+def _dying_rank_worker(rank, world, port):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "obj-gan_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OBJGAN_DIST_TIMEOUT_S="20")
+    import bench
+    bench.init_dist("gloo", rank, world)
+    dist.barrier()
+    if rank == 1:
+        os._exit(3)                               # this rank dies between two steps
+    t = torch.ones(1)
+    dist.all_reduce(t)                            # ... and its peer must not wait for ever
+    dist.barrier()
+    sys.exit(0)
+
+
+@pytest.mark.timeout(180)
+def test_a_dying_rank_fails_its_peer_instead_of_hanging_it():
+    """`bench.py --gpus N` must end with a non-zero exit code and no hang when a rank dies.  The process
+    group is created with a finite timeout (bench.init_dist); the surviving rank's next collective raises, the rank exits
+    non-zero (torch.distributed.run then terminates the job with that status)."""
+    import time
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_dying_rank_worker, args=(r, world, port)) for r in range(world)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+    assert all(not p.is_alive() for p in procs), "a rank is still waiting for its dead peer"
+    assert procs[1].exitcode == 3 and procs[0].exitcode not in (0, None), [p.exitcode for p in procs]
+    assert time.time() - t0 < 120

@@ -330,7 +330,7 @@ def test_bench_main_end_to_end_on_the_cpu_shim(monkeypatch, capsys):
             return 1
 
         def objgan_prof_collect(self, ms, fl, cnt):      # two recorded launches of one kernel instance
-            i = bench.cat_names("fp16x2").index("conv_igemm3_kernel<6, false, 4, 4>")
+            i = bench.cat_names("fp16x2").index("conv_igemm3_kernel<6, false, 4, 4, 1>")
             ms[i], fl[i], cnt[i] = 2.0, 2.0e11, 2
             return 1
     fake = FakeLib()
@@ -360,8 +360,31 @@ def test_bench_main_end_to_end_on_the_cpu_shim(monkeypatch, capsys):
     assert res["n_gpus"] == 1 and res["steps"] == 1 and res["unit"] == "images/sec" and res["value"] > 0
     assert res["metric"].endswith("at 64x64, batch 2 per GPU") and res["config"]["workload"].startswith("stage1_64x64")
     roof = res["roofline"]
-    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["kernel"] == "conv_igemm3_kernel<6, false, 4, 4>"
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["kernel"] == "conv_igemm3_kernel<6, false, 4, 4, 1>"
     assert abs(roof["achieved"] - 100.0) < 1e-6 and abs(roof["frac"] - 100.0 / roof["peak"]) < 1e-3
     assert roof["traffic"] is None or roof["traffic"] > 1e8             # committed PMC record of that kernel
     assert res["conv_total"]["tflops"] == roof["achieved"] and res["kernel_breakdown"][0]["launches_per_step"] == 2.0
     assert "cpu_baseline" not in res and "side_configs" not in res and res["dtype"].startswith("fp32 (fp16x2")
+
+
+def test_bench_respawn_passes_every_flag_through_and_numa_slices_are_disjoint():
+    """`python bench.py --gpus 8 --math bf16 --batch 32 --d-streams 3` outside a launcher re-starts itself under
+    torch.distributed.run: every flag of the original call reaches the ranks verbatim.  Rank pinning: the cores of a GPU's
+    NUMA node are split evenly among the ranks whose GPUs hang off that node -- disjoint, NUMA-local slices."""
+    import bench
+    argv = ["--gpus", "8", "--steps", "20", "--warmup", "5", "--math", "bf16", "--batch", "32", "--d-streams", "3",
+            "--workload", "stage3_obj", "--no-cpu-baseline"]
+    cmd = bench.respawn_command(8, argv, 29777)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29777"
+    assert cmd[-len(argv):] == argv and cmd[-len(argv) - 1].endswith("bench.py")
+    assert bench.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    # two sockets of 64 cores + SMT siblings, GPUs 0-3 on node 0 and 4-7 on node 1
+    nodes = {0: list(range(64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}
+    gpus = [0, 0, 0, 0, 1, 1, 1, 1]
+    slices = [bench.numa_slice(nodes, gpus, r) for r in range(8)]
+    assert all(len(c) == 32 for c in slices)
+    assert len(set().union(*map(set, slices))) == 256                       # disjoint and complete
+    assert all(set(slices[r]) <= set(nodes[gpus[r]]) for r in range(8))     # NUMA-local
+    assert bench.numa_slice({0: [0, 1]}, [0, 0, 0, 0], 1) is None           # fewer cores than ranks: no pinning

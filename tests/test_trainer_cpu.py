@@ -290,3 +290,36 @@ def test_sampling_with_ema_weights(monkeypatch):
         assert rel_l2(fake[i], want[0][i]) < 1e-5, i
     live, _, _ = tr.sample(b, b["noise"], b["words_embs"], b["sent_emb"], b["glove_words_embs"], b["mask"], use_ema=False)
     assert rel_l2(live[1], fake[1]) > 1e-3                      # the swap really changed the weights
+
+
+def test_arena_refuses_a_weight_whose_gradient_arrives_in_two_pieces():
+    """ops' direct weight-gradient sink reports a parameter once per USE, from inside that use's
+    backward, and the armed arena hands a bucket to the all-reduce as soon as all its parameters reported.  A weight used
+    twice per forward would ship a partial gradient.  The arena detects both forms -- two sink reports, or a sink report
+    followed by a contribution through autograd -- and raises; the normal case (one sink report, then AccumulateGrad's
+    post-hook, which fires even when autograd was handed None) passes."""
+    import trainer as T
+
+    def fresh():
+        net = torch.nn.Sequential(torch.nn.Linear(4, 4, bias=False), torch.nn.Linear(4, 4, bias=False))
+        arena = T.ParamArena(net)
+        fired = []
+        arena.arm(lambda s0, e0: fired.append((s0, e0)))
+        return net, arena, fired
+
+    # (1) one use through the sink: reports once, the hook that follows is the same use
+    net, arena, fired = fresh()
+    w1 = net[1].weight
+    w1._og_grad_sink[1]()                                  # the sink's report of its single use (raw-pointer add: no version bump)
+    arena._mark(1, False)                                  # AccumulateGrad's post-hook of the same pass (autograd got None)
+    assert arena._sink_marked == {1}
+    # (2) two sink reports of one parameter
+    net, arena, fired = fresh()
+    net[1].weight._og_grad_sink[1]()
+    with pytest.raises(RuntimeError, match="more than once per forward"):
+        net[1].weight._og_grad_sink[1]()
+    # (3) a sink report, then a contribution through autograd (the version counter of the gradient view moves)
+    net, arena, fired = fresh()
+    net[1].weight._og_grad_sink[1]()
+    with pytest.raises(RuntimeError, match="more than once per forward"):
+        net(torch.randn(2, 4)).sum().backward()
