@@ -153,6 +153,12 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
                       int accumulate, const float* xmax, const float* dymax, float* ws, long ws_floats, void* stream);
 /* (math 4: xmax / dymax = objgan_absmax_partials of x / dy; launches planned on the LDS-staged or first-generation
  * kernels run bf16x3 instead -- both are fp32-result arithmetics) */
+/* math 5: `x` is the fp16 RECORD of the source (objgan_h2_records under xmax; dy stays the fp32 tensor): the lanes read
+ * half records and transpose them through LDS (ds_read_b64_tr_b16) instead of gathering 32 (channel, tap) planes per
+ * wave from the fp32 tensor and splitting on the VALU.  Same products per 16-pixel step as math 4 (fp32 results; the
+ * pixel splits differ, so the two are equal up to summation order).  Only where objgan_conv_wgrad_rec_ok says so
+ * (OH * OW % 32 == 0, OH, OW <= 256, (H - 1) * W < 65535). */
+int objgan_conv_wgrad_rec_ok(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ksize);
 
 /* ---- frozen text encoder (reference model.py:85-179 RNN_ENCODER: Embedding + bidirectional LSTM on
  * a packed sequence).  table [ntoken][I]; captions [B][L] int64; lens [B] int32; wt_ih [2][I][4H] and

@@ -42,6 +42,7 @@ static void og_absmax_launch(const float* x, long n, float* out, hipStream_t s);
 
 // conv_igemm_rec.hip: the instances of conv_igemm3_kernel that read pre-split fp16 records (math 5)
 int og_launch_igemm3_rec(const IgemmArgs& a, int TM, int nw, int ng, dim3 grid, hipStream_t s);
+int og_launch_wgrad_rec(const WgradArgs& a, int tm, int nw, dim3 grid, int ksize, int Cp, hipStream_t s);
 
 template <int WM, int TM>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
@@ -691,47 +692,7 @@ __global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ y, co
     }
 }
 
-// ---- weight gradient -------------------------------------------------------------------
-//   dw[co][ci*T + t] += sum_{n,oh,ow} dy[n,co,oh,ow] * x[n,ci,oh*s - pad + kh, ow*s - pad + kw]
-// GEMM: M = cout, N = cin*T columns, K = pixels (split across gridDim.y, fp32 atomics into
-// a zero-initialised dw).  Both operands are contiguous along K (pixels) in HBM, so the
-// LDS tiles are [row][BK+1] (padded: conflict-free column reads by the MFMA lanes).
-struct WgradArgs {
-    const float* x;    // [N, Cin, H, W]
-    const float* dy;   // [N, Cout, OH, OW]
-    float* dw;         // [Cout][Cin*T]
-    int N, Cin, H, W, LH, LW;
-    int Cout, OH, OW;
-    int stride, pad, pad_mode, upsample;
-    int m_begin, m_end;
-    int ncol;
-    int pix_per_split;
-    int math;          // 0 fp32, 1 bf16 inputs, 2 bf16x3, 4 fp16x2 (register-fragment kernel only; else bf16x3 runs)
-    const float* xmax;   // math 4: per-workgroup maxima of |x| and |dy| (objgan_absmax_partials)
-    const float* dymax;
-    // Where a workgroup's tile goes.  One split (gridDim.y == 1): straight into dw -- stored, or added to what is there
-    // when `accumulate` -- every element by exactly one thread.  Several splits: the partial tile of split s goes to
-    // ws[s * ws_stride + (m - m_begin) * ncol + col] (extra rows behind the block rows); wgrad_combine_kernel sums the
-    // splits in order.  No atomics, no zero-fill: the weight gradient is bit-reproducible.
-    float* ws;
-    long ws_stride;
-    int accumulate;
-    int xr_begin, xr_count;   // XR kernels: dy rows [xr_begin, xr_begin + xr_count) (<= 4) are carried by block row 0 on
-                              // the fp32 VALU instead of costing a 32-row MFMA group (194 = 6*32 + 2, 388 = 12*32 + 4):
-                              // the lane's eight gathered values (its MFMA operand) meet the extra rows' dy values read
-                              // as LDS broadcasts; the two pixel halves of a column meet in one shuffle in the epilogue.
-                              // r02: -8 % on the 194 / 388-channel weight gradients at 128^2, -20 % at 32^2.
-};
-
-__device__ __forceinline__ void og_wgrad_store(const WgradArgs& a, int m, int col, float v, int split) {
-    if (a.ws) {
-        a.ws[(size_t)split * a.ws_stride + (size_t)(m - a.m_begin) * a.ncol + col] = v;
-    } else {
-        float* p = a.dw + (size_t)m * a.ncol + col;
-        *p = a.accumulate ? *p + v : v;
-    }
-}
-// extra row j of the XR kernels: local row (m_end - m_begin) + j of the workspace slot
+// (WgradArgs / og_wgrad_store: conv_igemm3.h)
 __device__ __forceinline__ void og_wgrad_store_xr(const WgradArgs& a, int j, int col, float v, int split) {
     if (a.ws) {
         a.ws[(size_t)split * a.ws_stride + (size_t)(a.m_end - a.m_begin + j) * a.ncol + col] = v;
@@ -1986,6 +1947,8 @@ OG_KNOB(og_rec_ng2_min, "OG_REC_NG2_MIN", 1024)     // ... while the grid keeps 
 OG_KNOB(og_rec_nw8_tm, "OG_REC_NW8_TM", 4)          // fp16x2 on records: 8-wave workgroups from this block-row height on
 OG_KNOB(og_rec_tmmax, "OG_REC_TMMAX", 7)            // ... tallest block row
 OG_KNOB(og_rec_ng2_nw8, "OG_REC_NG2_NW8", 0)        // ... 1: two pixel groups per wave also in 8-wave workgroups
+OG_KNOB(og_wgrad_rec_tmmax, "OG_WGRAD_REC_TMMAX", 6)  // weight gradient on records: tallest block row (7: one wave per SIMD)
+OG_KNOB(og_wgrad_rec_nw8, "OG_WGRAD_REC_NW8", 1)      // ... 8-wave workgroups for block rows <= 6 on >= 16384 pixels
 static int og_igemm_tmmax() { const int v = og_igemm_tmmax_raw(); return (v < 1 || v > 8) ? 8 : v; }
 
 // ---- host side ---------------------------------------------------------------------------
@@ -2744,6 +2707,15 @@ int objgan_reflect_ring_fold(const float* ring, float* y, long planes, int H, in
 
 }  // extern "C"
 
+// Does the record form of the weight gradient (conv_wgrad_rec_kernel, math 5) take this geometry?
+static bool og_wgrad_rec_geometry(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ksize) {
+    const long OHW = (long)OH * OW;
+    const long Cp = ((long)Cin + 15) / 16 * 16;
+    return !og_igemm_v1() && (OW % 8 == 0) && (OHW % 32 == 0) && OH <= 256 && OW <= 256 && (long)(H - 1) * W < 65535
+           && (ksize == 1 || ksize == 3 || ksize == 4)
+           && (double)N * Cp * H * W * 4.0 < 4.0e9 && (double)N * Cout * OHW * 4.0 < 4.0e9;
+}
+
 // Plan and (unless ws_need != nullptr: plan only) run the weight gradient.  The reduction over pixels is split across
 // gridDim.y; each split writes its partial tile into its own workspace slot and wgrad_combine_kernel sums the slots
 // in split order into dw (stored, or added when `accumulate`): bit-reproducible, dw needs no zero-fill.
@@ -2756,13 +2728,17 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
     long ws_used = 0;
     if (plan_only) *ws_need = 0;
     if (ksize != 1 && ksize != 3 && ksize != 4) return OG_BAD_ARGS;
-    if (math < 0 || math > 4 || math == 3) return OG_BAD_ARGS;
-    if (math == 4 && !plan_only && (!xmax || !dymax)) return OG_BAD_ARGS;
+    if (math < 0 || math > 5 || math == 3) return OG_BAD_ARGS;
+    if (math >= 4 && !plan_only && (!xmax || !dymax)) return OG_BAD_ARGS;
     if (N <= 0 || Cout <= 0 || Cin <= 0) return OG_OK;
+    // math 5: x is the fp16 record of the source (conv_igemm_rec.hip), dy the fp32 tensor: conv_wgrad_rec_kernel.  The
+    // caller asks objgan_conv_wgrad_rec_ok first; a geometry the record kernel does not take is an argument error here.
+    const bool rec = math == 5;
+    if (rec && !og_wgrad_rec_geometry(N, Cin, H, W, Cout, OH, OW, ksize)) return OG_BAD_ARGS;
     // fp16x2 lives in the register-fragment kernel; launches that plan the LDS-staged / first-generation kernels run
     // bf16x3 (both are fp32-result arithmetics)
     const bool h2 = math == 4;
-    if (h2) math = 2;
+    if (h2 || rec) math = 2;
     WgradArgs a;
     a.xmax = xmax; a.dymax = dymax;
     a.ws = nullptr; a.ws_stride = 0; a.accumulate = accumulate;
@@ -2814,7 +2790,7 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
             og_row_plan(groups - 1, tiles_n0, 1, &TM, &full_rows, &rest);
             if (TM >= 2 && full_rows >= 1) groups -= 1; else xrows = false;
         }
-        og_row_plan(groups, tiles_n0, 1, &TM, &full_rows, &rest);      // (tall tiles: independent of the column tiling)
+        og_row_plan(groups, tiles_n0, 1, &TM, &full_rows, &rest, 100, rec ? og_wgrad_rec_tmmax() : 7);      // (tall tiles: independent of the column tiling)
         a.xr_begin = groups * 32;
         for (int part = 0; part < 2; ++part) {
             const int tm = part == 0 ? TM : rest;
@@ -2840,9 +2816,10 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
             const bool use3 = bf ? tm <= 2 : (sp ? x3_frag : (tm <= og_wgrad3_maxtm() || b128));
             // bf16x3, register-fragment form: 8-wave workgroups (256 columns per dy row tile), as in run_igemm2
             const int nw = bfb ? ((tm <= 6 && Npix >= 16384) ? 8 : 4)
-                               : ((sp && use3 && tm >= 4 && og_nw8_min() > 0 && Npix >= 16384) ? 8 : 4);
-            // column tiles: 32 columns (ci * T + t) per wave; bfb: one (tap, 32-channel group) per wave
-            const int tiles_n = bfb ? og_cdiv(ksize * ksize * og_cdiv(Cpb, 32), nw) : og_cdiv(a.ncol, 32 * nw);
+                               : (rec ? ((tm <= 6 && Npix >= 16384 && og_wgrad_rec_nw8()) ? 8 : 4)
+                                      : ((sp && use3 && tm >= 4 && og_nw8_min() > 0 && Npix >= 16384) ? 8 : 4));
+            // column tiles: 32 columns (ci * T + t) per wave; bfb / rec: one (tap, 32-channel group) per wave
+            const int tiles_n = (bfb || rec) ? og_cdiv(ksize * ksize * og_cdiv(Cpb, 32), nw) : og_cdiv(a.ncol, 32 * nw);
             int splits;
             const int max_splits = og_cdiv(Npix, 512);       // >= 32 K steps per split
             if (og_wgrad_oldsplit()) {
@@ -2865,7 +2842,7 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
                 }
             }
             int pps = og_cdiv(Npix, splits);
-            pps = bfb ? (pps + 31) / 32 * 32 : (pps + 15) / 16 * 16;
+            pps = (bfb || rec) ? (pps + 31) / 32 * 32 : (pps + 15) / 16 * 16;
             splits = og_cdiv(Npix, pps);
             a.pix_per_split = pps;
             {
@@ -2883,8 +2860,9 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
                 fprintf(stderr, "OGTRACE wgrad TM=%d NW=%d form=%d Cout=%d Cin=%d k=%d N=%d OH=%d OW=%d stride=%d grid=%u,%u math=%d\n", tm, nw,
                         use3 ? 3 : 2, Cout, Cin, ksize, N, OH, OW, stride, grid.x, grid.y, math);
             ProfRec* pr = prof_begin(bfb ? OG_CAT_WGRAD2(tm)
-                                         : (use3 ? (nw == 8 ? OG_CAT_WGRAD3_NW8(tm) : OG_CAT_WGRAD3(tm)) + (h2 ? 48 : 0)
-                                                 : OG_CAT_WGRAD2(tm)),
+                                         : (rec ? (nw == 8 ? OG_CAT_WGRAD3_NW8(tm) : OG_CAT_WGRAD3(tm)) + 96
+                                                : (use3 ? (nw == 8 ? OG_CAT_WGRAD3_NW8(tm) : OG_CAT_WGRAD3(tm)) + (h2 ? 48 : 0)
+                                                        : OG_CAT_WGRAD2(tm))),
                                      2.0 * (a.m_end - a.m_begin + a.xr_count) * (double)a.ncol * (double)Npix, s);
             prof_meta(pr, 1, tm, a.m_end - a.m_begin + a.xr_count, Cin, ksize * ksize, N, OH, OW,
                       stride * (upsample ? 10 : 1) * (pad_mode ? -1 : 1), splits);
@@ -2912,7 +2890,10 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
                     else if (use3 && b128) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, 0, true>), grid, dim3(256), 0, s, a, ksize); \
                     else if (use3) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv>), grid, dim3(256), 0, s, a, ksize); \
                     else hipLaunchKernelGGL((conv_wgrad2_kernel<TMv>), grid, dim3(256), 0, s, a, ksize);
-            if (bfb) {
+            if (rec) {
+                const int rc_ = og_launch_wgrad_rec(a, tm, nw, grid, ksize, Cpb, s);
+                if (rc_ != OG_OK) { prof_end(pr, s); return rc_; }
+            } else if (bfb) {
 #define OG_WGB(TMv) if (nw == 8) hipLaunchKernelGGL((conv_wgrad_bfb_kernel<(TMv <= 6 ? TMv : 6), 8>), grid, dim3(512), 0, s, a, xb, dyb, ksize, Cpb); \
                     else hipLaunchKernelGGL((conv_wgrad_bfb_kernel<TMv, 4>), grid, dim3(256), 0, s, a, xb, dyb, ksize, Cpb);
                 switch (tm) {
@@ -3023,6 +3004,12 @@ long objgan_conv_wgrad_ws_floats(int N, int Cin, int H, int W, int upsample, int
     (void)og_wgrad(nullptr, nullptr, nullptr, N, Cin, H, W, upsample, pad_mode, Cout, OH, OW, ksize, stride, pad, math, 0,
                    nullptr, 0, &need, nullptr);
     return need;
+}
+
+// 1 if objgan_conv_wgrad takes math 5 (x as its fp16 record, see objgan_h2_records) for this geometry.  Host-only.
+int objgan_conv_wgrad_rec_ok(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ksize) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || OH <= 0 || OW <= 0) return 0;
+    return og_wgrad_rec_geometry(N, Cin, H, W, Cout, OH, OW, ksize) ? 1 : 0;
 }
 
 // dw [Cout][Cin][k][k] = (accumulate ? dw : 0) + sum dy * x.  ws: objgan_conv_wgrad_ws_floats(...) floats of scratch.

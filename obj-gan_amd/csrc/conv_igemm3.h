@@ -793,3 +793,45 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
             atomicMax(reinterpret_cast<unsigned*>(a.ymax) + ((blockIdx.x * NW + wid) & (OG_AMAX_SLOTS - 1)), __float_as_uint(wm));
     }
 }
+
+// ---- weight gradient -------------------------------------------------------------------
+//   dw[co][ci*T + t] += sum_{n,oh,ow} dy[n,co,oh,ow] * x[n,ci,oh*s - pad + kh, ow*s - pad + kw]
+// GEMM: M = cout, N = cin*T columns, K = pixels (split across gridDim.y, fp32 atomics into
+// a zero-initialised dw).  Both operands are contiguous along K (pixels) in HBM, so the
+// LDS tiles are [row][BK+1] (padded: conflict-free column reads by the MFMA lanes).
+struct WgradArgs {
+    const float* x;    // [N, Cin, H, W]
+    const float* dy;   // [N, Cout, OH, OW]
+    float* dw;         // [Cout][Cin*T]
+    int N, Cin, H, W, LH, LW;
+    int Cout, OH, OW;
+    int stride, pad, pad_mode, upsample;
+    int m_begin, m_end;
+    int ncol;
+    int pix_per_split;
+    int math;          // 0 fp32, 1 bf16 inputs, 2 bf16x3, 4 fp16x2 (register-fragment kernel only; else bf16x3 runs)
+    const float* xmax;   // math 4: per-workgroup maxima of |x| and |dy| (objgan_absmax_partials)
+    const float* dymax;
+    // Where a workgroup's tile goes.  One split (gridDim.y == 1): straight into dw -- stored, or added to what is there
+    // when `accumulate` -- every element by exactly one thread.  Several splits: the partial tile of split s goes to
+    // ws[s * ws_stride + (m - m_begin) * ncol + col] (extra rows behind the block rows); wgrad_combine_kernel sums the
+    // splits in order.  No atomics, no zero-fill: the weight gradient is bit-reproducible.
+    float* ws;
+    long ws_stride;
+    int accumulate;
+    int xr_begin, xr_count;   // XR kernels: dy rows [xr_begin, xr_begin + xr_count) (<= 4) are carried by block row 0 on
+                              // the fp32 VALU instead of costing a 32-row MFMA group (194 = 6*32 + 2, 388 = 12*32 + 4):
+                              // the lane's eight gathered values (its MFMA operand) meet the extra rows' dy values read
+                              // as LDS broadcasts; the two pixel halves of a column meet in one shuffle in the epilogue.
+                              // r02: -8 % on the 194 / 388-channel weight gradients at 128^2, -20 % at 32^2.
+};
+
+__device__ __forceinline__ void og_wgrad_store(const WgradArgs& a, int m, int col, float v, int split) {
+    if (a.ws) {
+        a.ws[(size_t)split * a.ws_stride + (size_t)(m - a.m_begin) * a.ncol + col] = v;
+    } else {
+        float* p = a.dw + (size_t)m * a.ncol + col;
+        *p = a.accumulate ? *p + v : v;
+    }
+}
+// extra row j of the XR kernels: local row (m_end - m_begin) + j of the workspace slot

@@ -83,6 +83,7 @@ SIGNATURES = {
     "objgan_mask_resize": [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr],
     "objgan_prof_enable": [_c_int],
     "objgan_conv_bank_layout": [_c_int] * 10,
+    "objgan_conv_wgrad_rec_ok": [_c_int] * 8,
     "objgan_prof_collect": [_ptr, _ptr, _ptr],
     "objgan_prof_dump": [_ptr, _ptr, _ptr, _c_int, _ptr],
 }

@@ -185,6 +185,8 @@ _REC = {"on": _os.environ.get("OBJGAN_H2_RECORDS", "1") != "0",
         # when the launch does enough arithmetic per element of its pixel operand: 2 * M * taps * (output / input pixels)
         # flop per element (profiles/r05_records_convbench.txt).  A tensor that already carries its record is always read
         # through it.
+        # the weight gradient reads x through its record where that pays ("all": wherever the geometry allows; "0": never)
+        "wgrad": {"0": False, "all": "all"}.get(_os.environ.get("OBJGAN_REC_WGRAD", "1"), True),
         "min_i": float(_os.environ.get("OBJGAN_REC_MIN_I", "2500")),
         "min_i_short": float(_os.environ.get("OBJGAN_REC_MIN_I_SHORT", "1200"))}
 
@@ -583,7 +585,24 @@ def _conv_wgrad(x, g, Cout, k, stride, pad, refl, upsample, sink=None):
     if math == 4 and _H2_CENSUS is not None:
         _census("weight gradient: x channels (filter columns)", x, 1)
         _census("weight gradient: dy channels (filter rows)", g, 1)
-    _lib.call("objgan_conv_wgrad", _p(x), _p(g), _p(dw_), *geo, 0 if sink is None else 1, _p(xmax), _p(gmax), _p(ws), nws,
+    xk = x
+    # Where: measured per shape class (profiles/r05_records_convbench.txt).  The record form wins where the register-
+    # fragment gather has no constant-stride fast path or runs on few pixels -- up-sampled sources 120 -> 257 TFLOP/s,
+    # reflect-padded maps up to 64 x 64: 85 -> 137 at 32 x 32 -- ties on the large stride-1 / stride-2 layers (254 vs 258,
+    # 251 vs 269) and loses where it has to give up the 7-group block row (194 -> 194 at 128 x 128: 239 vs 214) or runs
+    # 4-wave workgroups at one wave per SIMD (16 x 16 maps, 186 vs 129): those keep the gather form.
+    rec_pays = bool(upsample) or (refl and H * W <= 4096) or _REC["wgrad"] == "all"
+    if (math == 4 and _REC["on"] and _REC["wgrad"] and rec_pays and not (x.data_ptr() & 15) and
+            _lib.load().objgan_conv_wgrad_rec_ok(N, Cin, H, W, Cout, g.shape[2], g.shape[3], k)):
+        # x as its fp16 record (usually the one the forward convolution of this layer made): half-record loads +
+        # transposing LDS reads instead of 32-plane gathers and the split on the VALU
+        rec = _records(x, xmax, N, Cin, H * W, 2.0 * Cout * k * k * g.shape[2] * g.shape[3] / float(H * W), Cout)
+        if rec is not None:
+            geo = geo[:-1] + (5,)
+            nws = _lib.load().objgan_conv_wgrad_ws_floats(*geo)
+            ws = torch.empty(nws, dtype=_F32, device=x.device) if nws > 0 else None
+            xk = rec
+    _lib.call("objgan_conv_wgrad", _p(xk), _p(g), _p(dw_), *geo, 0 if sink is None else 1, _p(xmax), _p(gmax), _p(ws), nws,
               _stream())
     if sink is not None:
         sink[1]()

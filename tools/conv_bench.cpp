@@ -161,8 +161,10 @@ int main(int argc, char** argv) {
             }
         };
         auto wgrad = [&]() {
-            int rc = objgan_conv_wgrad(dx, dg, dgw, sh.N, sh.Cin, sh.H, sh.W, sh.up, sh.refl, sh.Cout, OH, OW, sh.k, sh.s, sh.p, kmath,
-                                       0, mxx, mxg, wsb, nwsb, st);
+            // math 5: x as its record where the record form of the weight gradient takes the geometry
+            const bool wrec = g_math == 5 && objgan_conv_wgrad_rec_ok(sh.N, sh.Cin, sh.H, sh.W, sh.Cout, OH, OW, sh.k);
+            int rc = objgan_conv_wgrad(wrec ? recx : dx, dg, dgw, sh.N, sh.Cin, sh.H, sh.W, sh.up, sh.refl, sh.Cout, OH, OW, sh.k, sh.s, sh.p,
+                                       wrec ? 5 : kmath, 0, mxx, mxg, wsb, nwsb, st);
             if (rc != 1) { fprintf(stderr, "wgrad rc=%d\n", rc); exit(1); }
         };
         auto timeit = [&](auto&& fn) {
@@ -258,7 +260,7 @@ int main(int argc, char** argv) {
         {
             std::vector<float> hgx2(ngx);
             CK(hipMemcpy(hgx2.data(), dgx, ngx * 4, hipMemcpyDeviceToHost));
-            printf("    hash fwd %016llx dgrad %016llx", fnv(hy.data(), ny), fnv(hgx2.data(), ngx));
+            printf("    hash fwd %016llx dgrad %016llx wgrad %016llx", fnv(hy.data(), ny), fnv(hgx2.data(), ngx), fnv(hgw.data(), nw));
             if (g_math == 5) printf("  | record passes (absmax + split): x %.3f ms  dy %.3f ms", tpx, tpg);
             printf("\n");
         }
