@@ -163,9 +163,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk_all = a.Kpad / BK;
-    const int kt0 = a.ksplit_steps > 0 ? blockIdx.y * a.ksplit_steps : 0;
-    const int nk = a.ksplit_steps > 0 ? min(nk_all, kt0 + a.ksplit_steps) : nk_all;
+    const int kt0 = 0;                         // (this kernel is never split along K: no fp32 atomics in the library's convolutions)
+    const int nk = a.Kpad / BK;
     load_a(kt0 * BK);
     load_b(kt0);
     store_tiles(0);
@@ -215,13 +214,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
                 if (m < a.m_end) {
                     float v = acc[i][j][r];
-                    if (a.ksplit_steps > 0) {
-                        atomicAdd(&yb[(size_t)m * a.OHf * a.OWf], v);   // bias/act: follow-up pass
-                    } else {
-                        if (a.bias) v += a.bias[m];
-                        v = og_act(v, a.act);
-                        yb[(size_t)m * a.OHf * a.OWf] = v;
-                    }
+                    if (a.bias) v += a.bias[m];
+                    v = og_act(v, a.act);
+                    yb[(size_t)m * a.OHf * a.OWf] = v;
                 }
             }
         }
@@ -1962,8 +1957,7 @@ static inline int igemm_tiles(const IgemmArgs& a, int cfg) {
 
 static int launch_igemm(const IgemmArgs& a, int cfg, hipStream_t s) {
     const int g = igemm_tiles(a, cfg);
-    const int splits = a.ksplit_steps > 0 ? og_cdiv(a.Kpad / 16, a.ksplit_steps) : 1;
-    dim3 grid(g, splits);
+    dim3 grid(g, 1);
     if (cfg == 0) hipLaunchKernelGGL((conv_igemm_kernel<2, 2>), grid, dim3(256), 0, s, a);
     else if (cfg == 1) hipLaunchKernelGGL((conv_igemm_kernel<1, 2>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((conv_igemm_kernel<1, 1>), grid, dim3(256), 0, s, a);
@@ -1982,35 +1976,15 @@ static int og_row_parts(int M, RowPart* parts) {
     return n;
 }
 
-// Small-grid / long-K launches (discriminator heads at 4x4..16x16, `outlogits` with one output
-// channel and K = 12288) would run on a handful of CUs for hundreds of serial K steps: they are
-// split along K across gridDim.y, partial tiles are accumulated with fp32 atomics into a zeroed
-// output and bias/activation are applied by a follow-up streaming pass.
+// The first-generation kernel serves tensors beyond the 2 GiB reach of a buffer descriptor: grids of thousands of
+// workgroups, never split along K.  (Rounds 1-4 kept an fp32-atomics split-K form of it for small grids; the training step
+// never took it -- small grids run conv_igemm3_kernel with the ordered workspace reduction -- and it is gone: no fp32
+// atomic is left in the library's convolutions, `-munsafe-fp-atomics` is no longer a build flag of this file.)
 static int run_igemm(IgemmArgs a, hipStream_t s, int y_prezeroed) {
+    (void)y_prezeroed;
     RowPart parts[3];
     const int np = og_row_parts(a.M, parts);
-    int tiles = 0;
-    for (int i = 0; i < np; ++i) {
-        a.m_begin = parts[i].m_begin; a.m_end = parts[i].m_end;
-        tiles += igemm_tiles(a, parts[i].cfg);
-    }
-    const int nk = a.Kpad / 16;
-    const bool full_cover = (a.osh == 1 && a.osw == 1 && a.PH == a.OHf && a.PW == a.OWf);
-    int splits = 1;
-    if (tiles < 128 && nk >= 16 && (full_cover || y_prezeroed)) {
-        splits = og_cdiv(512, tiles);
-        if (splits > nk / 4) splits = nk / 4;
-    }
-    const float* bias = a.bias;
-    const int act = a.act;
-    if (splits > 1) {
-        a.ksplit_steps = og_cdiv(nk, splits);
-        a.bias = nullptr; a.act = OG_ACT_NONE;
-        if (!y_prezeroed)
-            (void)hipMemsetAsync(a.y, 0, sizeof(float) * (size_t)a.N * a.M * a.OHf * a.OWf, s);
-    } else {
-        a.ksplit_steps = 0;
-    }
+    a.ksplit_steps = 0;
     for (int i = 0; i < np; ++i) {
         a.m_begin = parts[i].m_begin; a.m_end = parts[i].m_end;
         const double fl = 2.0 * (a.m_end - a.m_begin) * (double)a.K * ((double)a.N * a.PH * a.PW);
@@ -2018,12 +1992,6 @@ static int run_igemm(IgemmArgs a, hipStream_t s, int y_prezeroed) {
         int rc = launch_igemm(a, parts[i].cfg, s);
         prof_end(pr, s);
         if (rc != OG_OK) return rc;
-    }
-    if (splits > 1 && (bias || act != OG_ACT_NONE) && full_cover) {
-        const long total = (long)a.N * a.M * a.OHf * a.OWf;
-        hipLaunchKernelGGL(bias_act_kernel, dim3(og_stream_grid(total, 256)), dim3(256), 0, s, a.y, bias,
-                           total, a.M, a.OHf * a.OWf, act);
-        return og_launch_status();
     }
     return OG_OK;
 }
@@ -2308,8 +2276,8 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed, float* ws, lo
         if (need > 0) {                       // two-level reduction through the caller's workspace
             if (!ws || ws_floats < need) return OG_BAD_ARGS;
             a.ws = ws; a.ws_stride = y_elems + ring_elems;
-        } else if (!y_prezeroed) {            // (not reached: partial coverage splits only when y is pre-zeroed)
-            (void)hipMemsetAsync(a.y, 0, sizeof(float) * (size_t)y_elems, s);
+        } else {
+            return OG_BAD_ARGS;               // (not reached: the plan splits only launches that cover their output)
         }
     } else {
         a.ksplit_steps = 0;

@@ -47,8 +47,7 @@ struct IgemmArgs {
     int act;
     int ksplit_steps;    // > 0: split-K -- blockIdx.y owns this many BK steps; epilogue: its partial tile goes to
                          // ws[blockIdx.y][...] (conv_igemm3_kernel; summed in split order by splitk_combine_kernel,
-                         // which also applies bias / activation: bit-reproducible, no zero-fill) or, ws == nullptr, is
-                         // added to a zeroed y with fp32 atomics (partial-coverage launches, first-generation kernel)
+                         // which also applies bias / activation: bit-reproducible, no zero-fill, no atomics)
     float* ws;           // split-K partials [splits][ws_stride]: y-shaped, then (ring mode) ring-shaped
     long ws_stride;
     int nphase;          // > 1 (conv_igemm3_kernel only): workgroup id % nphase = output phase p with its own tap table
@@ -773,10 +772,8 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
                 const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
                 if (m < a.m_end) {
                     float v = H2 ? acc[i * NG + g][r] * h2_inv : acc[i * NG + g][r];
-                    if (to_ws) {
+                    if (to_ws) {           // (a split launch always has its workspace: run_igemm2)
                         yb[(size_t)m * plane] = v;
-                    } else if (split) {
-                        atomicAdd(&yb[(size_t)m * plane], v);
                     } else {
                         if (a.bias) v += a.bias[m];
                         v = lrelu ? (v > 0.f ? v : 0.2f * v) : (relu ? fmaxf(v, 0.f) : v);

@@ -22,10 +22,9 @@ if os.environ.get("OBJGAN_DEV") == "1":
 # ROIAlign index math must be bit-exact with the reference C loop: no FMA contraction.
 # The Pillow-exact image resize evaluates its filter coefficients in double in Pillow's operation order.
 # -munsafe-fp-atomics (hardware fp32 atomic add instead of a CAS loop) only where a float atomic is left: the
-# reference-signature objgan_roi_align_backward (unordered scatter, as the CUDA original) and the first-generation /
-# partial-coverage split-K path of conv_igemm.hip; the training step itself runs without fp32 atomics.
-PER_FILE_FLAGS = {"roi_align.hip": ["-ffp-contract=off", "-munsafe-fp-atomics"], "resize_pil.hip": ["-ffp-contract=off"],
-                  "conv_igemm.hip": ["-munsafe-fp-atomics"], "conv_igemm_rec.hip": ["-munsafe-fp-atomics"]}
+# reference-signature objgan_roi_align_backward (unordered scatter, as the CUDA original).  The convolution files carry
+# no fp32 atomic any more (round 5: the first-generation split-K path is gone); the training step runs without any.
+PER_FILE_FLAGS = {"roi_align.hip": ["-ffp-contract=off", "-munsafe-fp-atomics"], "resize_pil.hip": ["-ffp-contract=off"]}
 
 
 def _hipcc():
