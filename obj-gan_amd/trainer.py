@@ -110,6 +110,7 @@ class ParamArena(object):
         self._armed = None
         for i, p in enumerate(self.params):
             p.register_post_accumulate_grad_hook(lambda *_a, i=i: self._mark(i))
+            p.register_hook(lambda g, i=i: self._autograd_piece(i))      # fires only when autograd delivers a gradient
         return self.buckets
 
     def arm(self, on_bucket):
@@ -120,28 +121,36 @@ class ParamArena(object):
         collectives identical on every rank even when a rank's batch prunes a branch of its graph."""
         self.make_buckets()
         self._armed = (on_bucket, [set(mem) for (_, _, mem) in self.buckets], [len(self.buckets) - 1])
-        self._sink_marked = set()
-        self._grad_versions = [p.grad._version if p.grad is not None else -1 for p in self.params]
+        self._sink_marked, self._hook_marked = set(), set()
+
+    def _two_pieces(self, i):
+        names = [k for k, p_ in self.module.named_parameters() if p_.requires_grad]
+        raise RuntimeError("ParamArena: parameter %d (%s) is used more than once per forward (its gradient arrived "
+                           "in two pieces during one armed backward pass): the bucketed all-reduce would ship a "
+                           "partial gradient -- switch the trainer's direct_wgrad off for this network"
+                           % (i, names[i] if i < len(names) else "?"))
+
+    def _autograd_piece(self, i):
+        """tensor hook of parameter i: autograd is about to accumulate a (defined) gradient into it"""
+        if self._armed is not None and i in self._sink_marked:
+            self._two_pieces(i)            # the sink already reported this parameter as complete
+        return None
 
     def _mark(self, i, from_sink=False):
         if self._armed is None:
             return
-        # AccumulateGrad's post-hook fires once per backward pass and parameter, after ALL contributions were summed (also
-        # when the only contribution went through the sink and autograd was handed None).  The direct weight-gradient
-        # sink of ops (`_grad_sink`) reports once per USE of the weight, from inside that use's backward: a weight used
-        # twice per forward -- two sink reports, or a sink report followed by a contribution through autograd (the hook
-        # then finds the gradient view's version counter moved: autograd's in-place accumulation bumps it, the sink's
-        # raw-pointer add does not) -- would hand its bucket to the all-reduce before its gradient is complete.  Refuse.
-        late = (not from_sink and i in self._sink_marked and self.params[i].grad is not None
-                and self.params[i].grad._version != self._grad_versions[i])
-        if (from_sink and i in self._sink_marked) or late:
-            names = [k for k, p_ in self.module.named_parameters() if p_.requires_grad]
-            raise RuntimeError("ParamArena: parameter %d (%s) is used more than once per forward (its gradient arrived "
-                               "in two pieces during one armed backward pass): the bucketed all-reduce would ship a "
-                               "partial gradient -- switch the trainer's direct_wgrad off for this network"
-                               % (i, names[i] if i < len(names) else "?"))
+        # AccumulateGrad's post-hook fires once per backward pass and parameter, after ALL contributions that went through
+        # autograd were summed (also when the only contribution went through the sink and autograd was handed None).  The
+        # direct weight-gradient sink of ops (`_grad_sink`) reports once per USE of the weight, from inside that use's
+        # backward.  A weight used twice per forward -- two sink reports, a sink report after the post-hook, or a sink
+        # report followed by a gradient through autograd (`_autograd_piece`) -- would hand its bucket to the all-reduce
+        # before its gradient is complete.  Refuse loudly.
         if from_sink:
+            if i in self._sink_marked or i in self._hook_marked:
+                self._two_pieces(i)
             self._sink_marked.add(i)
+        else:
+            self._hook_marked.add(i)
         on_bucket, waiting, nxt = self._armed
         waiting[self._bucket_of[i]].discard(i)
         while nxt[0] >= 0 and not waiting[nxt[0]]:
@@ -432,6 +441,11 @@ class condGANTrainer(object):
     d_stream_map = dict(zip(_D_JOB_NAMES, (2, 4, 3, 3, 4, 2, 1, 0)))
     direct_wgrad = True             # weight gradients straight into the arenas during train_step (ops._grad_sink)
     debug_after_d_updates = None    # tests: callable(trainer) between the discriminator updates and the generator loss
+    # Order in which the host ISSUES the discriminator jobs (names; jobs not listed keep their reference position behind the
+    # listed ones).  The patch discriminators draw no random numbers, so they can move without changing the python RNG
+    # sequence of the shape / object discriminators' permute_seg (which stay in the reference's relative order); the
+    # networks are independent, so the results do not depend on the order.  OBJGAN_D_ORDER="errPatD2,..." overrides.
+    d_job_order = None
 
     @classmethod
     def _stream_map_from_env(cls):
@@ -570,6 +584,15 @@ class condGANTrainer(object):
         # (discriminator heads on 4x4 .. 16x16 maps, normalisation / combine kernels of small layers) overlap with
         # another discriminator's work.  The host enqueues them in the reference order (python RNG draws of
         # permute_seg included); autograd replays every backward node on the stream of its forward.
+        order = ([n for n in os.environ["OBJGAN_D_ORDER"].split(",") if n] if os.environ.get("OBJGAN_D_ORDER")
+                 else self.d_job_order)
+        if order:
+            rng_users = [n for n in order if not n.startswith("errPatD")]
+            ref = [j[0] for j in jobs if not j[0].startswith("errPatD")]
+            if rng_users != [n for n in ref if n in rng_users]:
+                raise ValueError("d_job_order moves a job that draws random numbers out of the reference order: %s" % order)
+            by_name = dict((j[0], j) for j in jobs)
+            jobs = [by_name[n] for n in order if n in by_name] + [j for j in jobs if j[0] not in order]
         pending = []
         side = self._d_side_streams()
         main = torch.cuda.current_stream() if side else None

@@ -822,7 +822,7 @@ def test_fp16x2_on_records_equals_the_gather_form_bit_for_bit(dev, case):
     assert torch.equal(outs[0][1], outs[1][1]), ("dgrad", rel_l2(outs[0][1], outs[1][1]))
     # (the weight gradient: same products per 16-pixel step; where the record form runs, its pixel splits differ from
     # the gather form's -- equal up to the summation order of the splits)
-    assert rel_l2(outs[0][2], outs[1][2]) < 2e-6, ("wgrad", rel_l2(outs[0][2], outs[1][2]))
+    assert rel_l2(outs[0][2], outs[1][2]) < 5e-6, ("wgrad", rel_l2(outs[0][2], outs[1][2]))
 
 
 def test_h2_records_layout_and_split(dev):
