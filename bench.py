@@ -640,10 +640,13 @@ def main():
                                                "on v_mfma_f32_32x32x16_bf16, fp32 accumulation: fp32 results (error vs "
                                                "fp64 <= the fp32 MFMA's, profiles/r03_parity.txt)",
                                      "fp16x2": "fp32 operands as two fp16 pieces of x * 2^s (s from the tensor's maximum; residual "
-                                               "<= 2^-24 |x|), 3 partial products on v_mfma_f32_32x32x16_f16, fp32 "
+                                               "<= 2^-23 |x|), 3 partial products on v_mfma_f32_32x32x16_f16, fp32 "
                                                "accumulation, scales undone exactly: fp32 results (error vs fp64 <= the "
-                                               "fp32 MFMA's, profiles/r04_parity.txt); launches below 1 GFLOP and the "
-                                               "LDS-staged weight-gradient kernels run bf16x3 (six products on the bf16 MFMA)",
+                                               "fp32 MFMA's, profiles/r05_parity.txt); the forward / data-gradient "
+                                               "launches that do enough arithmetic per operand element read the pixel "
+                                               "operand as its PRE-SPLIT fp16 record (round 5, bit-identical results); "
+                                               "launches below 1 GFLOP and the LDS-staged weight-gradient kernels run "
+                                               "bf16x3 (six products on the bf16 MFMA)",
                                      "bf16": "operands rounded to bf16, fp32 accumulation"}[args.math]},
         }
         if args.host_batches:

@@ -98,7 +98,7 @@ int objgan_conv_igemm(const float* x, const float* w, const float* bias, float* 
                       float* ws, long ws_floats, void* stream);
 /* math: 0 fp32 operands on the fp32 MFMA; 1 operands rounded to bf16; 2 "bf16x3" (fp32 operands split exactly three ways
  * on the bf16 MFMA, six products); 4 "fp16x2" (fp32 operands as two fp16 pieces of x * 2^s on the fp16 MFMA, three
- * products: residual <= 2^-24 |x| for every element within 2^-10 of its tensor's maximum, 2^-39 of that maximum below;
+ * products: residual <= 2^-23 |x| for every element within 2^-10 of its tensor's maximum, 2^-39 of that maximum below;
  * the filter bank's scale comes from partial maxima the pack path leaves behind the bank).  xmax: math 4 only -- the 1024
  * partial maxima of |x| (the kernel derives 2^s from them), written by objgan_absmax_partials or by the producer of x
  * itself (objgan_norm_forward / objgan_norm_backward / objgan_act_backward `amax`, this call's `ymax`); NULL otherwise.

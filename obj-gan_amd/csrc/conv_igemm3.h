@@ -133,7 +133,8 @@ __device__ __forceinline__ void og_split4(const f32x4 v, bf16x4& h, bf16x4& m, b
 
 // ---- fp32 on the fp16 matrix pipe ("fp16x2", math 4) --------------------------------------------------------------
 // v_mfma_f32_32x32x16_f16 runs at the rate of the bf16 MFMA, and fp16 carries 11 significand bits: TWO pieces
-// x * 2^s = h + l (round-to-nearest at each cut) leave |residual| <= 2^-24 |x| -- half an fp32 ulp -- as long as l stays
+// x * 2^s = h + l (round-to-nearest at each cut) leave |residual| <= 2^-23 |x| -- one fp32 ulp: h keeps 11 significand
+// bits, l the next 11 plus its sign (tests/test_kernels_gpu.py::test_h2_records_layout_and_split) -- as long as l stays
 // a normal fp16, which a power-of-two scale 2^s per operand tensor arranges (max |x| * 2^s in [2^14, 2^15): activations
 // and gradients from the per-workgroup maxima of objgan_absmax_partials, filter banks from the partial maxima the pack
 // path leaves behind the bank; an

@@ -84,7 +84,7 @@ _ACT = {None: 0, "none": 0, "lrelu": 1, "tanh": 2, "sigmoid": 3, "relu": 4}
 #             (the dropped products are below 2^-24 of a product, 30x below the accumulation rounding both modes
 #             share) at 2.67x the native fp32 matrix rate -- csrc/conv_igemm.hip `og_split8`; the same scheme as
 #             oneMKL's BF16x3 / cuBLAS's BF16x9 fp32 emulation
-#   "fp16x2"  fp32 operands, each as TWO fp16 pieces of x * 2^s (s from the tensor's maximum: |x * 2^s - h - l| <= 2^-24 |x|
+#   "fp16x2"  fp32 operands, each as TWO fp16 pieces of x * 2^s (s from the tensor's maximum: |x * 2^s - h - l| <= 2^-23 |x|
 #             for every element within 2^-10 of the maximum), the three products hh, hl, lh on v_mfma_f32_32x32x16_f16
 #             with fp32 accumulation, the scales undone exactly in the epilogue: fp32 results at HALF the matrix work of
 #             bf16x3 -- measured against fp64 its error is below bf16x3's and the fp32 MFMA's.  Taken by the large
