@@ -77,6 +77,24 @@ def cat_names(math):
 PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
+def pmc_lookup(kernels, name):
+    """HBM bytes per launch of a timing category from the committed counter passes: the category name is the kernel
+    instance's, or (weight-gradient kernels: the 16-byte and the dword gather form report into one category) a pattern
+    with `*` for one template argument -- then the launch-weighted mean over the matching instances."""
+    ent = kernels.get(name)
+    if ent is not None:
+        return ent["hbm_bytes_per_launch"]
+    if "*" not in name:
+        return None
+    import re
+    pat = re.compile("^" + re.escape(name).replace("\\*", "[^,>]*") + ("" if name.rstrip().endswith(">") else ".*") + "$")
+    hits = [v for k, v in kernels.items() if pat.match(k)]
+    n = sum(v.get("launches", 0) for v in hits)
+    if not hits or n <= 0:
+        return None
+    return int(sum(v["hbm_bytes_per_launch"] * v.get("launches", 0) for v in hits) / n)
+
+
 WORKLOADS = {
     # BASELINE.json configs[3] (the configuration `metric` is quoted on, per GPU) -- the default
     "stage3_obj": (3, True, "stage3_256x256_full_GD_step: RNN_ENCODER+G_NET(3 stages)+PatD x3+ShpD x3+"
@@ -672,8 +690,7 @@ def main():
                         pmc = json.load(open(PMC_TRAFFIC_JSON))
                         same = (pmc.get("conv_math") == args.math and pmc.get("per_gpu_batch") == args.batch
                                 and args.workload == "stage3_obj")       # the run the counters were collected on
-                        ent = pmc.get("kernels", {}).get(name) if same else None
-                        traffic = ent["hbm_bytes_per_launch"] if ent else None
+                        traffic = pmc_lookup(pmc.get("kernels", {}), name) if same else None
                         traffic_source = "profiles/pmc_traffic.json (%s)" % pmc.get("source", "committed rocprofv3 --pmc passes")
                     except (ValueError, KeyError, OSError):
                         traffic = None

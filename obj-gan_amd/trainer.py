@@ -110,7 +110,7 @@ class ParamArena(object):
         self._armed = None
         for i, p in enumerate(self.params):
             p.register_post_accumulate_grad_hook(lambda *_a, i=i: self._mark(i))
-            p.register_hook(lambda g, i=i: self._autograd_piece(i))      # fires only when autograd delivers a gradient
+            p.register_hook(lambda g, i=i: self._autograd_piece(i, g))   # (g is None when autograd was handed no gradient)
         return self.buckets
 
     def arm(self, on_bucket):
@@ -130,9 +130,10 @@ class ParamArena(object):
                            "partial gradient -- switch the trainer's direct_wgrad off for this network"
                            % (i, names[i] if i < len(names) else "?"))
 
-    def _autograd_piece(self, i):
-        """tensor hook of parameter i: autograd is about to accumulate a (defined) gradient into it"""
-        if self._armed is not None and i in self._sink_marked:
+    def _autograd_piece(self, i, g):
+        """tensor hook of parameter i: autograd is about to accumulate the gradient g into it (the hook also fires with
+        g = None when the backward function handed autograd no gradient -- the sink's case)"""
+        if g is not None and self._armed is not None and i in self._sink_marked:
             self._two_pieces(i)            # the sink already reported this parameter as complete
         return None
 
