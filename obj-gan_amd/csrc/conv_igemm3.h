@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm3_kernel(const IgemmArgs a)
     // (nchw_to_nhwc_bf16_kernel): the eight consecutive k of a lane are eight consecutive channels of its pixel -- one
     // 16-byte load, no conversion -- instead of eight channel-strided dword gathers and eight conversions; the 32
     // pixels of a wave that are neighbours in a row read 1 KiB of contiguous memory per instruction (a plain
-    // channels-last [N][H][W][Cp] copy made every such load touch 32 cache lines: 517 -> 603 TFLOP/s).
+    // channels-last [N][H][W][Cp] copy made every such load touch 32 cache lines: 517 -> 603 TFLOP/s, LAB.md §4).
     // 4 (H2): fp32 operands as two fp16 pieces on the fp16 MFMA, three products (see OG_MFMA_H): the SP pipeline with a
     // 64-byte bank record [h16 | l16] per row and step and the scales of the two operands undone in the epilogue.
     // 5 (HR): the arithmetic of 4 with the pixel operand read from PRE-SPLIT fp16 records (objgan_h2_records, or a

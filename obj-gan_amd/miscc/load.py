@@ -20,7 +20,7 @@ pycocotools) is preprocessing, not the training path: where a prepared file is m
 readers below raise instead of trying.  Third-party arithmetic the reference delegates to
 packages that are absent here is restated and named where it happens (PIL bilinear resize for
 torchvision.transforms.Resize, scipy.ndimage for skimage.transform.resize): parity of those two
-is against the restatement, not against the packages ("data path").
+is against the restatement, not against the packages (LAB.md section 6, "data path").
 """
 import io
 import mmap
