@@ -135,6 +135,15 @@ int objgan_reflect_ring_fold(const float* ring, float* y, long planes, int H, in
  * then the partial maxima of |w| the fp16x2 pack leaves for its scale); wt_packed as above.
  * ws: objgan_conv_dgrad_s2_phases_ws_floats floats (math 1: the bf16 channel-blocked copy of dY, see objgan_conv_igemm; else 0). */
 long objgan_conv_dgrad_s2_phases_ws_floats(int N, int Cout, int OH, int OW, int math);
+/* Data gradient of a 4x4 / stride-2 / pad-1 convolution w.r.t. an input of Cin <= 32 channels (the first convolution of the
+ * shape / object discriminators, reference model.py:1119-1128, 1217-1220), all four output parity phases in ONE launch of the
+ * fp32 VALU kernel: dy [N, Cout, OH, OW] is read twice (the per-phase form read it four times), dx [N, Cin, 2 OH, 2 OW] is fully
+ * written.  wt: objgan_conv_dgrad_s2_thin_floats(Cout, Cin) floats, packed by the call unless wt_packed;
+ * objgan_conv_pack_job_thin_phase: the pack job of one of its four phase banks for objgan_conv_pack_jobs_run. */
+long objgan_conv_dgrad_s2_thin_floats(int Cout, int Cin);
+int objgan_conv_pack_job_thin_phase(void* job, const float* w, float* wt, int Cout, int Cin, int phase);
+int objgan_conv_dgrad_s2_thin(const float* dy, const float* w, float* dx, float* wt, int N, int Cout, int OH, int OW,
+                              int Cin, int wt_packed, void* stream);
 int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float* wt,
                                 int N, int Cout, int OH, int OW, int Cin, int Torig,
                                 int Tg, const int* dh, const int* dw, const int* src_tap,

@@ -432,6 +432,105 @@ __global__ __launch_bounds__(256) void conv_thin3x3_kernel(const IgemmArgs a) {
     }
 }
 
+// Data gradient of a 4x4 / stride-2 / pad-1 convolution w.r.t. an input of <= 32 channels (the first convolution of the
+// shape / object discriminators: 12 layout-code channels, 3 image channels), all four output parity phases in ONE launch.
+// The per-phase form (conv_thin_kernel, one launch per phase) reads dy four times -- every phase walks the whole
+// gradient tensor for a quarter of the output pixels: 16 launches and 6.4 GB of reads per step for the 96 -> 12 layers at
+// 256 x 256.  Here a thread owns a SOURCE position (n, a, b) of dy and one ROW parity pa = blockIdx.y: it loads the two
+// rows a + pa - 1, a + pa of the 3-wide neighbourhood once per channel (6 values) and produces the two column phases of
+// output row 2a + pa -- phase (pa, pb) uses both rows and columns b + {0, -1} (pb = 0) or b + {1, 0} (pb = 1).  dy is read
+// twice instead of four times, every output element is written once (8-byte stores of the column pair), same fp32 VALU
+// arithmetic: filter bank through the scalar cache (2 phases x 4 taps x MT scalars per channel -- all four phases in one
+// thread would need 16 MT and spill SGPRs by the hundred), PX source positions per thread share every SGPR operand.
+// Banks: the four phase banks of the thin layout, [Cout + 1][4 taps][MT] each (tap t = i * 2 + j: row choice i, column
+// choice j; objgan_conv_dgrad_s2_thin packs them).
+template <int MT, int PX>
+__global__ __launch_bounds__(256) void conv_thin_ph4_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                            float* __restrict__ y, int N, int C, int H, int W, int M) {
+    const int HW = H * W;
+    const int Npos = N * HW;
+    const int pa = blockIdx.y;                       // row parity of the output rows this workgroup writes
+    __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)x, 0, (int)((unsigned)N * C * HW * 4u), OG_BUF_FLAGS);
+    unsigned voff[PX][6];
+    bool pos_ok[PX];
+    int pn[PX], pr[PX], pb_[PX];
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+        const int pos = (blockIdx.x * PX + j) * 256 + threadIdx.x;
+        pos_ok[j] = pos < Npos;
+        const int pp = pos_ok[j] ? pos : 0;
+        const int n = pp / HW;
+        const int rem = pp - n * HW;
+        const int a = rem / W;
+        const int b = rem - a * W;
+        pn[j] = n; pr[j] = a; pb_[j] = b;
+        const unsigned img_off = (unsigned)n * (unsigned)C * (unsigned)HW;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int ih = a + pa - 1 + r, iw = b + c - 1;
+                const bool ok = pos_ok[j] && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                voff[j][r * 3 + c] = ok ? (img_off + (unsigned)(ih * W + iw)) * 4u : OG_OOB;
+            }
+    }
+    float acc[PX][2][MT];
+#pragma unroll
+    for (int j = 0; j < PX; ++j)
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[j][pb][m] = 0.f;
+    const long bank = (long)(C + 1) * 4 * MT;       // floats per phase bank (one zero channel of padding)
+    const float* __restrict__ wp = wt + (long)(pa * 2) * bank;
+    auto load_nb = [&](float (&xv)[PX][6], int c) {
+        const int so = min(c, C - 1) * HW * 4;
+#pragma unroll
+        for (int j = 0; j < PX; ++j)
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                xv[j][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, voff[j][q], so, 0));
+    };
+    auto fma_nb = [&](const float (&xv)[PX][6], int c) {
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            const float* __restrict__ wc = wp + pb * bank + (size_t)c * (4 * MT);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                // tap t = i * 2 + j: row choice i -> local row 1 - i (dh = 0, -1 for pa = 0; 1, 0 for pa = 1);
+                // column choice j -> column pb ? 2 - j : 1 - j of the 3-wide neighbourhood
+                const int r = 1 - (t >> 1);
+                const int q = pb ? 2 - (t & 1) : 1 - (t & 1);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const float wv = wc[t * MT + m];
+#pragma unroll
+                    for (int j = 0; j < PX; ++j) acc[j][pb][m] = fmaf(wv, xv[j][r * 3 + q], acc[j][pb][m]);
+                }
+            }
+        }
+    };
+    float xa[PX][6], xb[PX][6];
+    load_nb(xa, 0);
+    for (int c = 0; c < C; c += 2) {                 // (an odd C runs one step into the bank's zero channel)
+        load_nb(xb, c + 1);
+        fma_nb(xa, c);
+        load_nb(xa, c + 2);
+        fma_nb(xb, c + 1);
+    }
+    const int OWf = 2 * W;
+    const size_t plane = (size_t)(2 * H) * OWf;
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+        if (!pos_ok[j]) continue;
+        float* yb = y + (size_t)pn[j] * M * plane + (size_t)(2 * pr[j] + pa) * OWf + 2 * pb_[j];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            if (m < M) *reinterpret_cast<float2*>(yb + (size_t)m * plane) = make_float2(acc[j][0][m], acc[j][1][m]);
+    }
+}
+
 // ---- weight packing ------------------------------------------------------------------
 // wt[(t*Cp + ck) * Mpad + cm] = src_tap[t] >= 0 ? w[...] : 0, zero padded to [T*Cp][Mpad].
 // w is the PyTorch conv weight [Cout][Cin][Torig].  transpose = 0: cm = cout, ck = cin
@@ -2388,6 +2487,14 @@ static void og_fill_pack_phase(PackArgs& p, const float* w, float* wt, int Cout,
                                const int* src_tap_phase, int phase, int math) {
     const int M = Cin, C = Cout;
     const int Cp = (C + 15) / 16 * 16;
+    if (math == -2) {       // thin layout of conv_thin_ph4_kernel: [C + 1][Tg][MT] per phase
+        const int MT = M <= 4 ? 4 : (M <= 12 ? 12 : (M <= 16 ? 16 : (M <= 24 ? 24 : 32)));
+        p.w = w; p.wt = wt + (long)phase * (C + 1) * Tg * MT; p.Cout = Cout; p.Cin = Cin; p.Torig = Torig; p.Tg = Tg;
+        p.M = M; p.Mpad = MT; p.Ck = C; p.Cp = Cp;
+        p.transpose = 1; p.m_major = 2; p.kgroup = 0; p.wmax = nullptr; p.wexp = 0;
+        for (int t = 0; t < OG_MAX_TAPS; ++t) p.src_tap[t] = (signed char)(t < Tg ? src_tap_phase[t] : -1);
+        return;
+    }
     const int Kpad = Tg * Cp;
     const int Krow = og_krow(Kpad, math);
     const long bank = math ? (long)M * Krow / 2 : (long)M * Krow;
@@ -2660,6 +2767,70 @@ int objgan_conv_dgrad_s2_phases(const float* x, const float* w, float* y, float*
 // floats of workspace objgan_conv_dgrad_s2_phases takes (bf16 mode: the channel-blocked bf16 copy of dY; else 0)
 long objgan_conv_dgrad_s2_phases_ws_floats(int N, int Cout, int OH, int OW, int math) {
     return igemm2_nhwc_floats(math, N, OH, OW, (Cout + 15) / 16 * 16);
+}
+
+// Data gradient of a 4 x 4 / stride-2 / pad-1 convolution w.r.t. an input of Cin <= 32 channels, all four output parity
+// phases in ONE launch of the fp32 VALU kernel (conv_thin_ph4_kernel: dy read twice instead of four times): dy [N, Cout, OH, OW]
+// -> dx [N, Cin, 2 OH, 2 OW], every element written exactly once (no pre-zeroing).  w [Cout][Cin][16]; wt: objgan_conv_dgrad_s2_thin_floats(Cout, Cin) floats
+// (the four phase banks of the thin layout), packed by the call unless wt_packed.
+static inline int og_thin_mt(int M) { return M <= 4 ? 4 : (M <= 12 ? 12 : (M <= 16 ? 16 : (M <= 24 ? 24 : 32))); }
+static void og_thin_phase_taps(int phase, int* st) {      // source taps of phase (pa, pb), t = i * 2 + j (see the kernel)
+    const int pa = phase >> 1, pb = phase & 1;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) {
+            const int kh = pa ? 2 * i : 1 + 2 * i, kw = pb ? 2 * j : 1 + 2 * j;     // dh = (pa + 1 - kh) / 2: 0, -1 | 1, 0
+            st[i * 2 + j] = kh * 4 + kw;
+        }
+}
+long objgan_conv_dgrad_s2_thin_floats(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0 || Cin > 32) return 0;
+    return 4L * (Cout + 1) * 4 * og_thin_mt(Cin);
+}
+// the pack job of phase `phase` of that bank set (for objgan_conv_pack_jobs_run)
+int objgan_conv_pack_job_thin_phase(void* job, const float* w, float* wt, int Cout, int Cin, int phase) {
+    if (!job || phase < 0 || phase > 3 || Cin > 32 || Cin <= 0 || Cout <= 0) return OG_BAD_ARGS;
+    int st[4];
+    og_thin_phase_taps(phase, st);
+    PackArgs p;
+    memset(&p, 0, sizeof(p));
+    og_fill_pack_phase(p, w, wt, Cout, Cin, 16, 4, st, phase, -2);
+    memcpy(job, &p, sizeof(p));
+    return OG_OK;
+}
+int objgan_conv_dgrad_s2_thin(const float* dy, const float* w, float* dx, float* wt, int N, int Cout, int OH, int OW,
+                              int Cin, int wt_packed, void* stream) {
+    OG_ENTRY();
+    if (Cin <= 0 || Cin > 32 || Cout <= 0) return OG_BAD_ARGS;
+    if (N <= 0 || OH <= 0 || OW <= 0) return OG_OK;
+    if ((double)N * Cout * OH * OW * 4.0 >= 4.0e9 || (double)N * OH * OW >= 2.0e9) return OG_BAD_ARGS;
+    hipStream_t s = (hipStream_t)stream;
+    const int MT = og_thin_mt(Cin);
+    if (!wt_packed) {
+        for (int ph = 0; ph < 4; ++ph) {
+            int st[4];
+            og_thin_phase_taps(ph, st);
+            PackArgs p;
+            memset(&p, 0, sizeof(p));
+            og_fill_pack_phase(p, w, wt, Cout, Cin, 16, 4, st, ph, -2);
+            hipLaunchKernelGGL(pack_weights_kernel, dim3(og_stream_grid((long)(Cout + 1) * 4 * MT, 256)), dim3(256), 0, s, p);
+            int rc = og_launch_status();
+            if (rc != OG_OK) return rc;
+        }
+    }
+    const long Npos = (long)N * OH * OW;
+    const int PX = MT <= 16 ? 2 : 1;
+    dim3 grid(og_cdiv(Npos, 256 * PX), 2);           // y: row parity of the output rows
+    ProfRec* pr = prof_begin(OG_CAT_THIN, 2.0 * Cin * (double)Cout * 4.0 * (double)Npos * 4.0, s);
+    prof_meta(pr, 2, MT, Cin, Cout, 4, N, 4 * OH, OW, -1, 1);
+    switch (MT) {
+        case 4: hipLaunchKernelGGL((conv_thin_ph4_kernel<4, 2>), grid, dim3(256), 0, s, dy, wt, dx, N, Cout, OH, OW, Cin); break;
+        case 12: hipLaunchKernelGGL((conv_thin_ph4_kernel<12, 2>), grid, dim3(256), 0, s, dy, wt, dx, N, Cout, OH, OW, Cin); break;
+        case 16: hipLaunchKernelGGL((conv_thin_ph4_kernel<16, 2>), grid, dim3(256), 0, s, dy, wt, dx, N, Cout, OH, OW, Cin); break;
+        case 24: hipLaunchKernelGGL((conv_thin_ph4_kernel<24, 1>), grid, dim3(256), 0, s, dy, wt, dx, N, Cout, OH, OW, Cin); break;
+        default: hipLaunchKernelGGL((conv_thin_ph4_kernel<32, 1>), grid, dim3(256), 0, s, dy, wt, dx, N, Cout, OH, OW, Cin); break;
+    }
+    prof_end(pr, s);
+    return og_launch_status();
 }
 
 // y [planes, H, W] += mirror of ring [planes, 2*(W+2) + 2*(H+2)] (written by objgan_conv_igemm in ring mode).

@@ -64,6 +64,8 @@ SIGNATURES = {
     "objgan_conv_pack_job": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                              _c_int, _ptr, _c_int, _c_int, _c_int, _c_int],
     "objgan_conv_pack_job_phase": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _c_int, _c_int],
+    "objgan_conv_pack_job_thin_phase": [_ptr, _ptr, _ptr, _c_int, _c_int, _c_int],
+    "objgan_conv_dgrad_s2_thin": [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr],
     "objgan_conv_pack_jobs_run": [_ptr, _c_int, _ptr],
     "objgan_bce_const_forward": [_ptr, _ptr, _c_int, _c_float, _ptr],
     "objgan_bce_const_backward": [_ptr, _ptr, _ptr, _c_int, _c_float, _ptr],
@@ -91,6 +93,7 @@ LONG_RETURN = {"objgan_conv_packed_floats": [_c_int, _c_int, _c_int],
                "objgan_conv_igemm_ws_floats": [_c_int] * 22,
                "objgan_conv_wgrad_ws_floats": [_c_int] * 13,
                "objgan_conv_dgrad_s2_phases_ws_floats": [_c_int] * 5,
+               "objgan_conv_dgrad_s2_thin_floats": [_c_int, _c_int],
                "objgan_h2_records_floats": [_c_int, _c_int, _c_long],
                "objgan_norm_ws_floats": [_c_int] * 4,
                "objgan_attn_general_backward_ws_floats": [_c_int] * 4,

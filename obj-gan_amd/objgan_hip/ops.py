@@ -509,6 +509,34 @@ def _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad_h, pad_w, LH, LW, cachea
     return dx
 
 
+_THIN4 = {"on": _os.environ.get("OBJGAN_THIN4", "1") != "0"}
+
+
+def _dgrad_s2_thin(g, w, N, Cout, OH, OW, Cin, cacheable=True):
+    """dX of a 4x4 / stride-2 / pad-1 convolution w.r.t. <= 32 input channels (layout code / image part of the first
+    shape / object discriminator convolution): the four output parity phases in ONE launch of the fp32 VALU kernel -- dY is
+    read twice instead of once per phase."""
+    dx = torch.empty((N, Cin, 2 * OH, 2 * OW), dtype=_F32, device=g.device)
+    n = _q("objgan_conv_dgrad_s2_thin_floats", Cout, Cin)
+    key = _pack_key(w, 3, (0,), "thin4", 0) if cacheable else None
+    if key is not None:
+        ent, fresh = _bank_lookup(key, w, n, g.device)
+        wt, packed = ent.wt, int(fresh)
+        if ent.jobs is None:
+            ent.jobs = []
+            for ph in range(4):
+                job = _job_blob()
+                _lib.call("objgan_conv_pack_job_thin_phase", job, _p(w), _p(wt), Cout, Cin, ph)
+                ent.jobs.append(job.raw)
+        _bank_mark(ent)
+    else:
+        wt, packed = torch.empty(n, dtype=_F32, device=g.device), 0
+    if _PACK_LOG is not None and not packed:
+        _pack_log("thin4", w, key is not None)
+    _lib.call("objgan_conv_dgrad_s2_thin", _p(g), _p(w), _p(dx), _p(wt), N, Cout, OH, OW, Cin, packed, _stream())
+    return dx
+
+
 def conv_out_size(L, k, s, p):
     return (L + 2 * p - k) // s + 1
 
@@ -565,7 +593,12 @@ def _conv_dgrad(g, w, N, Cin, H, W, stride, pad, refl, upsample, cacheable=True)
     elif stride == 2:
         if refl:
             raise _lib.ObjganHipError("stride-2 reflect conv is not on the hot path")
-        dxl = _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad, pad, LH, LW, cacheable)
+        dxl = None
+        if (_THIN4["on"] and k == 4 and pad == 1 and Cin <= 12 and LH == 2 * OH and LW == 2 * OW
+                and N * OH * OW >= 65536 and float(N) * Cout * OH * OW * 4.0 < 4.0e9):
+            dxl = _dgrad_s2_thin(g, w, N, Cout, OH, OW, Cin, cacheable)      # (thin outputs: the four phases in one launch)
+        if dxl is None:
+            dxl = _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad, pad, LH, LW, cacheable)
         phases = range(2) if dxl is None else ()
         if dxl is None:
             dxl = torch.zeros((N, Cin, LH, LW), dtype=_F32, device=g.device)
