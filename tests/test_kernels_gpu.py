@@ -1218,6 +1218,67 @@ def test_conv2d_cat_gives_per_input_gradients(dev, need):
             assert dd.grad is None
 
 
+@pytest.mark.parametrize("cin,cout", [(12, 40), (3, 96)])
+def test_thin_data_gradient_four_phases_in_one_launch_equals_the_per_phase_form(dev, cin, cout):
+    """Round 5: the data gradient of a 4x4 / stride-2 / pad-1 convolution w.r.t. <= 12 input channels (layout code / image part
+    of the first shape / object discriminator convolution) runs its four output parity phases in ONE launch
+    (conv_thin_ph4_kernel: dY read twice instead of four times).  Same fp32 FMAs in the same order per output element: BIT-identical
+    to the per-phase launches of the thin kernel, and within fp32 tolerance of the oracle."""
+    ops, tr = _ops(), _tref()
+    N, H, W = 2, 384, 384                       # N * OH * OW = 73 728 source positions: above the thin kernels' threshold
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 4, 4, generator=g) / (cin * 16) ** 0.5
+    gy = torch.randn(N, cout, H // 2, W // 2, generator=g)
+    xr = x.clone().requires_grad_()
+    tr.conv2d(xr, w, None, 2, 1, "zeros", False, None).backward(gy)
+    outs = []
+    prev = dict(ops._THIN4)
+    try:
+        for on in (True, False):
+            ops._THIN4["on"] = on
+            xd = x.to(dev).requires_grad_()
+            ops.conv2d(xd, w.to(dev), None, 2, 1, "zeros", False, None).backward(gy.to(dev))
+            torch.cuda.synchronize()
+            outs.append(xd.grad.clone())
+    finally:
+        ops._THIN4.update(prev)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]), rel_l2(outs[0], outs[1])
+    assert rel_l2(outs[0], xr.grad) < TOL, rel_l2(outs[0], xr.grad)
+
+
+def test_conv2d_cat_filter_slices_follow_weight_updates(dev):
+    """Round 5: the per-input data gradients of conv2d_cat keep a contiguous copy of their filter slice (and its packed banks)
+    while the weights are unchanged -- `ops._w_slice`, keyed on the weight's version counter and, for arena parameters, on the
+    arena's epoch cell (the fused Adam writes through a raw pointer).  After either kind of update the next call must see the
+    new weights."""
+    ops, tr = _ops(), _tref()
+    N, H, W, c1, c2, cout = 2, 384, 384, 3, 12, 40
+    g = torch.Generator().manual_seed(78)
+    x1, x2 = torch.randn(N, c1, H, W, generator=g), torch.randn(N, c2, H, W, generator=g)
+    w0 = torch.randn(cout, c1 + c2, 4, 4, generator=g) / ((c1 + c2) * 16) ** 0.5
+    gy = torch.randn(N, cout, H // 2, W // 2, generator=g)
+    wd = w0.to(dev).requires_grad_()
+    wd._og_epoch = [0]                          # what an optimizer arena attaches to its parameters
+
+    def layout_grad(wcpu):
+        x2r = x2.clone().requires_grad_()
+        tr.conv2d(torch.cat([x1, x2r], 1), wcpu, None, 2, 1, "zeros", False, None).backward(gy)
+        x2d = x2.to(dev).requires_grad_()
+        ops.conv2d_cat(x1.to(dev), x2d, wd, 2, 1).backward(gy.to(dev))      # only the layout part needs a gradient
+        torch.cuda.synchronize()
+        return rel_l2(x2d.grad, x2r.grad)
+    assert layout_grad(w0) < TOL
+    assert layout_grad(w0) < TOL                                              # second call: slice and banks from the cache
+    with torch.no_grad():
+        wd.mul_(-1.5)                                                         # torch-side edit: version counter
+    assert layout_grad(w0 * -1.5) < TOL
+    wd.data.copy_((w0 * 0.25).to(dev))                                        # raw write (no version bump) + epoch, like the fused Adam
+    wd._og_epoch[0] += 1
+    assert layout_grad(w0 * 0.25) < TOL
+
+
 def test_conv_reductions_are_bit_reproducible(dev, fp32_math):
     """Split reductions go through a workspace and are summed in split order (no fp32 atomics): the weight gradient
     (pixels split across workgroups) and split-K outputs (small grids, long K) are bit-identical from run to run, the
