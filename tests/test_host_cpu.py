@@ -388,3 +388,24 @@ def test_bench_respawn_passes_every_flag_through_and_numa_slices_are_disjoint():
     assert len(set().union(*map(set, slices))) == 256                       # disjoint and complete
     assert all(set(slices[r]) <= set(nodes[gpus[r]]) for r in range(8))     # NUMA-local
     assert bench.numa_slice({0: [0, 1]}, [0, 0, 0, 0], 1) is None           # fewer cores than ranks: no pinning
+
+
+def test_bench_traffic_lookup_resolves_category_patterns():
+    """`roofline.traffic` comes from the committed counter passes (profiles/pmc_traffic.json).  A timing category is either a
+    kernel instance or -- the weight-gradient kernels, whose 16-byte and dword gather forms report into one category -- a
+    pattern with `*` for one template argument: then the launch-weighted mean over the matching instances."""
+    import json
+    import bench
+    kernels = {"conv_wgrad3_kernel<6, 4, false, 0, 8>": {"launches": 30, "hbm_bytes_per_launch": 100},
+               "conv_wgrad3_kernel<6, 4, true, 0, 8>": {"launches": 10, "hbm_bytes_per_launch": 300},
+               "conv_wgrad3_kernel<6, 4, false, 0, 4>": {"launches": 50, "hbm_bytes_per_launch": 7},
+               "conv_igemm3_kernel<7, false, 5, 8, 1>": {"launches": 5, "hbm_bytes_per_launch": 42}}
+    assert bench.pmc_lookup(kernels, "conv_igemm3_kernel<7, false, 5, 8, 1>") == 42
+    assert bench.pmc_lookup(kernels, "conv_wgrad3_kernel<6, 4, *, 0, 8>") == (30 * 100 + 10 * 300) // 40
+    assert bench.pmc_lookup(kernels, "conv_wgrad3_kernel<7, 4, *, 0, 8>") is None
+    assert bench.pmc_lookup(kernels, "conv_thin_kernel") is None
+    # the committed file answers for the categories the bench line names on the configuration it was collected on
+    pmc = json.load(open(bench.PMC_TRAFFIC_JSON))
+    assert pmc["conv_math"] == "fp16x2" and pmc["per_gpu_batch"] == 16
+    assert bench.pmc_lookup(pmc["kernels"], "conv_wgrad3_kernel<6, 4, *, 0, 8>") > 0
+    assert bench.pmc_lookup(pmc["kernels"], "conv_igemm3_kernel<7, false, 5, 8, 1>") > 0
