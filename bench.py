@@ -57,18 +57,20 @@ FP16X2_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3.0
 def cat_names(math):
     """rocprofv3's names of the kernel instances behind the library's timing categories (leading template
     arguments: tile height, LDS-free form / arithmetic), indexed by category id."""
-    def names(mi, m, bfb=False, ng=1):
+    def names(mi, m, bfb=False, ng=1, rec=False):
+        # (rec: the weight gradient that reads x from its fp16 record reports in the record categories' slots, ADVICE r5)
+        wg4 = ["conv_wgrad_rec_kernel<%d, 4>" % tm if rec else "conv_wgrad3_kernel<%d, %d" % (tm, m) for tm in range(1, 8)]
+        wg8 = ["conv_wgrad_rec_kernel<%d, 8>" % tm if rec else "conv_wgrad3_kernel<%d, %d, *, 0, 8>" % (tm, m) for tm in range(1, 8)]
         return (["conv_igemm3_kernel<%d, false, %d, 4, %d>" % (tm, mi, ng) for tm in range(1, 8)] +
                 # (bf16 mode: the bf16-operand weight-gradient kernel reports in the slots of the LDS-staged one)
                 [("conv_wgrad_bfb_kernel<%d," % tm) if bfb else ("conv_wgrad2_kernel<%d, %d" % (tm, min(m, 2))) for tm in range(1, 8)] +
                 ["conv_thin_kernel", "conv_thin3x3_kernel", "conv_igemm_kernel", "conv_wgrad_kernel",
-                 "conv_igemm3_kernel<1, true, %d, 4, 1>" % m] + ["conv_wgrad3_kernel<%d, %d" % (tm, m) for tm in range(1, 8)] +
-                ["conv_igemm3_kernel<%d, false, %d, 8, %d>" % (tm, mi, ng) for tm in range(1, 8)] +
-                ["conv_wgrad3_kernel<%d, %d, *, 0, 8>" % (tm, m) for tm in range(1, 8)])
+                 "conv_igemm3_kernel<1, true, %d, 4, 1>" % m] + wg4 +
+                ["conv_igemm3_kernel<%d, false, %d, 8, %d>" % (tm, mi, ng) for tm in range(1, 8)] + wg8)
     if math == "fp16x2":       # categories 0..47: this mode's bf16x3 launches (small ones, LDS-staged weight gradients);
         base = names(2, 2)               # 48..95: the fp16x2 instances of the same kernel families; 96..143 / 144..191:
         pad = [""] * (48 - len(base))    # the forward / data-gradient kernel on pre-split records, one / two pixel groups
-        return base + pad + names(4, 4) + pad + names(5, 5) + pad + names(5, 5, ng=2)
+        return base + pad + names(4, 4) + pad + names(5, 5, rec=True) + pad + names(5, 5, ng=2, rec=True)
     m = MATH_IDS[math]
     # bf16 mode: the matrix kernels read the bf16 channel-blocked copy (template value 3)
     return names(3 if m == 1 else m, m, bfb=(m == 1))

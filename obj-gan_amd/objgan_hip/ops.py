@@ -232,6 +232,8 @@ def _records(t, amax, N, C, HW, intensity=None, rows=0):
             return got[1]
     if intensity is not None and intensity < (_REC["min_i_short"] if rows <= 96 else _REC["min_i"]):
         return None
+    if N > 65535 or float(N) * ((C + 15) // 16 * 16) * HW * 4.0 >= 4.0e9:
+        return None                 # beyond objgan_h2_records' 32-bit offsets: the launch keeps the gather form (math 4)
     rec = torch.empty(N * ((C + 15) // 16 * 16) * HW, dtype=_F32, device=t.device)
     _lib.call("objgan_h2_records", _p(t), _p(amax), _p(rec), N, C, HW, _stream())
     try:

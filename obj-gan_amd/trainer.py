@@ -268,6 +268,25 @@ def _dist_on():
 # ---------------------------------------------------------------------------------------------
 # trainer
 # ---------------------------------------------------------------------------------------------
+def resolve_d_job_order(job_names, order):
+    """The issue order of the discriminator jobs of one step under a `d_job_order` / OBJGAN_D_ORDER request: the listed jobs
+    first, the rest behind them in the reference order (reference trainer.py:398-443).  Every job but the patch
+    discriminators draws from the python RNG (permute_seg, miscc/utils.py), so the FINAL order must keep those jobs in the
+    reference sequence -- a partial list such as ["errShpD1"] would otherwise run ShpD1 ahead of ShpD0 and silently lose the
+    reference parity of the step.  Unknown or repeated names raise."""
+    order = list(order)
+    unknown = [n for n in order if n not in job_names]
+    if unknown or len(set(order)) != len(order):
+        raise ValueError("d_job_order names jobs that do not exist in this step (or names one twice): %s; jobs: %s"
+                         % (unknown or order, list(job_names)))
+    final = order + [n for n in job_names if n not in order]
+    ref = [n for n in job_names if not n.startswith("errPatD")]
+    if [n for n in final if not n.startswith("errPatD")] != ref:
+        raise ValueError("d_job_order moves a job that draws random numbers out of the reference order: %s "
+                         "(issue order would be %s)" % (order, final))
+    return final
+
+
 class condGANTrainer(object):
     def __init__(self, output_dir, data_loader, dataset, device=None):
         if cfg.TRAIN.FLAG and output_dir:
@@ -588,12 +607,8 @@ class condGANTrainer(object):
         order = ([n for n in os.environ["OBJGAN_D_ORDER"].split(",") if n] if os.environ.get("OBJGAN_D_ORDER")
                  else self.d_job_order)
         if order:
-            rng_users = [n for n in order if not n.startswith("errPatD")]
-            ref = [j[0] for j in jobs if not j[0].startswith("errPatD")]
-            if rng_users != [n for n in ref if n in rng_users]:
-                raise ValueError("d_job_order moves a job that draws random numbers out of the reference order: %s" % order)
             by_name = dict((j[0], j) for j in jobs)
-            jobs = [by_name[n] for n in order if n in by_name] + [j for j in jobs if j[0] not in order]
+            jobs = [by_name[n] for n in resolve_d_job_order([j[0] for j in jobs], order)]
         pending = []
         side = self._d_side_streams()
         main = torch.cuda.current_stream() if side else None

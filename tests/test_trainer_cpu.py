@@ -323,3 +323,50 @@ def test_arena_refuses_a_weight_whose_gradient_arrives_in_two_pieces():
     net[1].weight._og_grad_sink[1]()
     with pytest.raises(RuntimeError, match="more than once per forward"):
         net(torch.randn(2, 4)).sum().backward()
+
+
+def test_autograd_hooks_fire_for_a_parameter_whose_backward_function_returned_none():
+    """ParamArena._mark / _autograd_piece rely on the installed torch running BOTH the tensor hook (with
+    g = None) and AccumulateGrad's post-accumulate hook for a parameter whose backward function handed autograd no
+    gradient -- the direct weight-gradient sink's case (ops._grad_sink).  Pinned here on the installed version: if a
+    future torch returns early on an undefined gradient, `_hook_marked` stops seeing sink-only parameters (harmless: the
+    sink itself marks them) and this test says so."""
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            return x @ w
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            return g @ w.t(), None
+
+    w = torch.randn(4, 4, requires_grad=True)
+    x = torch.randn(2, 4, requires_grad=True)
+    w.grad = torch.zeros_like(w)
+    seen = []
+    w.register_post_accumulate_grad_hook(lambda p: seen.append("post"))
+    w.register_hook(lambda g: seen.append(("tensor", g is None)))
+    Fn.apply(x, w).sum().backward()
+    assert seen == [("tensor", True), "post"], seen
+
+
+def test_d_job_order_keeps_the_rng_drawing_jobs_in_the_reference_sequence():
+    """a PARTIAL d_job_order list is completed with the unlisted jobs behind it; the check runs on the final
+    order.  Every job but the patch discriminators draws from the python RNG (permute_seg), so they must stay in the
+    reference sequence; unknown / repeated names raise."""
+    import trainer as T
+    names = ["errPatD0", "errPatD1", "errPatD2", "errShpD0", "errShpD1", "errShpD2", "errObjSSD", "errObjLSD"]
+    assert T.resolve_d_job_order(names, ["errPatD2"]) == ["errPatD2", "errPatD0", "errPatD1"] + names[3:]
+    assert T.resolve_d_job_order(names, ["errShpD0", "errPatD2"])[:2] == ["errShpD0", "errPatD2"]
+    full = ["errPatD2", "errShpD0", "errShpD1", "errShpD2", "errObjSSD", "errObjLSD", "errPatD1", "errPatD0"]
+    assert T.resolve_d_job_order(names, full) == full
+    with pytest.raises(ValueError, match="out of the reference order"):
+        T.resolve_d_job_order(names, ["errShpD1"])               # would run ShpD1 ahead of ShpD0
+    with pytest.raises(ValueError, match="out of the reference order"):
+        T.resolve_d_job_order(names, ["errObjLSD", "errObjSSD"])
+    with pytest.raises(ValueError, match="do not exist"):
+        T.resolve_d_job_order(names, ["errPatD7"])
+    with pytest.raises(ValueError, match="do not exist"):
+        T.resolve_d_job_order(names, ["errPatD0", "errPatD0"])
