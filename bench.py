@@ -592,6 +592,8 @@ def main():
         return float(t.item())
 
     lib = _lib.load()
+    from objgan_hip import graphs
+    graphs_on = graphs.enabled()
     timing = (rank == 0) and not args.no_kernel_timing
     prof_steps = 0 if args.no_kernel_timing else max(1, min(args.steps, 10))
     timed_streams = int(tr.d_streams)
@@ -600,12 +602,14 @@ def main():
         # per-kernel durations are those of a kernel ALONE on the device: the profiling pass runs on one stream
         # (in the timed pass kernels of different streams overlap and stretch each other)
         tr.d_streams = 1
+        graphs.enable(False)              # hipEvents around every convolution launch: the chains run eagerly here
         if timing:
             lib.objgan_prof_enable(1)
 
     def prof_end():
         if timing:
             lib.objgan_prof_enable(0)
+        graphs.enable(graphs_on)
         tr.d_streams = timed_streams
     dt, prof_dt = timed_passes(step, barrier, max_over_ranks, args.steps, args.warmup, prof_steps,
                                prof_begin if timing else None, prof_end if timing else None)
@@ -740,6 +744,13 @@ def main():
         if host is not None:
             if pinned:
                 host["pinned_cpus_per_rank"] = len(pinned)
+            gs = graphs.stats()
+            host["hip_graphs"] = {"on": bool(gs["on"]), "captures": gs["captures"], "replays": gs["replays"],
+                                  "fallbacks": gs["fallbacks"]}
+            try:
+                host["peak_device_memory_gb"] = round(torch.cuda.max_memory_allocated(device) / 2.0 ** 30, 2)
+            except Exception:                                   # noqa: BLE001 (CPU shim of the host tests)
+                pass
             res["host_step"] = host
         if comm is not None:
             comm["world_size"] = dist.get_world_size()

@@ -317,6 +317,32 @@ int objgan_resize_pil_rgb8(const unsigned char* src, const long* offs, const int
                            int Hmax, int kmax, int S, int* coef_scratch, unsigned char* tmp_scratch, float* out,
                            void* stream);
 
+/* ---- training images: baseline JPEG decode on the device ------------------------------
+ * Replaces the host decode `Image.open(BytesIO(img_bytes)).convert('RGB')` of reference
+ * image_generation/miscc/load.py:141-151 (get_imgs; Pillow = libjpeg-turbo with the library defaults: JDCT_ISLOW, fancy
+ * upsampling, RGB output): the FILE bytes cross PCIe, the decoded image never exists on the host.  Bit for bit Pillow's
+ * output (integer arithmetic throughout: jdhuff.c entropy decode, jidctint.c inverse DCT, jdsample.c triangle-filter
+ * upsampling, jdcolor.c fixed-point colour conversion).
+ *
+ * objgan_jpeg_parse     HOST ONLY.  Markers, quantisation and Huffman tables of one file -> a descriptor of
+ *                       objgan_jpeg_desc_bytes() bytes whose first ten ints are {width, height, components, hmax, vmax,
+ *                       MCUs per row, MCU rows, restart interval, reason, scan offset}.  Returns 1 for a file the device
+ *                       decodes (baseline / sequential Huffman, 8 bit, one interleaved scan, grey or YCbCr 4:4:4 / 4:2:2 /
+ *                       4:2:0) and 0 with reason != 0 for anything else (1 not JPEG, 2 progressive / arithmetic / lossless,
+ *                       3 precision, 4 components, 5 sampling, 6 scan, 7 tables, 8 truncated): the caller routes that file
+ *                       to its host decoder knowingly.
+ * objgan_jpeg_plan      HOST ONLY.  Lays a batch out: descs[i] gets its file's byte offset in the batch buffer
+ *                       (file_offsets[i], multiples of 16), its output byte offset and its workspace slices.
+ *                       -> workspace bytes (0: a refused descriptor in the batch).
+ * objgan_jpeg_decode    files: the batch's files back to back (device); descs_host: the planned descriptors (launch
+ *                       geometry), descs_dev: a device copy of the same bytes (what the kernels read); out: image i as
+ *                       [height][width][3] RGB bytes at its output offset; ws: objgan_jpeg_plan's byte count. */
+long objgan_jpeg_desc_bytes(void);
+int objgan_jpeg_parse(const unsigned char* file, long nbytes, void* desc_out);
+long objgan_jpeg_plan(void* descs, int n, const long* file_offsets, const long* out_offsets);
+int objgan_jpeg_decode(const unsigned char* files, const void* descs_host, const void* descs_dev, int n,
+                       unsigned char* out, void* ws, long ws_bytes, void* stream);
+
 /* ---- per-box instance masks on the device (the loader side of the path) --------------------
  * Replaces the four `skimage.transform.resize(mask, [s, s])` calls per box of reference
  * image_generation/miscc/load.py:160-176 (s = 32, 64, 128, 256 from the 64 x 64 instance mask): `count` square

@@ -60,6 +60,9 @@ def parse_args(argv=None):
                         help='hand over the box masks only and rebuild the layout maps on the device')
     parser.add_argument('--device_imgs', action='store_true',
                         help='hand over the decoded 8-bit images and resize them on the device (Pillow-exact)')
+    parser.add_argument('--device_jpeg', action='store_true',
+                        help='hand over the JPEG FILES and decode + resize them on the device (Pillow-exact); implies '
+                             '--device_imgs')
     parser.add_argument('--device_masks', action='store_true',
                         help='hand over the raw 64 x 64 instance masks and resize them on the device (scipy-exact); '
                              'implies --device_hmaps')
@@ -148,7 +151,8 @@ def build_training(args, rank, world, device):
     dataset = TrainDataset(cfg.DATA_DIR, 'train', base_size=cfg.TREE.BASE_SIZE,
                            device_hmaps=getattr(args, "device_hmaps", False),
                            device_imgs=getattr(args, "device_imgs", False),
-                           device_masks=getattr(args, "device_masks", False))
+                           device_masks=getattr(args, "device_masks", False),
+                           device_jpeg=getattr(args, "device_jpeg", False))
     assert dataset
     dataloader = build_loader(dataset, cfg.TRAIN.BATCH_SIZE, workers=int(cfg.WORKERS), rank=rank,
                               world=world, seed=args.manualSeed or 0, shuffle=True)

@@ -83,6 +83,8 @@ SIGNATURES = {
     "objgan_resize_pil_kmax": [_c_int, _c_int],
     "objgan_resize_pil_rgb8": [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr],
     "objgan_mask_resize": [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "objgan_jpeg_parse": [ctypes.c_char_p, _c_long, _ptr],
+    "objgan_jpeg_decode": [_ptr, _ptr, _ptr, _c_int, _ptr, _ptr, _c_long, _ptr],
     "objgan_prof_enable": [_c_int],
     "objgan_conv_bank_layout": [_c_int] * 10,
     "objgan_conv_wgrad_rec_ok": [_c_int] * 8,
@@ -99,7 +101,9 @@ LONG_RETURN = {"objgan_conv_packed_floats": [_c_int, _c_int, _c_int],
                "objgan_attn_general_backward_ws_floats": [_c_int] * 4,
                "objgan_masked_max_backward_ws_floats": [_c_int] * 4,
                "objgan_channel_sum_ws_floats": [_c_int] * 3,
-               "objgan_roi_align_backward_ws_floats": [_c_int] * 7}
+               "objgan_roi_align_backward_ws_floats": [_c_int] * 7,
+               "objgan_jpeg_desc_bytes": [],
+               "objgan_jpeg_plan": [_ptr, _c_int, _ptr, _ptr]}
 
 _LIB = None
 

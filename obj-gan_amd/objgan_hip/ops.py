@@ -137,6 +137,22 @@ _ZERO_ROWS = {}             # HIP stream -> [chunk of zeroed slot rows, rows han
 _ZERO_CHUNK = 32
 
 
+_CAPTURE = {"on": False}
+
+
+def capture_begin():
+    """A hipGraph capture of a chain of these operators starts (objgan_hip.graphs): zeroed slot rows handed out from now
+    on must come from a chunk whose fill launch is INSIDE the capture (a replay re-zeroes it), never from a chunk an eager
+    launch filled earlier on a stream the capture happens to reuse."""
+    _ZERO_ROWS.clear()
+    _CAPTURE["on"] = True
+
+
+def capture_end():
+    _ZERO_ROWS.clear()          # the chunks of the capture belong to its replays: eager producers start a fresh one
+    _CAPTURE["on"] = False
+
+
 def _amax_zeroed(device):
     """1024 zeroed maximum slots for a producer that adds into them atomically: a row of a chunk zero-filled by ONE
     launch per 32 rows (it was one fill launch per producer call).  Per HIP stream: the fill and the producers that use
@@ -1471,7 +1487,142 @@ def bilinear_resize(x, oh, ow):
     return _BilinearFn.apply(x, int(oh), int(ow))
 
 
+# ---- training images: baseline JPEG decode on the device (csrc/jpeg.hip) ---------------------------------
+class JpegUnsupported(_lib.ObjganHipError):
+    """the file is not a baseline / sequential Huffman JPEG in a supported sampling (progressive, arithmetic, CMYK ...):
+    the caller routes it to its host decoder knowingly -- nothing is decoded approximately on the device"""
+
+    REASONS = {1: "not a JPEG file", 2: "progressive / lossless / arithmetic-coded frame", 3: "sample precision is not 8 bits",
+               4: "neither 1 nor 3 components", 5: "unsupported chroma sampling", 6: "non-interleaved or missing scan",
+               7: "missing / oversized table", 8: "truncated file"}
+
+    def __init__(self, index, reason):
+        super().__init__("JPEG %d: %s" % (index, self.REASONS.get(reason, "reason %d" % reason)))
+        self.index, self.reason = index, reason
+
+
+def jpeg_parse(files):
+    """files: the JPEG files of a batch (bytes-like).  HOST ONLY (no GPU call): -> (descriptors uint8 [n, desc bytes] as a
+    numpy array, heads int32 [n, 10] view: width, height, components, hmax, vmax, mcux, mcuy, restart interval, reason,
+    scan offset).  A file the device path does not decode has heads[i, 8] != 0 (see JpegUnsupported.REASONS)."""
+    import numpy as np
+    lib = _lib.load()
+    nb = int(lib.objgan_jpeg_desc_bytes())
+    descs = np.zeros((len(files), nb), np.uint8)
+    for i, f in enumerate(files):
+        buf = bytes(f) if not isinstance(f, bytes) else f
+        lib.objgan_jpeg_parse(buf, len(buf), descs[i].ctypes.data_as(ctypes.c_void_p))
+    heads = descs[:, :40].view(np.int32) if len(files) else np.zeros((0, 10), np.int32)
+    return descs, heads
+
+
+def jpeg_decode_batch(files, device):
+    """files: baseline JPEG files (bytes-like) -> (rgb, offs, hs, ws): the decoded images back to back in ONE uint8 device
+    buffer (image i: [hs[i], ws[i], 3] at byte offs[i]) -- bit for bit PIL.Image.open(f).convert('RGB') (reference
+    miscc/load.py:141-151).  Only the file bytes cross PCIe.  Raises JpegUnsupported (with the index) for a file that is
+    not baseline."""
+    import numpy as np
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.ObjganHipError("jpeg_decode_batch: needs a HIP device (no CPU path)")
+    files = [bytes(f) if not isinstance(f, bytes) else f for f in files]
+    n = len(files)
+    descs, heads = jpeg_parse(files)
+    for i in range(n):
+        if heads[i, 8] != 0:
+            raise JpegUnsupported(i, int(heads[i, 8]))
+    lib = _lib.load()
+    hs, ws = [int(h) for h in heads[:, 1]], [int(w) for w in heads[:, 0]]
+    sizes = [(len(f) + 15) // 16 * 16 for f in files]                 # 16-byte aligned file starts (vector loads of the ring)
+    foffs = np.concatenate(([0], np.cumsum(sizes)[:-1])).astype(np.int64)
+    osz = [(h * w * 3 + 15) // 16 * 16 for h, w in zip(hs, ws)]
+    ooffs = np.concatenate(([0], np.cumsum(osz)[:-1])).astype(np.int64)
+    ws_bytes = int(lib.objgan_jpeg_plan(descs.ctypes.data_as(ctypes.c_void_p), n,
+                                        foffs.ctypes.data_as(ctypes.c_void_p), ooffs.ctypes.data_as(ctypes.c_void_p)))
+    if ws_bytes <= 0:
+        raise _lib.ObjganHipError("objgan_jpeg_plan: bad descriptor")
+    host = torch.empty(int(sum(sizes)) + descs.size, dtype=torch.uint8).pin_memory()
+    flat = host.numpy()
+    for f, o in zip(files, foffs):
+        flat[o:o + len(f)] = np.frombuffer(f, np.uint8)
+    d0 = int(sum(sizes))
+    flat[d0:] = descs.reshape(-1)
+    dev = host.to(device, non_blocking=True)                          # files + descriptors: one upload
+    out = torch.empty(int(sum(osz)), dtype=torch.uint8, device=device)
+    work = torch.empty((ws_bytes + 15) // 16 * 16, dtype=torch.uint8, device=device)
+    _lib.call("objgan_jpeg_decode", _p(dev), descs.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(dev.data_ptr() + d0), n,
+              _p(out), _p(work), ws_bytes, _stream())
+    return out, ooffs, hs, ws
+
+
+def images_to_device(items, device):
+    """The `device_jpeg` hand-over of a batch: every item is either a JPEG file (1-D uint8 tensor / bytes: decoded on the
+    device) or an image the loader had to decode on the host (uint8 [H, W, 3]: a progressive / CMYK file the device path
+    refuses, uploaded as it is) -> (buffer, offs, hs, ws) in the items' order, the form resize_pil_bilinear_device reads."""
+    import numpy as np
+    device = torch.device(device)
+    kinds = []
+    for it in items:
+        a = it.numpy() if torch.is_tensor(it) else (np.frombuffer(it, np.uint8) if isinstance(it, (bytes, bytearray)) else np.asarray(it))
+        kinds.append(a)
+    jidx = [i for i, a in enumerate(kinds) if a.ndim == 1]
+    hidx = [i for i, a in enumerate(kinds) if a.ndim == 3]
+    if len(jidx) + len(hidx) != len(kinds):
+        raise _lib.ObjganHipError("images_to_device: items must be JPEG byte strings (1-D uint8) or uint8 [H, W, 3] images")
+    if not hidx:
+        return jpeg_decode_batch([kinds[i].tobytes() for i in jidx], device)
+    parts, offs, hs, ws = [], [0] * len(kinds), [0] * len(kinds), [0] * len(kinds)
+    total = 0
+    if jidx:
+        out, jo, jh, jw = jpeg_decode_batch([kinds[i].tobytes() for i in jidx], device)
+        parts.append(out)
+        for k, i in enumerate(jidx):
+            offs[i], hs[i], ws[i] = int(jo[k]), jh[k], jw[k]
+        total = out.numel()
+    host = torch.empty(sum((kinds[i].size + 15) // 16 * 16 for i in hidx), dtype=torch.uint8).pin_memory()
+    o = 0
+    for i in hidx:
+        a = np.ascontiguousarray(kinds[i], dtype=np.uint8)
+        if a.shape[2] != 3:
+            raise _lib.ObjganHipError("images_to_device: host-decoded images must be uint8 [H, W, 3], got %s" % (a.shape,))
+        host.numpy()[o:o + a.size] = a.reshape(-1)
+        offs[i], hs[i], ws[i] = total + o, a.shape[0], a.shape[1]
+        o += (a.size + 15) // 16 * 16
+    parts.append(host.to(device, non_blocking=True))
+    return torch.cat(parts), np.asarray(offs, np.int64), hs, ws
+
+
+def jpeg_decode(files, device):
+    """-> list of uint8 [H, W, 3] device tensors (views of one buffer)"""
+    out, offs, hs, ws = jpeg_decode_batch(files, device)
+    return [out[int(o):int(o) + h * w * 3].view(h, w, 3) for o, h, w in zip(offs, hs, ws)]
+
+
 # ---- training images: Pillow's antialiased bilinear resize + ToTensor + Normalize on the device -------
+def resize_pil_bilinear_device(src, offs, hs, ws, sizes):
+    """resize_pil_bilinear on images that are ALREADY on the device (jpeg_decode_batch's hand-over): src uint8 buffer, image b
+    [hs[b], ws[b], 3] at byte offs[b]."""
+    import numpy as np
+    device = src.device
+    B = len(hs)
+    hs_d = torch.tensor(list(hs), dtype=torch.int32).to(device)
+    ws_d = torch.tensor(list(ws), dtype=torch.int32).to(device)
+    offs_d = torch.from_numpy(np.asarray(offs, np.int64)).to(device)
+    Hmax = max(hs)
+    side = max(max(hs), max(ws))
+    outs = []
+    for S in sizes:
+        S = int(S)
+        kmax = int(_lib.load().objgan_resize_pil_kmax(side, S))
+        coef = torch.empty(B * 2 * S * (kmax + 2), dtype=torch.int32, device=device)
+        tmp = torch.empty(B * Hmax * S * 3, dtype=torch.uint8, device=device)
+        out = torch.empty((B, 3, S, S), dtype=_F32, device=device)
+        _lib.call("objgan_resize_pil_rgb8", _p(src), _p(offs_d), _p(hs_d), _p(ws_d), B, Hmax, kmax, S,
+                  _p(coef), _p(tmp), _p(out), _stream())
+        outs.append(out)
+    return outs
+
+
 def resize_pil_bilinear(images, sizes, device):
     """images: the decoded RGB images of a batch as uint8 [H, W, 3] host tensors / arrays (any sizes);
     -> [B, 3, S, S] float32 on `device` for every S in `sizes`, bit for bit

@@ -31,7 +31,15 @@ class TrainDataset(data.Dataset):
     cat_labels / cat_label_lens / sorted_cat_label_indices, class_id, cats_dict / cats_index_dict,
     img_bytes, insanns_dict."""
 
-    def __init__(self, data_dir, split='train', base_size=64, device_hmaps=False, device_imgs=False, device_masks=False):
+    def __init__(self, data_dir, split='train', base_size=64, device_hmaps=False, device_imgs=False, device_masks=False,
+                 device_jpeg=False):
+        # `device_jpeg=True`: the items carry the JPEG FILE (1-D uint8 tensor) and `prepare_data` decodes it on the device
+        # (ops.jpeg_decode_batch, bit for bit Pillow) before the device resize -- no decode, no resize in the loader
+        # workers, only the file bytes cross PCIe.  A file the device path refuses (progressive, CMYK: objgan_jpeg_parse,
+        # host-only) is decoded by Pillow in the worker and travels as the decoded image; `host_decoded` counts those.
+        self.device_jpeg = device_jpeg
+        device_imgs = device_imgs or device_jpeg
+        self.host_decoded = 0
         self.device_masks = device_masks
         self.device_hmaps = device_hmaps or device_masks      # the maps are sums of the masks: rebuilt behind them
         self.device_imgs = device_imgs
@@ -67,7 +75,15 @@ class TrainDataset(data.Dataset):
         hmaps, rois, fm_rois, num_rois, bt_masks, fm_bt_masks = maps[0], maps[4], maps[5], maps[6], maps[7], maps[8]
         pick = index * self.embeddings_num + random.randint(0, self.embeddings_num)    # one of the image's captions
         caps, glove_caps, cap_len = get_caption(self.captions, self.glove_captions, pick)
-        imgs = decode_rgb(self.img_bytes[index]) if self.device_imgs else get_imgs(self.img_bytes[index], self.imsize)
+        if self.device_jpeg:
+            raw = self.img_bytes[index]
+            if ops.jpeg_parse([raw])[1][0, 8] == 0:
+                imgs = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+            else:
+                imgs = decode_rgb(raw)
+                self.host_decoded += 1
+        else:
+            imgs = decode_rgb(self.img_bytes[index]) if self.device_imgs else get_imgs(self.img_bytes[index], self.imsize)
         return (imgs, caps, glove_caps, cap_len, hmaps, rois, fm_rois,
                 num_rois, bt_masks, fm_bt_masks, self.class_id[index], key)
 
@@ -107,8 +123,13 @@ def prepare_data(data, device=None, num_classes=None):
         # `device_imgs` hand-over: one decoded [H, W, 3] image per sample (collate_keep_images)
         if device is None:
             raise ValueError("prepare_data: decoded images are resized on the device; pass `device`")
-        out_imgs = ops.resize_pil_bilinear([imgs[i] for i in order.tolist()],
-                                           [bt_masks[b].shape[-1] for b in branches], device)
+        picked = [imgs[i] for i in order.tolist()]
+        if any(im.dim() == 1 for im in picked):
+            # `device_jpeg` hand-over: JPEG files (and the odd host-decoded image) -> decoded on the device -> resized there
+            src, offs, hs, ws = ops.images_to_device(picked, device)
+            out_imgs = ops.resize_pil_bilinear_device(src, offs, hs, ws, [bt_masks[b].shape[-1] for b in branches])
+        else:
+            out_imgs = ops.resize_pil_bilinear(picked, [bt_masks[b].shape[-1] for b in branches], device)
     else:
         out_imgs = [take(imgs[b]) for b in branches]
     out_rois = [take_small(rois[b]) for b in branches]

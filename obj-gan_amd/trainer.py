@@ -442,6 +442,25 @@ class condGANTrainer(object):
         self.gen_iterations = 0
         return self
 
+    # The frozen Inception chains (DAMSM image encoder: forward + backward w.r.t. the image; Inception-score monitor:
+    # forward) are shape-static and launch-bound: each is captured once into hipGraphs and replayed (objgan_hip.graphs).
+    use_graphs = True
+
+    def _graphed(self, attr):
+        import encoders
+        enc = getattr(self, attr)
+        if (not self.use_graphs or self.device.type != "cuda"
+                or not isinstance(enc, (encoders.CNN_ENCODER, encoders.INCEPTION_V3))):
+            return enc
+        cache = self.__dict__.setdefault("_graph_wrappers", {})
+        got = cache.get(attr)
+        if got is None or got[0] is not enc:
+            from objgan_hip import graphs
+            fn = enc if attr == "image_encoder" else (lambda x, enc=enc: (enc(x),))
+            ver = graphs.graphed_encoder(enc).version
+            got = cache[attr] = (enc, graphs.GraphedCallable(fn, version=ver, name=attr))
+        return got[1]
+
     def _d_optimizers(self):
         return self.optimizersPatD + self.optimizersShpD + [self.optimizerObjSSD, self.optimizerObjLSD]
 
@@ -657,7 +676,7 @@ class condGANTrainer(object):
         self.optimizerG.zero_grad()
         bt_last = bt_c_codes[-1] if bt_c_codes else None
         errG_total, G_logs = G_loss(self.netsPatD, self.netsShpD, self.netObjSSD, self.netObjLSD,
-                                    self.image_encoder, fake_imgs, hmaps, words_embs, sent_emb,
+                                    self._graphed("image_encoder"), fake_imgs, hmaps, words_embs, sent_emb,
                                     clabels_emb, bt_last, self.match_labels, b["cap_lens"],
                                     b["class_ids"], rois[0], fm_rois, num_rois, use_obj=self.use_obj) \
             if want_logs else _g_loss_quiet(self, fake_imgs, hmaps, words_embs, sent_emb, clabels_emb,
@@ -695,7 +714,9 @@ class condGANTrainer(object):
             img = out["fake_imgs"][-1]
             self.is_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.is_stream), torch.no_grad():
-                pred = self.inception_model(img)
+                pred = self._graphed("inception_model")(img)
+                if isinstance(pred, tuple):              # (a replayed graph hands out its static output buffer: the
+                    pred = pred[0].clone()               #  caller keeps predictions across steps, write_scores)
             # the image was allocated on the main stream and is read on the side stream; the prediction
             # the other way round: tell the caching allocator, and remember where to wait before reading
             img.record_stream(self.is_stream)
@@ -810,7 +831,7 @@ def _g_loss_quiet(tr, fake_imgs, hmaps, words_embs, sent_emb, clabels_emb, bt_c,
                   num_rois):
     """G_loss without building the log string (no .item() host syncs on non-print steps)."""
     import miscc.losses as L
-    total, _ = L.G_loss(tr.netsPatD, tr.netsShpD, tr.netObjSSD, tr.netObjLSD, tr.image_encoder,
+    total, _ = L.G_loss(tr.netsPatD, tr.netsShpD, tr.netObjSSD, tr.netObjLSD, tr._graphed("image_encoder"),
                         fake_imgs, hmaps, words_embs, sent_emb, clabels_emb, bt_c, tr.match_labels,
                         b["cap_lens"], b["class_ids"], rois[0], fm_rois, num_rois, quiet=True,
                         use_obj=tr.use_obj, streams=tr._d_side_streams() or None)

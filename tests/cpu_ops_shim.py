@@ -156,6 +156,27 @@ def resize_pil_bilinear(images, sizes, device):
             for S in sizes]
 
 
+def jpeg_parse(files):
+    """the real host-only parser of the C-ABI (no GPU call)"""
+    from objgan_hip import ops as real_ops
+    return real_ops.jpeg_parse(files)
+
+
+def images_to_device(items, device):
+    """CPU definition of the `device_jpeg` hand-over: JPEG files through the numpy oracle (bit for bit Pillow), host-decoded
+    images as they are -> (list of uint8 [H, W, 3] arrays, None, heights, widths)"""
+    from oracle import jpeg_oracle as J
+    arrs = []
+    for it in items:
+        a = it.numpy() if torch.is_tensor(it) else np.asarray(it)
+        arrs.append(J.decode(a.tobytes()) if a.ndim == 1 else np.asarray(a, np.uint8))
+    return arrs, None, [a.shape[0] for a in arrs], [a.shape[1] for a in arrs]
+
+
+def resize_pil_bilinear_device(src, offs, hs, ws, sizes):
+    return resize_pil_bilinear(src, sizes, "cpu")
+
+
 def resize_masks(masks, sizes):
     from oracle import mask_resize as mr
     m = masks.detach().cpu().numpy().astype(np.float64)
@@ -189,7 +210,7 @@ def get_conv_math():
 API = ("conv2d", "conv2d_cat", "conv2d_frozen", "linear", "norm_act", "norm_act_eval", "attn_general", "attn_bu", "masked_max",
        "softmax_strided", "roi_align", "avgpool2s1", "bilinear_resize", "lstm_bidir_forward", "adam_step_",
        "adam_step_gated_", "ema_update_", "max_pool2d", "avg_pool2d", "lift_stem_conv", "bmm", "repack_arena", "bce_const",
-       "resize_pil_bilinear", "resize_masks")
+       "resize_pil_bilinear", "resize_masks", "jpeg_parse", "images_to_device", "resize_pil_bilinear_device")
 
 
 def install(monkeypatch):
