@@ -332,16 +332,23 @@ int objgan_resize_pil_rgb8(const unsigned char* src, const long* offs, const int
  *                       3 precision, 4 components, 5 sampling, 6 scan, 7 tables, 8 truncated): the caller routes that file
  *                       to its host decoder knowingly.
  * objgan_jpeg_plan      HOST ONLY.  Lays a batch out: descs[i] gets its file's byte offset in the batch buffer
- *                       (file_offsets[i], multiples of 16), its output byte offset and its workspace slices.
+ *                       (file_offsets[i], multiples of 16), its output byte offset, its workspace slices and the slice of
+ *                       the entropy index handed in (nsegs[i] entries; NULL / 0: none).
  *                       -> workspace bytes (0: a refused descriptor in the batch).
- * objgan_jpeg_decode    files: the batch's files back to back (device); descs_host: the planned descriptors (launch
- *                       geometry), descs_dev: a device copy of the same bytes (what the kernels read); out: image i as
- *                       [height][width][3] RGB bytes at its output offset; ws: objgan_jpeg_plan's byte count. */
+ * objgan_jpeg_decode    files: the batch's files back to back (device, buffer padded to 16 bytes); descs_host: the planned
+ *                       descriptors (launch geometry), descs_dev: a device copy of the same bytes (what the kernels read);
+ *                       out: image i as [height][width][3] RGB bytes at its output offset; ws: objgan_jpeg_plan's byte
+ *                       count.  The Huffman scan of a file is serial: a file without index is walked by ONE lane, which
+ *                       writes its state at every MCU-row start to index_out (objgan_jpeg_seg_bytes() bytes per MCU row,
+ *                       image i at the sum of the MCU rows of the images before it; NULL: not wanted); handed back in
+ *                       as index_in (NULL: none) the same file is decoded by one lane per MCU row -- a training set is
+ *                       decoded once per epoch, so the index of the first epoch serves all later ones. */
 long objgan_jpeg_desc_bytes(void);
+long objgan_jpeg_seg_bytes(void);
 int objgan_jpeg_parse(const unsigned char* file, long nbytes, void* desc_out);
-long objgan_jpeg_plan(void* descs, int n, const long* file_offsets, const long* out_offsets);
+long objgan_jpeg_plan(void* descs, int n, const long* file_offsets, const long* out_offsets, const int* nsegs);
 int objgan_jpeg_decode(const unsigned char* files, const void* descs_host, const void* descs_dev, int n,
-                       unsigned char* out, void* ws, long ws_bytes, void* stream);
+                       unsigned char* out, void* ws, long ws_bytes, const void* index_in, void* index_out, void* stream);
 
 /* ---- per-box instance masks on the device (the loader side of the path) --------------------
  * Replaces the four `skimage.transform.resize(mask, [s, s])` calls per box of reference

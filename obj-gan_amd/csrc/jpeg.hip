@@ -5,14 +5,16 @@
 // fancy upsampling, RGB output).  Here the file BYTES cross PCIe and the image is decoded on the device, bit for bit what
 // Pillow returns, in three kernels:
 //
-//   jpeg_entropy_kernel   one 64-lane workgroup per image: the Huffman-coded scan is a serial bit stream (no restart
-//                         markers in ordinary files), so ONE lane walks it -- JPEG Annex F / jdhuff.c decode_mcu: 9-bit
-//                         look-ahead table, canonical-code walk for longer codes, DC prediction, EOB / ZRL, restart
-//                         intervals -- while all 64 lanes stage the file through an 8 KB LDS ring with 16-byte loads and keep
-//                         the derived Huffman tables in LDS.  A batch decodes its images in parallel on as many CUs; a
-//                         640 x 480 photograph takes ~10 ms on its lane, a batch of 16 runs beside the training step on a
-//                         side stream.  Output: quantised coefficients, int16 [block][64] in natural order, written sparsely
-//                         into a zero-filled buffer.
+//   jpeg_entropy_kernel   one 64-lane workgroup per image.  The Huffman-coded scan is a serial bit stream (no restart markers
+//                         in ordinary files): a file seen for the FIRST time is walked by one lane -- JPEG Annex F /
+//                         jdhuff.c decode_mcu: 9-bit look-ahead table, canonical-code walk for longer codes, DC prediction,
+//                         EOB / ZRL, restart intervals; tables and a per-lane 128-byte window of the file in LDS -- and on the
+//                         way the lane records its state (byte position, bit accumulator, DC predictors) at every MCU-row
+//                         start: the file's ENTROPY INDEX (48 bytes per MCU row).  A training set is decoded once per epoch,
+//                         so from the second epoch on the file arrives with its index and every MCU row is decoded by its own
+//                         lane (60 rows of a 640 x 480 image at once).  Same state machine, same state: bit-identical.
+//                         Output: quantised coefficients, int16 [block][64] in natural order, written sparsely into a
+//                         zero-filled buffer.
 //   jpeg_idct_kernel      one thread per 8 x 8 block: de-quantisation and the accurate integer inverse DCT of jidctint.c
 //                         (jpeg_idct_islow: CONST_BITS 13, PASS1_BITS 2), samples clamped to 0..255 into the component's
 //                         plane.  Integer arithmetic: exactly libjpeg's values.
@@ -46,6 +48,8 @@ struct JpegDesc {                      // first fields mirrored by ctypes (objga
     long file_offset, nbytes;          // where the file sits in the batch's byte buffer (set by the caller)
     long out_offset;                   // byte offset of this image's RGB output (set by the caller)
     long coef_offset, plane_offset;    // element / byte offsets into the workspace (set by objgan_jpeg_plan)
+    long seg_offset, idx_offset;       // first entry of this image in the batch's index (in) / index (out) arrays
+    int nseg, pad0;                    // entries of the index handed in (0: none -- one lane decodes the whole scan)
     int ch[OG_JPEG_MAXC], cv[OG_JPEG_MAXC], ctq[OG_JPEG_MAXC], ctd[OG_JPEG_MAXC], cta[OG_JPEG_MAXC];
     int cblk_w[OG_JPEG_MAXC], cblk_h[OG_JPEG_MAXC];      // blocks per row / column of the component (MCU-padded)
     long ccoef[OG_JPEG_MAXC], cplane[OG_JPEG_MAXC];      // per-component offsets (elements of int16 / bytes) inside this image's slices
@@ -60,8 +64,21 @@ __constant__ int c_zigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 1
 // --------------------------------------------------------------------------------------------------------------
 // entropy decode
 // --------------------------------------------------------------------------------------------------------------
-#define OG_RING 8192                   // bytes of the file held in LDS (two halves refilled alternately)
-#define OG_HALF 4096
+// A SEGMENT is a run of consecutive MCUs with the decoder state at its first MCU.  A file seen for the first time is one
+// segment (state: start of the scan) walked by one lane, which writes the state at every MCU-row start into the file's
+// INDEX as it passes; a file that comes with its index is decoded by up to 64 lanes at once, one MCU row each.
+#define OG_WIN 128                     // bytes of the file each lane holds in LDS (refilled by the lane itself, 16-byte loads)
+
+struct JpegSeg {                       // decoder state in front of MCU `mcu` (48 bytes)
+    unsigned long long acc;            // bit accumulator (the low `nbits` bits are the unread bits)
+    int pos;                           // next byte of the file to read
+    int nbits;
+    int mcu;                           // first MCU of the segment; -1: entry not written (yet)
+    int todo;                          // MCUs until the next restart marker
+    int pred[OG_JPEG_MAXC];            // DC predictors
+    int marker;                        // a marker has been reached
+    int pad;
+};
 
 struct LdsHuff {
     unsigned short look[1 << OG_JPEG_LOOK];
@@ -72,17 +89,26 @@ struct LdsHuff {
 
 struct BitReader {
     const unsigned char* file;         // global
-    const unsigned char* ring;         // LDS image of file[ring_base .. ring_base + OG_RING)
-    long ring_base, nbytes, pos;       // pos: next byte of the file to read
+    unsigned char* win;                // this lane's LDS window: file[wbase .. wbase + OG_WIN)
+    long wbase, nbytes, pos;           // pos: next byte of the file to read
     unsigned long long acc;
     int nbits;
     bool marker;                       // a marker was reached: the rest of the segment reads as zeros (jdhuff.c)
 };
 
-__device__ __forceinline__ unsigned br_byte(const BitReader& b, long p) {
-    const long r = p - b.ring_base;
-    if (r >= 0 && r < OG_RING) return b.ring[(p) & (OG_RING - 1)];
-    return p < b.nbytes ? b.file[p] : 0xD9u;        // (slow path: an MCU longer than the staged window)
+__device__ __forceinline__ unsigned br_byte(BitReader& b, long p) {
+    if (p >= b.nbytes) return 0xD9u;
+    if (p < b.wbase || p >= b.wbase + OG_WIN) {             // refill: the 16-byte aligned window that starts at p
+        b.wbase = p & ~15L;
+#pragma unroll
+        for (int i = 0; i < OG_WIN; i += 16) {
+            uint4 v = {0xD9D9D9D9u, 0xD9D9D9D9u, 0xD9D9D9D9u, 0xD9D9D9D9u};
+            // (whole 16-byte pieces inside the batch buffer: files start on 16-byte boundaries and the buffer is padded)
+            if (b.wbase + i < ((b.nbytes + 15) & ~15L)) v = *reinterpret_cast<const uint4*>(b.file + b.wbase + i);
+            *reinterpret_cast<uint4*>(b.win + i) = v;
+        }
+    }
+    return b.win[p - b.wbase];
 }
 
 __device__ __forceinline__ void br_fill(BitReader& b) {
@@ -94,7 +120,7 @@ __device__ __forceinline__ void br_fill(BitReader& b) {
             } else {
                 v = br_byte(b, b.pos);
                 if (v == 0xFFu) {
-                    const unsigned nx = (b.pos + 1 < b.nbytes) ? br_byte(b, b.pos + 1) : 0xD9u;
+                    const unsigned nx = br_byte(b, b.pos + 1);
                     if (nx == 0) b.pos += 2;                 // stuffed zero
                     else { b.marker = true; v = 0; }         // RSTn / EOI / anything else: stop consuming
                 } else {
@@ -135,17 +161,19 @@ __device__ __forceinline__ int br_receive_extend(BitReader& b, int s) {
     return v < (1 << (s - 1)) ? v - ((1 << s) - 1) : v;
 }
 
+// grid: images.  seg_in: per image `nseg` entries at d.seg_offset (nseg = 0: the file has no index -- one segment from the
+// start of the scan); seg_out (may be null): one entry per MCU row at d.idx_offset, written by whichever lane passes the row.
 __global__ __launch_bounds__(64) void jpeg_entropy_kernel(const unsigned char* __restrict__ files,
-                                                          const JpegDesc* __restrict__ descs, short* __restrict__ coef) {
-    __shared__ __attribute__((aligned(16))) unsigned char ring[OG_RING];
-    __shared__ LdsHuff tabs[4];        // slot 2 * k + (0 dc / 1 ac) for the table pair k of the scan; see `slot`
-    __shared__ long s_pos;
-    __shared__ int s_done;
+                                                          const JpegDesc* __restrict__ descs, short* __restrict__ coef,
+                                                          const JpegSeg* __restrict__ seg_in, JpegSeg* __restrict__ seg_out) {
+    __shared__ __attribute__((aligned(16))) unsigned char wins[64 * OG_WIN];
+    __shared__ LdsHuff tabs[4];        // slots 0, 1: the scan's DC tables; 2, 3: its AC tables
+    __shared__ unsigned char zz[64];
     const JpegDesc& d = descs[blockIdx.x];
     if (d.reason != 0) return;
     const int lane = threadIdx.x;
     const unsigned char* file = files + d.file_offset;
-    // Huffman tables used by the components (at most two DC + two AC in baseline files; components that share ids share a slot)
+    // Huffman tables used by the components (at most two DC + two AC in one scan; components that share ids share a slot)
     int dslot[OG_JPEG_MAXC], aslot[OG_JPEG_MAXC];
     {
         int nd = 0, na = 0, did[2] = {-1, -1}, aid[2] = {-1, -1};
@@ -171,103 +199,85 @@ __global__ __launch_bounds__(64) void jpeg_entropy_kernel(const unsigned char* _
             }
         }
     }
-    // ring: file bytes [base, base + OG_RING); the half containing `pos` and the next one are always resident
-    long base = (d.scan_offset / OG_HALF) * (long)OG_HALF;
-    auto load_half = [&](long from) {              // file[from .. from + OG_HALF) -> ring[from & (OG_RING - 1) ..]
-        for (int i = lane * 16; i < OG_HALF; i += 64 * 16) {
-            const long p = from + i;
-            uint4 v = {0xD9D9D9D9u, 0xD9D9D9D9u, 0xD9D9D9D9u, 0xD9D9D9D9u};
-            if (p + 16 <= d.nbytes && (((uintptr_t)(file + p)) & 15) == 0) {
-                v = *reinterpret_cast<const uint4*>(file + p);
-            } else {
-                unsigned char* q = reinterpret_cast<unsigned char*>(&v);
-                for (int j = 0; j < 16; ++j) if (p + j < d.nbytes) q[j] = file[p + j];
-            }
-            *reinterpret_cast<uint4*>(ring + ((from + i) & (OG_RING - 1))) = v;
-        }
-    };
-    load_half(base);
-    load_half(base + OG_HALF);
-    if (lane == 0) { s_pos = d.scan_offset; s_done = 0; }
+    zz[lane] = (unsigned char)c_zigzag[lane];
     __syncthreads();
 
-    // lane 0's decoder state lives across the refill rounds
-    BitReader br;
-    br.file = file; br.ring = ring; br.ring_base = base; br.nbytes = d.nbytes; br.pos = d.scan_offset;
-    br.acc = 0; br.nbits = 0; br.marker = false;
-    int pred[OG_JPEG_MAXC] = {0, 0, 0};
-    int mcu = 0;
-    // the descriptor fields the serial loop needs, in registers (a global load per use would sit on lane 0's critical path)
+    // the descriptor fields the serial loop needs, in registers (a global load per use would sit on the lane's critical path)
     const int ncomp = d.ncomp, mcux = d.mcux, rint = d.restart_interval;
     const int nmcu = d.mcux * d.mcuy;
     int c_h[OG_JPEG_MAXC], c_v[OG_JPEG_MAXC], c_bw[OG_JPEG_MAXC];
     long c_co[OG_JPEG_MAXC];
     for (int c = 0; c < OG_JPEG_MAXC; ++c) { c_h[c] = d.ch[c]; c_v[c] = d.cv[c]; c_bw[c] = d.cblk_w[c]; c_co[c] = d.ccoef[c]; }
-    int todo = rint;
     short* cimg = coef + d.coef_offset;
+    const int nseg = d.nseg > 0 ? d.nseg : 1;
+    JpegSeg* iout = seg_out ? seg_out + d.idx_offset : nullptr;
 
-    while (true) {
-        if (lane == 0) {
-            // decode MCUs while the read position stays inside the first half of the resident window
-            while (mcu < nmcu && br.pos < br.ring_base + OG_HALF) {
-                if (rint && todo == 0) {
-                    // byte-align, skip to behind the RSTn marker (jdhuff.c process_restart)
-                    br.acc = 0; br.nbits = 0; br.marker = false;
-                    while (br.pos + 1 < br.nbytes) {
-                        const unsigned a0 = br_byte(br, br.pos), a1 = br_byte(br, br.pos + 1);
-                        if (a0 == 0xFFu && a1 >= 0xD0u && a1 <= 0xD7u) break;
-                        br.pos += 1;
-                    }
-                    br.pos += 2;
-                    pred[0] = pred[1] = pred[2] = 0;
-                    todo = rint;
-                    if (br.pos >= br.ring_base + OG_HALF) break;         // refill first, then decode this MCU
+    for (int sg = lane; sg < nseg; sg += 64) {
+        BitReader br;
+        br.file = file; br.win = wins + lane * OG_WIN; br.wbase = -OG_WIN; br.nbytes = d.nbytes;
+        int pred[OG_JPEG_MAXC] = {0, 0, 0};
+        int mcu, mcu_end, todo;
+        if (d.nseg > 0) {
+            const JpegSeg e = seg_in[d.seg_offset + sg];
+            br.pos = e.pos; br.acc = e.acc; br.nbits = e.nbits; br.marker = e.marker != 0;
+            pred[0] = e.pred[0]; pred[1] = e.pred[1]; pred[2] = e.pred[2];
+            mcu = e.mcu; todo = e.todo;
+            mcu_end = sg + 1 < d.nseg ? seg_in[d.seg_offset + sg + 1].mcu : nmcu;
+        } else {
+            br.pos = d.scan_offset; br.acc = 0; br.nbits = 0; br.marker = false;
+            mcu = 0; mcu_end = nmcu; todo = rint;
+        }
+        while (mcu < mcu_end) {
+            if (rint && todo == 0) {
+                // byte-align, skip to behind the RSTn marker (jdhuff.c process_restart)
+                br.acc = 0; br.nbits = 0; br.marker = false;
+                while (br.pos + 1 < br.nbytes) {
+                    const unsigned a0 = br_byte(br, br.pos), a1 = br_byte(br, br.pos + 1);
+                    if (a0 == 0xFFu && a1 >= 0xD0u && a1 <= 0xD7u) break;
+                    br.pos += 1;
                 }
-                const int my = mcu / mcux, mx = mcu - my * mcux;
-                for (int c = 0; c < ncomp; ++c) {
-                    const LdsHuff& td = tabs[dslot[c]];
-                    const LdsHuff& ta = tabs[aslot[c]];
-                    for (int by = 0; by < c_v[c]; ++by)
-                        for (int bx = 0; bx < c_h[c]; ++bx) {
-                            short* blk = cimg + c_co[c] + ((long)(my * c_v[c] + by) * c_bw[c] + (mx * c_h[c] + bx)) * 64;
-                            int s = br_huff(br, td);
-                            pred[c] += br_receive_extend(br, s & 15);
-                            blk[0] = (short)pred[c];
-                            int k = 1;
-                            while (k < 64) {
-                                const int rs = br_huff(br, ta);
-                                const int r = rs >> 4;
-                                s = rs & 15;
-                                if (s) {
-                                    k += r;
-                                    const int v = br_receive_extend(br, s);
-                                    if (k > 63) break;
-                                    blk[c_zigzag[k]] = (short)v;
-                                    k += 1;
-                                } else if (r == 15) {
-                                    k += 16;
-                                } else {
-                                    break;
-                                }
+                br.pos += 2;
+                pred[0] = pred[1] = pred[2] = 0;
+                todo = rint;
+            }
+            const int my = mcu / mcux, mx = mcu - my * mcux;
+            if (iout && mx == 0) {                          // the index entry of this MCU row: the state right here
+                JpegSeg e;
+                e.acc = br.acc; e.pos = (int)br.pos; e.nbits = br.nbits; e.mcu = mcu; e.todo = todo;
+                e.pred[0] = pred[0]; e.pred[1] = pred[1]; e.pred[2] = pred[2]; e.marker = br.marker ? 1 : 0; e.pad = 0;
+                iout[my] = e;
+            }
+            for (int c = 0; c < ncomp; ++c) {
+                const LdsHuff& td = tabs[dslot[c]];
+                const LdsHuff& ta = tabs[aslot[c]];
+                for (int by = 0; by < c_v[c]; ++by)
+                    for (int bx = 0; bx < c_h[c]; ++bx) {
+                        short* blk = cimg + c_co[c] + ((long)(my * c_v[c] + by) * c_bw[c] + (mx * c_h[c] + bx)) * 64;
+                        int s = br_huff(br, td);
+                        pred[c] += br_receive_extend(br, s & 15);
+                        blk[0] = (short)pred[c];
+                        int k = 1;
+                        while (k < 64) {
+                            const int rs = br_huff(br, ta);
+                            const int r = rs >> 4;
+                            s = rs & 15;
+                            if (s) {
+                                k += r;
+                                const int v = br_receive_extend(br, s);
+                                if (k > 63) break;
+                                blk[zz[k]] = (short)v;
+                                k += 1;
+                            } else if (r == 15) {
+                                k += 16;
+                            } else {
+                                break;
                             }
                         }
-                }
-                mcu += 1;
-                todo -= 1;
+                    }
             }
-            s_pos = br.pos;
-            s_done = mcu >= nmcu ? 1 : 0;
+            mcu += 1;
+            todo -= 1;
         }
-        __syncthreads();
-        if (s_done) break;
-        // slide the window: the half that `pos` left is replaced by the half after the resident one
-        const long pos = s_pos;
-        while (pos >= base + OG_HALF) {
-            load_half(base + OG_RING);         // overwrites the slots of [base, base + OG_HALF)
-            base += OG_HALF;
-        }
-        if (lane == 0) br.ring_base = base;
-        __syncthreads();
     }
 }
 
@@ -589,17 +599,24 @@ static long og_jpeg_blocks(const JpegDesc& d) {
     return b;
 }
 
-// Lay the batch out: file / output offsets from the caller's arrays, workspace slices from the geometry.
+// Lay the batch out: file / output offsets from the caller's arrays, workspace slices from the geometry, index slices from
+// nsegs (entries of the entropy index handed in per image; NULL or 0: none).
 // -> workspace bytes: [int16 coefficients of all images | uint8 planes of all images], or 0 on a bad descriptor.
-long objgan_jpeg_plan(void* descs, int n, const long* file_offsets, const long* out_offsets) {
+long objgan_jpeg_plan(void* descs, int n, const long* file_offsets, const long* out_offsets, const int* nsegs) {
     JpegDesc* d = reinterpret_cast<JpegDesc*>(descs);
-    long blocks = 0;
+    long blocks = 0, segs = 0, rows = 0;
     for (int i = 0; i < n; ++i) {
         if (d[i].reason != 0) return 0;
         d[i].file_offset = file_offsets[i];
         d[i].out_offset = out_offsets[i];
         d[i].coef_offset = blocks * 64;
         blocks += og_jpeg_blocks(d[i]);
+        d[i].nseg = nsegs ? nsegs[i] : 0;
+        if (d[i].nseg < 0 || d[i].nseg > d[i].mcuy) return 0;
+        d[i].seg_offset = segs;
+        segs += d[i].nseg;
+        d[i].idx_offset = rows;
+        rows += d[i].mcuy;
     }
     long done = 0;
     for (int i = 0; i < n; ++i) {
@@ -609,17 +626,24 @@ long objgan_jpeg_plan(void* descs, int n, const long* file_offsets, const long* 
     return blocks * 128 + blocks * 64;
 }
 
-// files: the batch's JPEG files back to back (device); descs_host / descs_dev: the planned descriptors (the device copy is
-// what the kernels read, the host copy gives the launch geometry); out: RGB bytes, image i [height][width][3] at its
-// out_offset; ws: objgan_jpeg_plan's byte count.  Asynchronous on `stream`.
+long objgan_jpeg_seg_bytes(void) { return (long)sizeof(JpegSeg); }
+
+// files: the batch's JPEG files back to back (device, every file on a 16-byte boundary, the buffer padded to 16 bytes);
+// descs_host / descs_dev: the planned descriptors (the device copy is what the kernels read, the host copy gives the launch
+// geometry); out: RGB bytes, image i [height][width][3] at its out_offset; ws: objgan_jpeg_plan's byte count.
+// index_in (may be NULL): the entropy-index entries the plan counted (image i: nsegs[i] entries of objgan_jpeg_seg_bytes()
+// bytes, back to back) -- a file with an index is decoded by one lane per MCU row.  index_out (may be NULL): receives one
+// entry per MCU row of every image (image i at the sum of the MCU rows before it): what to hand in next time.
+// Asynchronous on `stream`.
 int objgan_jpeg_decode(const unsigned char* files, const void* descs_host, const void* descs_dev, int n,
-                       unsigned char* out, void* ws, long ws_bytes, void* stream) {
+                       unsigned char* out, void* ws, long ws_bytes, const void* index_in, void* index_out, void* stream) {
     OG_ENTRY();
     if (n <= 0 || !files || !descs_host || !descs_dev || !out || !ws) return OG_BAD_ARGS;
     const JpegDesc* h = reinterpret_cast<const JpegDesc*>(descs_host);
     long blocks = 0, max_blocks = 0, max_quads = 0;
     for (int i = 0; i < n; ++i) {
         if (h[i].reason != 0) return OG_BAD_ARGS;
+        if (h[i].nseg > 0 && !index_in) return OG_BAD_ARGS;
         const long b = og_jpeg_blocks(h[i]);
         blocks += b;
         max_blocks = b > max_blocks ? b : max_blocks;
@@ -632,7 +656,8 @@ int objgan_jpeg_decode(const unsigned char* files, const void* descs_host, const
     short* coef = reinterpret_cast<short*>(ws);
     unsigned char* planes = reinterpret_cast<unsigned char*>(ws);
     if (hipMemsetAsync(coef, 0, (size_t)blocks * 128, s) != hipSuccess) return og_launch_status();
-    hipLaunchKernelGGL(jpeg_entropy_kernel, dim3(n), dim3(64), 0, s, files, dd, coef);
+    hipLaunchKernelGGL(jpeg_entropy_kernel, dim3(n), dim3(64), 0, s, files, dd, coef,
+                       reinterpret_cast<const JpegSeg*>(index_in), reinterpret_cast<JpegSeg*>(index_out));
     hipLaunchKernelGGL(jpeg_idct_kernel, dim3(og_cdiv(max_blocks, 256), n), dim3(256), 0, s, dd, coef, planes, (int)max_blocks);
     hipLaunchKernelGGL(jpeg_color_kernel, dim3(og_cdiv(max_quads, 256), n), dim3(256), 0, s, dd, planes, out, (int)max_quads);
     return og_launch_status();

@@ -151,16 +151,17 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(
 // (and the reference's CUDA kernel, which leaves the order of its atomicAdds unspecified).  r02's privatised scatter
 // took 146 us per launch, an ordered gather without the table 609 us.
 #define ROI_TAB_MAX 512           // rois per call the table path takes (the hot path has 160: 16 images x 10; 320 at B = 32)
-struct RoiTabDims { int maxs, maxp, o_start, o_sorted, o_smp, stride; };
+struct RoiTabDims { int maxs, maxp, o_start, o_sorted, o_smp, o_rlist, stride; };
 static inline RoiTabDims roi_tab_dims(int num_rois, int HW, int S) {
     RoiTabDims d;
     d.maxs = num_rois * S;                                   // samples of one image (all rois may belong to it)
     d.maxp = HW < 4 * d.maxs ? HW : 4 * d.maxs;              // touched pixels
-    // ints per image: [hdr 4][pix maxp][start HW + 1][sorted maxs][smp 4 x maxs], every part 16-byte aligned
+    // ints per image: [hdr 4][pix maxp][start HW + 1][sorted maxs][smp 4 x maxs][rois of the image], every part 16-byte aligned
     d.o_start = 4 + ((d.maxp + 3) & ~3);
     d.o_sorted = d.o_start + ((HW + 1 + 3) & ~3);
     d.o_smp = d.o_sorted + ((d.maxs + 3) & ~3);
-    d.stride = d.o_smp + 4 * d.maxs;
+    d.o_rlist = d.o_smp + 4 * d.maxs;
+    d.stride = d.o_rlist + ((num_rois + 3) & ~3);
     return d;
 }
 
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(256) void roi_tap_table_kernel(
     int* start = hdr + d.o_start;
     int* sorted = hdr + d.o_sorted;
     int* smp = hdr + d.o_smp;
+    int* rlist = hdr + d.o_rlist;
     for (int i = threadIdx.x; i < HW; i += blockDim.x) cnt[i] = 0;
     // ordered compaction of the rois that belong to image b (ballot + prefix count per wave, waves in order)
     int nlist = 0;
@@ -204,6 +206,7 @@ __global__ __launch_bounds__(256) void roi_tap_table_kernel(
         __syncthreads();
     }
     const int n_smp = nlist * S;
+    for (int i = threadIdx.x; i < nlist; i += blockDim.x) rlist[i] = s_list[i];
     for (int i = threadIdx.x; i < n_smp; i += blockDim.x) {
         const int k = i / S, sidx = i - k * S;
         const int r = s_list[k];
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(256) void roi_tap_table_kernel(
         roi_geometry(rois + (size_t)r * 5, spatial_scale, H, W, AH, AW, sidx, g);
         const int off = g.valid ? g.off : -1;
         soff[i] = (unsigned short)(off >= 0 ? off : 0xffff);
-        smp[4 * i + 0] = off;
+        smp[4 * i + 0] = k;                            // the roi's position in this image's list (rlist[k] = r)
         smp[4 * i + 1] = __float_as_int(g.h_ratio);
         smp[4 * i + 2] = __float_as_int(g.w_ratio);
         smp[4 * i + 3] = (r << 8) | sidx;
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(256) void roi_tap_table_kernel(
             s_scan[2 * t] = e; s_scan[2 * t + 1] = n;
             e += a; n += c;
         }
-        hdr[0] = n; hdr[1] = e; hdr[2] = n_smp; hdr[3] = 0;
+        hdr[0] = n; hdr[1] = e; hdr[2] = n_smp; hdr[3] = nlist;
         start[HW] = e;
     }
     __syncthreads();
@@ -262,20 +265,53 @@ __global__ __launch_bounds__(256) void roi_tap_table_kernel(
 // ranges, concatenated) is strided over the 16 lanes and their partial sums meet in a fixed butterfly: with the 1/16
 // spatial-scale of the hot path most of an image's 360 samples share a handful of anchors, and one lane walking 300
 // dependent loads took 284 us per launch.
+// Round 6: the per-tap chain sorted[k] -> smp[..] -> top_grad[..] was three dependent global loads, repeated by every channel
+// of the slab (111 us per launch, 20 MB moved: latency, not bytes).  A workgroup now stages what its elements read ONCE:
+// the image's samples in anchor order (16 bytes each) and the top gradients of the image's rois for the slab's channels
+// ([roi of the image][channel][sample]: one contiguous, fully coalesced piece per roi) -- every tap is then two LDS reads.
+// Same taps, same per-lane order, same butterfly: the sums are bit-identical to the global-memory form, which stays as the
+// path for an image whose table or gradient slab does not fit (ROI_LDS_SMP samples / ROI_LDS_G floats).
 #define ROI_SUB 16
+#define ROI_LDS_SMP 1024
+#define ROI_LDS_G 8192
+__device__ __forceinline__ float roi_tap_value(float dv, float h_ratio, float w_ratio, int t) {
+    // reference kernel.cu:137-140: `(1. - h_ratio)` is double, `(1 - w_ratio)` is FLOAT (int
+    // literal); the two h_ratio terms are all-float products.
+    const double omh = 1.0 - (double)h_ratio;
+    const float omw = 1.0f - w_ratio;
+    const float dh_ = dv * h_ratio;
+    if (t == 0) return (float)(((double)dv * omh) * (double)omw);
+    if (t == 1) return (float)(((double)dv * omh) * (double)w_ratio);
+    if (t == 2) return dh_ * omw;
+    return dh_ * w_ratio;
+}
+
 __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
     const float* __restrict__ top_grad, const int* __restrict__ ws, float* __restrict__ bottom_grad,
     int C, int HW, int W, int S, RoiTabDims d, int cpb) {
+    __shared__ int4 s_smp[ROI_LDS_SMP];
+    __shared__ float s_g[ROI_LDS_G];
     const int b = blockIdx.y;
     const int* hdr = ws + (size_t)b * d.stride;
     const int* pix = hdr + 4;
     const int* start = hdr + d.o_start;
     const int* sorted = hdr + d.o_sorted;
     const int4* smp = reinterpret_cast<const int4*>(hdr + d.o_smp);
-    const int n_pix = hdr[0];
+    const int* rlist = hdr + d.o_rlist;
+    const int n_pix = hdr[0], n_e = hdr[1], nlist = hdr[3];
     const int c0 = blockIdx.x * cpb;
     const int nc = min(cpb, C - c0);
     const int sub = threadIdx.x & (ROI_SUB - 1), grp = threadIdx.x / ROI_SUB;
+    const bool staged = n_e <= ROI_LDS_SMP && nlist * nc * S <= ROI_LDS_G;          // (uniform over the workgroup)
+    if (staged) {
+        for (int k = threadIdx.x; k < n_e; k += 256) s_smp[k] = smp[sorted[k]];
+        const int per = nc * S;                                                     // floats of one roi's slab
+        for (int i = threadIdx.x; i < nlist * per; i += 256) {
+            const int kl = i / per, j = i - kl * per;
+            s_g[i] = top_grad[((size_t)rlist[kl] * C + c0) * S + j];
+        }
+        __syncthreads();
+    }
     for (int i = grp; i < n_pix * nc; i += 256 / ROI_SUB) {
         const int ci = i / n_pix, ip = i - ci * n_pix;
         const int c = c0 + ci;
@@ -293,20 +329,17 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
         for (int m = sub; m < total; m += ROI_SUB) {
             const int t = (m >= lim[0]) + (m >= lim[1]) + (m >= lim[2]);
             const int k = t == 0 ? k0[0] + m : t == 1 ? k0[1] + m - lim[0] : t == 2 ? k0[2] + m - lim[1] : k0[3] + m - lim[2];
-            const int4 g = smp[sorted[k]];
-            const float h_ratio = __int_as_float(g.y), w_ratio = __int_as_float(g.z);
-            const float dv = top_grad[((size_t)(g.w >> 8) * C + c) * S + (g.w & 255)];
-            // reference kernel.cu:137-140: `(1. - h_ratio)` is double, `(1 - w_ratio)` is FLOAT (int
-            // literal); the two h_ratio terms are all-float products.
-            const double omh = 1.0 - (double)h_ratio;
-            const float omw = 1.0f - w_ratio;
-            const float dh_ = dv * h_ratio;
-            float v;
-            if (t == 0) v = (float)(((double)dv * omh) * (double)omw);
-            else if (t == 1) v = (float)(((double)dv * omh) * (double)w_ratio);
-            else if (t == 2) v = dh_ * omw;
-            else v = dh_ * w_ratio;
-            acc += v;
+            float dv, h_ratio, w_ratio;
+            if (staged) {
+                const int4 g = s_smp[k];
+                h_ratio = __int_as_float(g.y); w_ratio = __int_as_float(g.z);
+                dv = s_g[(g.x * nc + ci) * S + (g.w & 255)];
+            } else {
+                const int4 g = smp[sorted[k]];
+                h_ratio = __int_as_float(g.y); w_ratio = __int_as_float(g.z);
+                dv = top_grad[((size_t)(g.w >> 8) * C + c) * S + (g.w & 255)];
+            }
+            acc += roi_tap_value(dv, h_ratio, w_ratio, t);
         }
 #pragma unroll
         for (int o = ROI_SUB / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);

@@ -84,7 +84,7 @@ SIGNATURES = {
     "objgan_resize_pil_rgb8": [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr],
     "objgan_mask_resize": [_ptr, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr],
     "objgan_jpeg_parse": [ctypes.c_char_p, _c_long, _ptr],
-    "objgan_jpeg_decode": [_ptr, _ptr, _ptr, _c_int, _ptr, _ptr, _c_long, _ptr],
+    "objgan_jpeg_decode": [_ptr, _ptr, _ptr, _c_int, _ptr, _ptr, _c_long, _ptr, _ptr, _ptr],
     "objgan_prof_enable": [_c_int],
     "objgan_conv_bank_layout": [_c_int] * 10,
     "objgan_conv_wgrad_rec_ok": [_c_int] * 8,
@@ -103,7 +103,8 @@ LONG_RETURN = {"objgan_conv_packed_floats": [_c_int, _c_int, _c_int],
                "objgan_channel_sum_ws_floats": [_c_int] * 3,
                "objgan_roi_align_backward_ws_floats": [_c_int] * 7,
                "objgan_jpeg_desc_bytes": [],
-               "objgan_jpeg_plan": [_ptr, _c_int, _ptr, _ptr]}
+               "objgan_jpeg_seg_bytes": [],
+               "objgan_jpeg_plan": [_ptr, _c_int, _ptr, _ptr, _ptr]}
 
 _LIB = None
 

@@ -358,8 +358,47 @@ def repack_arena(epoch_cell):
 # operand, the largest spread log2(max over channels / min over non-zero channels of the per-channel maximum) seen.
 _H2_CENSUS = None
 
+# Run-time guard of fp16x2.  The scale of an operand is per TENSOR; a GEMM row / column whose entries sit
+# 2^-k below the tensor's maximum keeps ~2^(k - 38) relative error -- harmless while channels stay within 2^16 of each other
+# (census of a training step: <= 2^6.2 at B = 16), wrong if training ever drives one channel's scale far from the rest.
+# `h2_guard_begin()` .. `h2_guard_end()` bracket ONE checked step (the trainer does that every `h2_guard_every` steps, rank-local,
+# host syncs included -- a census step is slower and is not a timed step): every fp16x2 launch reports the per-channel spread
+# of the operands whose channels are GEMM rows / columns, keyed by its call SITE (filter-bank address + direction; layer
+# geometry for the weight gradient).  A site whose spread exceeds 2^limit is DEMOTED: from then on it runs bf16x3 (exact
+# three-way split, no scale), and the event is logged.  Demotions are sticky for the life of the process.
+_H2_GUARD = {"on": False, "limit": 16.0, "demoted": {}, "log": [], "checked": 0}
 
-def _census(kind, t, dim):
+
+def h2_guard_begin(limit=None):
+    global _H2_CENSUS
+    if limit is not None:
+        _H2_GUARD["limit"] = float(limit)
+    _H2_GUARD["on"] = True
+    _H2_GUARD["saved_census"] = _H2_CENSUS
+    if _H2_CENSUS is None:
+        _H2_CENSUS = {}
+
+
+def h2_guard_end():
+    """-> the demotions this checked step added: [(site, kind, spread as log2, operand shape)]"""
+    global _H2_CENSUS
+    _H2_GUARD["on"] = False
+    _H2_CENSUS = _H2_GUARD.pop("saved_census", None)
+    new = _H2_GUARD.pop("new", [])
+    return new
+
+
+def h2_guard_state():
+    return {"demoted_sites": len(_H2_GUARD["demoted"]), "log": list(_H2_GUARD["log"]), "launches_checked": _H2_GUARD["checked"]}
+
+
+def h2_guard_reset():
+    _H2_GUARD["demoted"].clear()
+    del _H2_GUARD["log"][:]
+    _H2_GUARD["checked"] = 0
+
+
+def _census(kind, t, dim, site=None):
     if _H2_CENSUS is None:
         return
     m = t.detach().abs().amax(dim=[d for d in range(t.dim()) if d != dim])
@@ -371,6 +410,20 @@ def _census(kind, t, dim):
     ent[2] += 1
     if spread > ent[0]:
         ent[0], ent[1] = spread, tuple(t.shape)
+    if _H2_GUARD["on"] and site is not None:
+        _H2_GUARD["checked"] += 1
+        if spread > _H2_GUARD["limit"] and site not in _H2_GUARD["demoted"]:
+            _H2_GUARD["demoted"][site] = (kind, spread)
+            rec = (site, kind, round(spread, 1), tuple(t.shape))
+            _H2_GUARD["log"].append(rec)
+            _H2_GUARD.setdefault("new", []).append(rec)
+            import warnings
+            warnings.warn("objgan_hip fp16x2 guard: %s -- per-channel spread 2^%.1f > 2^%.0f on an operand of shape %s; this "
+                          "call site runs bf16x3 from now on" % (kind, spread, _H2_GUARD["limit"], tuple(t.shape)))
+
+
+def _demoted(site):
+    return bool(_H2_GUARD["demoted"]) and site in _H2_GUARD["demoted"]
 
 
 # Debug mode OBJGAN_H2_VERIFY=1: every maximum handed to a kernel from the per-tensor cache / a producer's
@@ -429,6 +482,9 @@ def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, tran
     Tg = len(dh)
     M = Cin if transpose else Cout
     math = _call_math(2.0 * M * C * Tg * N * PH * PW)
+    site = ("conv", w.data_ptr(), int(transpose))
+    if math == 4 and _demoted(site):
+        math = 2                              # fp16x2 guard: this filter bank's rows / columns are too far apart for one scale
     # the library picks the kernel -- hence the bank layout -- from sizes, taps and math: ask it
     layout = _q("objgan_conv_bank_layout", N, C, H, W, M, Tg, PH, PW, act, math)
     if math == 4 and (layout & 255) != 5:
@@ -437,7 +493,7 @@ def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, tran
     xmax = _absmax(x) if math == 4 else None
     if math == 4 and _H2_CENSUS is not None:
         _census("data gradient: filter columns (input channels)" if transpose else "forward: filter rows (output channels)",
-                w, 1 if transpose else 0)
+                w, 1 if transpose else 0, site)
     kmath, xk = math, x
     if math == 4 and _REC["on"] and not (x.data_ptr() & 15):
         # same arithmetic, same bank; the pixel operand as its fp16 record where that pays
@@ -495,9 +551,12 @@ def _dgrad_s2_phases(g, w, N, Cout, OH, OW, Cin, k, pad_h, pad_w, LH, LW, cachea
     dx = torch.empty((N, Cin, LH, LW), dtype=_F32, device=g.device)
     n = 4 * ((Cin * Tg * ((Cout + 15) // 16 * 16) * 3 + 1) // 2) + _AMAX_SLOTS    # bf16x3 banks: 6 B per element; + |w| maxima
     math = _call_math(2.0 * Cin * Cout * Tg * N * LH * LW)
+    site = ("conv", w.data_ptr(), 1)
+    if math == 4 and _demoted(site):
+        math = 2
     xmax = _absmax(g) if math == 4 else None
     if math == 4 and _H2_CENSUS is not None:
-        _census("data gradient: filter columns (input channels)", w, 1)
+        _census("data gradient: filter columns (input channels)", w, 1, site)
     key = _pack_key(w, 2, st, False, math) if cacheable else None
     if key is not None:
         ent, fresh = _bank_lookup(key, w, n, g.device)
@@ -655,13 +714,16 @@ def _conv_wgrad(x, g, Cout, k, stride, pad, refl, upsample, sink=None):
     else:
         dw_ = torch.empty((Cout, Cin, k, k), dtype=_F32, device=x.device)      # fully written: no zero-fill
     math = _call_math(2.0 * Cout * Cin * k * k * N * g.shape[2] * g.shape[3])
+    site = ("wgrad", sink[0].data_ptr() if sink is not None else 0, N, Cin, H, W, Cout, k, stride, int(upsample), refl)
+    if math == 4 and _demoted(site):
+        math = 2                              # fp16x2 guard: x / dy channels too far apart for one scale per tensor
     geo = (N, Cin, H, W, int(upsample), refl, Cout, g.shape[2], g.shape[3], k, stride, pad, math)
     nws = _q("objgan_conv_wgrad_ws_floats", *geo)
     ws = torch.empty(nws, dtype=_F32, device=x.device) if nws > 0 else None
     xmax, gmax = (_absmax(x), _absmax(g)) if math == 4 else (None, None)
     if math == 4 and _H2_CENSUS is not None:
-        _census("weight gradient: x channels (filter columns)", x, 1)
-        _census("weight gradient: dy channels (filter rows)", g, 1)
+        _census("weight gradient: x channels (filter columns)", x, 1, site)
+        _census("weight gradient: dy channels (filter rows)", g, 1, site)
     xk = x
     # Where: measured per shape class (profiles/r05_records_convbench.txt).  The record form wins where the register-
     # fragment gather has no constant-stride fast path or runs on few pixels -- up-sampled sources 120 -> 257 TFLOP/s,
@@ -1516,11 +1578,33 @@ def jpeg_parse(files):
     return descs, heads
 
 
-def jpeg_decode_batch(files, device):
+class JpegIndexCache(object):
+    """Entropy indexes of the files of a data set, kept ON THE DEVICE (48 bytes per MCU row: 3 KB for a 640 x 480 image,
+    ~250 MB for all of COCO train -- nothing next to 288 GB): key -> uint8 tensor.  The first decode of a file walks its
+    Huffman scan with one lane and leaves the index; every later decode (the next epoch) runs one lane per MCU row."""
+
+    def __init__(self):
+        self.entries = {}
+        self.hits = self.misses = 0
+
+    def get(self, key, nbytes, rows, seg_bytes):
+        e = self.entries.get(key)
+        if e is not None and e[0] == nbytes and e[1].numel() == rows * seg_bytes:
+            self.hits += 1
+            return e[1]
+        self.misses += 1
+        return None
+
+    def put(self, key, nbytes, index):
+        self.entries[key] = (nbytes, index)
+
+
+def jpeg_decode_batch(files, device, cache=None, keys=None):
     """files: baseline JPEG files (bytes-like) -> (rgb, offs, hs, ws): the decoded images back to back in ONE uint8 device
     buffer (image i: [hs[i], ws[i], 3] at byte offs[i]) -- bit for bit PIL.Image.open(f).convert('RGB') (reference
     miscc/load.py:141-151).  Only the file bytes cross PCIe.  Raises JpegUnsupported (with the index) for a file that is
-    not baseline."""
+    not baseline.  cache / keys (a JpegIndexCache and one hashable key per file): files whose entropy index is cached are
+    decoded by one lane per MCU row, the others by one lane -- and leave their index in the cache."""
     import numpy as np
     device = torch.device(device)
     if device.type != "cuda":
@@ -1532,13 +1616,20 @@ def jpeg_decode_batch(files, device):
         if heads[i, 8] != 0:
             raise JpegUnsupported(i, int(heads[i, 8]))
     lib = _lib.load()
+    seg_bytes = int(lib.objgan_jpeg_seg_bytes())
     hs, ws = [int(h) for h in heads[:, 1]], [int(w) for w in heads[:, 0]]
-    sizes = [(len(f) + 15) // 16 * 16 for f in files]                 # 16-byte aligned file starts (vector loads of the ring)
+    rows = [int(r) for r in heads[:, 6]]
+    sizes = [(len(f) + 15) // 16 * 16 for f in files]                 # 16-byte aligned file starts (vector loads of the window)
     foffs = np.concatenate(([0], np.cumsum(sizes)[:-1])).astype(np.int64)
     osz = [(h * w * 3 + 15) // 16 * 16 for h, w in zip(hs, ws)]
     ooffs = np.concatenate(([0], np.cumsum(osz)[:-1])).astype(np.int64)
+    have = [None] * n
+    if cache is not None and keys is not None:
+        have = [cache.get(k, len(f), r, seg_bytes) for k, f, r in zip(keys, files, rows)]
+    nsegs = np.asarray([0 if h is None else r for h, r in zip(have, rows)], np.int32)
     ws_bytes = int(lib.objgan_jpeg_plan(descs.ctypes.data_as(ctypes.c_void_p), n,
-                                        foffs.ctypes.data_as(ctypes.c_void_p), ooffs.ctypes.data_as(ctypes.c_void_p)))
+                                        foffs.ctypes.data_as(ctypes.c_void_p), ooffs.ctypes.data_as(ctypes.c_void_p),
+                                        nsegs.ctypes.data_as(ctypes.c_void_p)))
     if ws_bytes <= 0:
         raise _lib.ObjganHipError("objgan_jpeg_plan: bad descriptor")
     host = torch.empty(int(sum(sizes)) + descs.size, dtype=torch.uint8).pin_memory()
@@ -1550,12 +1641,21 @@ def jpeg_decode_batch(files, device):
     dev = host.to(device, non_blocking=True)                          # files + descriptors: one upload
     out = torch.empty(int(sum(osz)), dtype=torch.uint8, device=device)
     work = torch.empty((ws_bytes + 15) // 16 * 16, dtype=torch.uint8, device=device)
+    idx_in = torch.cat([h for h in have if h is not None]) if any(h is not None for h in have) else None
+    want_out = cache is not None and keys is not None and any(h is None for h in have)
+    idx_out = torch.empty(sum(rows) * seg_bytes, dtype=torch.uint8, device=device) if want_out else None
     _lib.call("objgan_jpeg_decode", _p(dev), descs.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(dev.data_ptr() + d0), n,
-              _p(out), _p(work), ws_bytes, _stream())
+              _p(out), _p(work), ws_bytes, _p(idx_in), _p(idx_out), _stream())
+    if want_out:
+        o = 0
+        for k, f, r, h in zip(keys, files, rows, have):
+            if h is None:
+                cache.put(k, len(f), idx_out[o * seg_bytes:(o + r) * seg_bytes])
+            o += r
     return out, ooffs, hs, ws
 
 
-def images_to_device(items, device):
+def images_to_device(items, device, cache=None, keys=None):
     """The `device_jpeg` hand-over of a batch: every item is either a JPEG file (1-D uint8 tensor / bytes: decoded on the
     device) or an image the loader had to decode on the host (uint8 [H, W, 3]: a progressive / CMYK file the device path
     refuses, uploaded as it is) -> (buffer, offs, hs, ws) in the items' order, the form resize_pil_bilinear_device reads."""
@@ -1569,12 +1669,13 @@ def images_to_device(items, device):
     hidx = [i for i, a in enumerate(kinds) if a.ndim == 3]
     if len(jidx) + len(hidx) != len(kinds):
         raise _lib.ObjganHipError("images_to_device: items must be JPEG byte strings (1-D uint8) or uint8 [H, W, 3] images")
+    jkeys = None if keys is None else [keys[i] for i in jidx]
     if not hidx:
-        return jpeg_decode_batch([kinds[i].tobytes() for i in jidx], device)
+        return jpeg_decode_batch([kinds[i].tobytes() for i in jidx], device, cache, jkeys)
     parts, offs, hs, ws = [], [0] * len(kinds), [0] * len(kinds), [0] * len(kinds)
     total = 0
     if jidx:
-        out, jo, jh, jw = jpeg_decode_batch([kinds[i].tobytes() for i in jidx], device)
+        out, jo, jh, jw = jpeg_decode_batch([kinds[i].tobytes() for i in jidx], device, cache, jkeys)
         parts.append(out)
         for k, i in enumerate(jidx):
             offs[i], hs[i], ws[i] = int(jo[k]), jh[k], jw[k]
@@ -1592,9 +1693,9 @@ def images_to_device(items, device):
     return torch.cat(parts), np.asarray(offs, np.int64), hs, ws
 
 
-def jpeg_decode(files, device):
+def jpeg_decode(files, device, cache=None, keys=None):
     """-> list of uint8 [H, W, 3] device tensors (views of one buffer)"""
-    out, offs, hs, ws = jpeg_decode_batch(files, device)
+    out, offs, hs, ws = jpeg_decode_batch(files, device, cache, keys)
     return [out[int(o):int(o) + h * w * 3].view(h, w, 3) for o, h, w in zip(offs, hs, ws)]
 
 

@@ -100,6 +100,15 @@ def hmaps_from_box_masks(bt_masks, rois0, num_classes):
     return out.view(B, num_classes, S, S).to(torch.float32)
 
 
+_JPEG_INDEX = []
+
+
+def _jpeg_index_cache():
+    if not _JPEG_INDEX:
+        _JPEG_INDEX.append(ops.JpegIndexCache() if hasattr(ops, "JpegIndexCache") else None)
+    return _JPEG_INDEX[0]
+
+
 def prepare_data(data, device=None, num_classes=None):
     """Collated loader output -> the reference's 12-item list: every per-sample tensor reordered by
     caption length (descending; `torch.sort` like the reference, so ties fall the same way), maps as
@@ -126,7 +135,9 @@ def prepare_data(data, device=None, num_classes=None):
         picked = [imgs[i] for i in order.tolist()]
         if any(im.dim() == 1 for im in picked):
             # `device_jpeg` hand-over: JPEG files (and the odd host-decoded image) -> decoded on the device -> resized there
-            src, offs, hs, ws = ops.images_to_device(picked, device)
+            # (the entropy index of every file decoded so far lives on the device: from the second epoch on a file is decoded
+            #  by one lane per MCU row instead of one lane per file)
+            src, offs, hs, ws = ops.images_to_device(picked, device, _jpeg_index_cache(), [keys[i] for i in order.tolist()])
             out_imgs = ops.resize_pil_bilinear_device(src, offs, hs, ws, [bt_masks[b].shape[-1] for b in branches])
         else:
             out_imgs = ops.resize_pil_bilinear(picked, [bt_masks[b].shape[-1] for b in branches], device)

@@ -445,6 +445,8 @@ class condGANTrainer(object):
     # The frozen Inception chains (DAMSM image encoder: forward + backward w.r.t. the image; Inception-score monitor:
     # forward) are shape-static and launch-bound: each is captured once into hipGraphs and replayed (objgan_hip.graphs).
     use_graphs = True
+    # fp16x2 run-time guard: every `h2_guard_every` iterations (and on the first) one step is a checked step (0: never)
+    h2_guard_every = 500
 
     def _graphed(self, attr):
         import encoders
@@ -560,8 +562,20 @@ class condGANTrainer(object):
         # weight gradients go straight into the optimizer arenas (ops._grad_sink) for the duration of the step only: under
         # `.backward()` into `.grad`, every arena weight used once per forward.  Anything else (torch.autograd.grad, a
         # weight shared between two uses) keeps autograd's own accumulation.
-        with M.deferred_bn_counters(), ops.direct_wgrad_scope(self.direct_wgrad):
-            return self._train_step(batch, noise, want_logs)
+        guard = (self.h2_guard_every > 0 and self.gen_iterations % self.h2_guard_every == 0
+                 and self.device.type == "cuda" and hasattr(ops, "h2_guard_begin") and ops.get_conv_math() == "fp16x2")
+        if guard:
+            # fp16x2 run-time guard: this step also measures the per-channel spread of every fp16x2 operand whose channels
+            # are GEMM rows / columns; a call site beyond 2^16 runs bf16x3 from now on (ops._H2_GUARD; logged)
+            ops.h2_guard_begin()
+        try:
+            with M.deferred_bn_counters(), ops.direct_wgrad_scope(self.direct_wgrad):
+                return self._train_step(batch, noise, want_logs)
+        finally:
+            if guard:
+                for rec in ops.h2_guard_end():
+                    print("fp16x2 guard, iteration %d: %s (spread 2^%.1f, operand %s) -> bf16x3 from now on"
+                          % (self.gen_iterations, rec[1], rec[2], rec[3]))
 
     def _train_step(self, batch, noise, want_logs):
         b = batch

@@ -162,7 +162,7 @@ def jpeg_parse(files):
     return real_ops.jpeg_parse(files)
 
 
-def images_to_device(items, device):
+def images_to_device(items, device, cache=None, keys=None):
     """CPU definition of the `device_jpeg` hand-over: JPEG files through the numpy oracle (bit for bit Pillow), host-decoded
     images as they are -> (list of uint8 [H, W, 3] arrays, None, heights, widths)"""
     from oracle import jpeg_oracle as J

@@ -41,7 +41,8 @@ def test_jpeg_parse_is_host_only_and_agrees_with_pillow():
     foffs = np.arange(n, dtype=np.int64) * 65536
     ooffs = np.arange(n, dtype=np.int64) * (1 << 20)
     ws = _lib.load().objgan_jpeg_plan(descs.ctypes.data_as(ctypes.c_void_p), n, foffs.ctypes.data_as(ctypes.c_void_p),
-                                       ooffs.ctypes.data_as(ctypes.c_void_p))
+                                       ooffs.ctypes.data_as(ctypes.c_void_p), None)
+    assert _lib.load().objgan_jpeg_seg_bytes() == 48
     blocks = 0
     for h in heads:
         per_mcu = (h[3] * h[4] + 2) if h[2] == 3 else 1

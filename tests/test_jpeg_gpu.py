@@ -36,6 +36,33 @@ def test_device_jpeg_decode_is_bit_exact_with_pillow(dev):
          "optimised tables)" % len(files), "bit-exact")
 
 
+def test_device_jpeg_entropy_index_gives_the_same_bytes(dev):
+    """The first decode of a file (one lane walks the scan) leaves its entropy index -- the decoder state at every MCU-row
+    start -- in the cache on the device; the second decode runs one lane per MCU row from that index.  Same state machine
+    resumed from the same state: bit-identical output, for every sampling, restart intervals included; a batch that mixes
+    indexed and new files works; a stale entry (other file under the same key) is not used."""
+    from objgan_hip import ops
+    cases = jpeg_cases.cases(big=True)
+    files = [d for _, d in cases]
+    keys = ["k%d" % i for i in range(len(files))]
+    cache = ops.JpegIndexCache()
+    first = [o.clone() for o in ops.jpeg_decode(files, dev, cache, keys)]
+    assert cache.misses == len(files) and cache.hits == 0 and len(cache.entries) == len(files)
+    second = ops.jpeg_decode(files, dev, cache, keys)
+    torch.cuda.synchronize()
+    assert cache.hits == len(files)
+    bad = [name for (name, data), a, b in zip(cases, first, second)
+           if not (torch.equal(a, b) and np.array_equal(b.cpu().numpy(), jpeg_cases.pillow(data)))]
+    assert not bad, bad[:8]
+    # mixed batch: half of the files come with their index, the others are new keys
+    keys2 = [k if i % 2 else "new" + k for i, k in enumerate(keys)]
+    third = ops.jpeg_decode(files, dev, cache, keys2)
+    assert all(torch.equal(a, b) for a, b in zip(first, third))
+    # a different file under a cached key: size differs -> the entry is not used (and is replaced)
+    swapped = ops.jpeg_decode([files[3]], dev, cache, [keys[10]])
+    assert np.array_equal(swapped[0].cpu().numpy(), jpeg_cases.pillow(files[3]))
+
+
 def test_device_jpeg_refuses_what_it_does_not_decode(dev):
     from objgan_hip import ops
     good = jpeg_cases.cases(big=False)[0][1]
@@ -98,21 +125,29 @@ def test_device_jpeg_throughput_record(dev):
         buf = io.BytesIO()
         pic.save(buf, "JPEG", quality=90, subsampling=2)
         files.append(buf.getvalue())
+    cache, keys = ops.JpegIndexCache(), list(range(16))
     outs = ops.jpeg_decode(files, dev)                      # warm-up
     torch.cuda.synchronize()
     assert np.array_equal(outs[3].cpu().numpy(), jpeg_cases.pillow(files[3]))
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(3):
-        ops.jpeg_decode(files, dev)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 3
+
+    def timed(reps, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.jpeg_decode(files, dev, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    ms = timed(2)                                           # first touch: one lane per file
+    ops.jpeg_decode(files, dev, cache=cache, keys=keys)     # (leaves the indexes)
+    ms_idx = timed(3, cache=cache, keys=keys)               # every later epoch: one lane per MCU row
+    assert cache.hits == 16 * 3
     import time
     t0 = time.perf_counter()
     for f in files:
         jpeg_cases.pillow(f)
     host_ms = 1000.0 * (time.perf_counter() - t0)
-    note("device JPEG decode, 16 files of 480x640 4:2:0 q90 (%.0f KB each): ms per batch (upload + 3 kernels) / Pillow on one "
-         "host core" % (sum(len(f) for f in files) / 16e3), "%.2f / %.1f" % (ms, host_ms))
-    assert ms < 200.0
+    note("device JPEG decode, 16 files of 480x640 4:2:0 q90 (%.0f KB each): ms per batch first touch (one lane per file) / "
+         "with the entropy index (one lane per MCU row) / Pillow on one host core" % (sum(len(f) for f in files) / 16e3),
+         "%.2f / %.2f / %.1f" % (ms, ms_idx, host_ms))
+    assert ms < 400.0 and ms_idx < ms

@@ -1096,6 +1096,73 @@ def test_fp16x2_per_row_error_follows_the_documented_bound(dev, records):
             assert worst[k_] <= _h2_row_bound(k_), (tag, k_, worst[k_], _h2_row_bound(k_))
 
 
+def test_fp16x2_guard_demotes_a_call_site_whose_channels_drift_apart(dev):
+    """the run-time guard of fp16x2.  One activation channel of x and one filter row of w sit 2^-24 below
+    the rest of their tensors.  Unguarded, the weight-gradient column of that channel and the output channel of that filter
+    row carry the documented ~2^(24 - 38) error (asserted: > 1e-5, i.e. the problem is real).  A checked step
+    (ops.h2_guard_begin / _end, what the trainer runs every `h2_guard_every` iterations) measures the per-channel spread,
+    finds 2^24 > 2^16, demotes exactly these call sites to bf16x3 and logs them; from then on the affected rows are at
+    fp32 level (asserted: <= 1e-4 as the review asks, observed ~3e-7), and an ordinary layer is left alone."""
+    import warnings
+    from conftest import note
+    ops = _ops()
+    N, Cin, H, W, Cout, k = 4, 64, 32, 32, 64, 3
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    gy = torch.randn(N, Cout, H, W, generator=g)
+    x[:, 5] *= 2.0 ** -24
+    w[9] *= 2.0 ** -24
+    w_ok = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    xt, wt = x.double().requires_grad_(), w.double().requires_grad_()
+    yt = torch.nn.functional.conv2d(xt, wt, None, 1, 1)
+    yt.backward(gy.double())
+    wd = w.to(dev).requires_grad_()                 # ONE parameter object: the guard keys a site on the bank's address
+    wd_ok = w_ok.to(dev).requires_grad_()
+
+    def run(weight):
+        weight.grad = None
+        xd = x.to(dev).requires_grad_()
+        yd = ops.conv2d(xd, weight, None, 1, 1, "zeros", False, None)
+        yd.backward(gy.to(dev))
+        torch.cuda.synchronize()
+        return yd.detach().cpu().double(), weight.grad.cpu().double()
+
+    def errs(y, dw):
+        e_row = float((y[:, 9] - yt[:, 9].detach()).norm() / yt[:, 9].detach().norm())          # output channel of the small filter row
+        e_col = float((dw[:, 5] - wt.grad[:, 5]).norm() / wt.grad[:, 5].norm())                # dW column of the small x channel
+        return e_row, e_col
+
+    prev, prev_min = ops.get_conv_math(), ops._H2_MIN_FLOP
+    ops.set_conv_math("fp16x2")
+    ops._H2_MIN_FLOP = 0.0
+    ops.h2_guard_reset()
+    try:
+        before = errs(*run(wd))
+        assert min(before) > 1e-5, before                   # the documented floor: 2^(24 - 38) = 6e-5
+        ops.h2_guard_begin()
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            run(wd)
+            run(wd_ok)
+        new = ops.h2_guard_end()
+        kinds = sorted(r[1] for r in new)
+        assert any("filter rows" in k_ for k_ in kinds) and any("x channels" in k_ for k_ in kinds), kinds
+        assert all(r[2] > 16.0 for r in new)
+        assert sum('fp16x2 guard' in str(c.message) for c in caught) == len(new)
+        after = errs(*run(wd))
+        state = ops.h2_guard_state()
+        note("fp16x2 guard: error of the rows of a channel 2^-24 below its tensor (forward row / dW column), unguarded -> guarded",
+             "%.1e / %.1e -> %.1e / %.1e (%d sites demoted)" % (before + after + (state["demoted_sites"],)))
+        assert max(after) < 1e-4 and max(after) < 3e-6, after
+        # the ordinary layer was checked and left on fp16x2
+        assert not any(site[1] == wd_ok.data_ptr() for site in ops._H2_GUARD["demoted"] if site[0] == "conv")
+    finally:
+        ops.h2_guard_reset()
+        ops.set_conv_math(prev)
+        ops._H2_MIN_FLOP = prev_min
+
+
 @pytest.mark.parametrize("records", [False, True])
 @pytest.mark.parametrize("factor_log2", [-12, -3, -1, 10])
 def test_fp16x2_survives_wrong_maxima(dev, records, factor_log2):
