@@ -130,9 +130,27 @@ def words_loss(img_features, words_emb, labels, cap_lens, class_ids, batch_size,
 
 
 # ################## Loss for G and Ds ##############################
-def patD_loss(netPatD, real_imgs, fake_imgs, conditions):
+# The passes of a discriminator update over the REAL images do not depend on the generator: `*_real` evaluates them on their
+# own (the trainer issues them on the discriminators' side streams while the generator's forward pass runs on the main
+# stream) and the loss takes the result through `real=`.  Same operators in the same per-network order (real, fake, wrong:
+# the BatchNorm running statistics see the same sequence), same arithmetic: the losses are bit-identical either way.
+def patD_real(netPatD, real_imgs):
+    return {"real_features": netPatD(real_imgs)}
+
+
+def shpD_real(netShpD, real_imgs, seg_conditions):
+    s_code = _net(netShpD).encode_seg(seg_conditions)
+    return {"s_code": s_code, "real_features": netShpD(real_imgs, seg_conditions, s_code=s_code)}
+
+
+def objD_real(netObjD, real_imgs, seg_conditions, fm_rois, num_rois):
+    s_code = _net(netObjD).encode_seg(seg_conditions)
+    return {"s_code": s_code, "real_pooled": netObjD(real_imgs, seg_conditions, fm_rois, num_rois, s_code=s_code)}
+
+
+def patD_loss(netPatD, real_imgs, fake_imgs, conditions, real=None):
     net = _net(netPatD)
-    real_features = netPatD(real_imgs)
+    real_features = real["real_features"] if real is not None else netPatD(real_imgs)
     fake_features = netPatD(fake_imgs.detach())
     B = real_features.size(0)
     lam_u, lam_t = cfg.TRAIN.SMOOTH.UNCOND_LAMBDA, cfg.TRAIN.SMOOTH.TXT_LAMBDA
@@ -148,11 +166,12 @@ def patD_loss(netPatD, real_imgs, fake_imgs, conditions):
     return (cond_real + (cond_fake + cond_wrong) / 2.) * lam_t
 
 
-def shpD_loss(netShpD, real_imgs, fake_imgs, seg_conditions, rois, num_rois):
+def shpD_loss(netShpD, real_imgs, fake_imgs, seg_conditions, rois, num_rois, real=None):
     net = _net(netShpD)
     # the encoded layout map is the same tensor in the real and the fake pass: evaluate it once
-    s_code = net.encode_seg(seg_conditions)
-    real_features = netShpD(real_imgs, seg_conditions, s_code=s_code)
+    if real is None:
+        real = shpD_real(netShpD, real_imgs, seg_conditions)
+    s_code, real_features = real["s_code"], real["real_features"]
     fake_features = netShpD(fake_imgs.detach(), seg_conditions, s_code=s_code)
     wrong_seg, valid = permuted_valid_seg(seg_conditions, rois, num_rois)
     errD = _bce(net.UNCOND_DNET(real_features), 1)
@@ -176,10 +195,11 @@ def _obj_conditions(class_table, classes, bt_c_codes, count=None):
 
 
 def objD_loss(netObjD, real_imgs, fake_imgs, seg_conditions, raw_conditions, raw_bt_c_codes,
-              fm_rois, num_rois, is_large_scale=False):
+              fm_rois, num_rois, is_large_scale=False, real=None):
     net = _net(netObjD)
-    s_code = net.encode_seg(seg_conditions)      # shared by the real and the fake pass
-    real_pooled = netObjD(real_imgs, seg_conditions, fm_rois, num_rois, s_code=s_code)
+    if real is None:
+        real = objD_real(netObjD, real_imgs, seg_conditions, fm_rois, num_rois)
+    s_code, real_pooled = real["s_code"], real["real_pooled"]      # (the encoded layout: shared by the real and the fake pass)
     real_features, classes, bt_c_codes = feat_select(real_pooled, raw_bt_c_codes, fm_rois, num_rois,
                                                      is_large_scale=is_large_scale)
     fake_pooled = netObjD(fake_imgs.detach(), seg_conditions, fm_rois, num_rois, s_code=s_code)

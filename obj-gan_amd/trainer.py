@@ -31,7 +31,7 @@ import torch.nn as nn
 from miscc.config import cfg
 from miscc.utils import (mkdir_p, weights_init, form_clabels_feat, _host, compute_inception_score,
                          negative_log_posterior_probability)
-from miscc.losses import patD_loss, shpD_loss, objD_loss, G_loss, KL_loss
+from miscc.losses import patD_loss, shpD_loss, objD_loss, G_loss, KL_loss, patD_real, shpD_real, objD_real
 import model as M
 from model import (G_NET, PAT_D_NET64, PAT_D_NET128, PAT_D_NET256, SHP_D_NET64, SHP_D_NET128,
                    SHP_D_NET256, OBJ_SS_D_NET, OBJ_LS_D_NET)
@@ -445,6 +445,8 @@ class condGANTrainer(object):
     # The frozen Inception chains (DAMSM image encoder: forward + backward w.r.t. the image; Inception-score monitor:
     # forward) are shape-static and launch-bound: each is captured once into hipGraphs and replayed (objgan_hip.graphs).
     use_graphs = True
+    # the discriminators' real-image passes run on the side streams beside the generator's forward pass (train_step (1b))
+    hoist_real_passes = os.environ.get("OBJGAN_HOIST_REAL", "1") != "0"
     # fp16x2 run-time guard: every `h2_guard_every` iterations (and on the first) one step is a checked step (0: never)
     h2_guard_every = 500
 
@@ -603,6 +605,41 @@ class condGANTrainer(object):
         out = {}
 
         clabels_feat = form_clabels_feat(clabels_emb, rois[0], num_rois)
+        # (1b) The discriminators' passes over the REAL images do not depend on the generator: they are issued now, each on
+        # the side stream its update will run on, and execute while the generator's forward pass (one long chain on the main
+        # stream, many of its launches too small to fill 256 CUs) is running.  Every network still sees real -> fake -> wrong
+        # in that order on ONE stream (BatchNorm running statistics included); the python RNG is not touched here.
+        side = self._d_side_streams()
+        main = torch.cuda.current_stream() if side else None
+        smap = self._stream_map_from_env() or self.d_stream_map or {}
+        if isinstance(smap, (list, tuple)):             # (older callers: positional list in job order)
+            smap = dict(zip(self._D_JOB_NAMES, smap))
+        job_names = ["errPatD%d" % i for i in range(len(self.optimizersPatD))] + \
+                    ["errShpD%d" % i for i in range(len(self.optimizersShpD))] + \
+                    (["errObjSSD", "errObjLSD"] if self.use_obj else [])
+        stream_of, rr = {}, 0
+        for name in job_names:
+            if name in smap:
+                stream_of[name] = smap[name]
+            else:
+                stream_of[name], rr = rr, rr + 1
+        pre = {}
+        if side and self.hoist_real_passes:
+            for s_ in side:
+                s_.wait_stream(main)
+            real_fns = [("errPatD%d" % i, opt, lambda i=i: patD_real(self.netsPatD[i], imgs[i]))
+                        for i, opt in enumerate(self.optimizersPatD)] + \
+                       [("errShpD%d" % i, opt, lambda i=i: shpD_real(self.netsShpD[i], imgs[i], hmaps[i]))
+                        for i, opt in enumerate(self.optimizersShpD)]
+            if self.use_obj:
+                real_fns += [("errObjSSD", self.optimizerObjSSD,
+                              lambda: objD_real(self.netObjSSD, imgs[-1], hmaps[-1], rois[0], num_rois)),
+                             ("errObjLSD", self.optimizerObjLSD,
+                              lambda: objD_real(self.netObjLSD, imgs[-1], hmaps[-1], fm_rois, num_rois))]
+            for name, opt, fn in real_fns:
+                with torch.cuda.stream(side[stream_of[name] % len(side)]):
+                    opt.zero_grad()
+                    pre[name] = fn()
         # (2) generate fake images
         if noise is None:
             self.noise.normal_(0, 1)
@@ -619,19 +656,20 @@ class condGANTrainer(object):
         jobs = []
         for i, opt in enumerate(self.optimizersPatD):
             jobs.append(("errPatD%d" % i, opt,
-                         lambda i=i: patD_loss(self.netsPatD[i], imgs[i], fake_imgs[i], sent_emb)))
+                         lambda real=None, i=i: patD_loss(self.netsPatD[i], imgs[i], fake_imgs[i], sent_emb, real=real)))
         for i, opt in enumerate(self.optimizersShpD):
             jobs.append(("errShpD%d" % i, opt,
-                         lambda i=i: shpD_loss(self.netsShpD[i], imgs[i], fake_imgs[i], hmaps[i], rois[i], num_rois)))
+                         lambda real=None, i=i: shpD_loss(self.netsShpD[i], imgs[i], fake_imgs[i], hmaps[i], rois[i], num_rois,
+                                                          real=real)))
         # the reference updates an object discriminator only `if float(err) > 0`, i.e. when at least one
         # box of the wanted scale exists (BCE of a sigmoid is > 0 otherwise)
         obj_jobs = (("errObjSSD", self.netObjSSD, self.optimizerObjSSD, rois[0], False),
                     ("errObjLSD", self.netObjLSD, self.optimizerObjLSD, fm_rois, True)) if self.use_obj else ()
         for name, net, opt, r, large in obj_jobs:
             jobs.append((name, opt,
-                         lambda net=net, r=r, large=large: objD_loss(net, imgs[-1], fake_imgs[-1], hmaps[-1],
-                                                                     clabels_emb, bt_c_codes[-1], r, num_rois,
-                                                                     is_large_scale=large)))
+                         lambda real=None, net=net, r=r, large=large: objD_loss(net, imgs[-1], fake_imgs[-1], hmaps[-1],
+                                                                                clabels_emb, bt_c_codes[-1], r, num_rois,
+                                                                                is_large_scale=large, real=real)))
         # The eight discriminator updates read the same fake images and touch disjoint networks: they are spread
         # round-robin over `d_streams` HIP streams so that the many launches that do not fill 256 CUs on their own
         # (discriminator heads on 4x4 .. 16x16 maps, normalisation / combine kernels of small layers) overlap with
@@ -643,23 +681,14 @@ class condGANTrainer(object):
             by_name = dict((j[0], j) for j in jobs)
             jobs = [by_name[n] for n in resolve_d_job_order([j[0] for j in jobs], order)]
         pending = []
-        side = self._d_side_streams()
-        main = torch.cuda.current_stream() if side else None
         for s_ in side:
             s_.wait_stream(main)
-        smap = self._stream_map_from_env() or self.d_stream_map or {}
-        if isinstance(smap, (list, tuple)):             # (older callers: positional list in job order)
-            smap = dict(zip(self._D_JOB_NAMES, smap))
-        rr = 0
         for j, (name, opt, loss_fn) in enumerate(jobs):
-            if name in smap:
-                sidx = smap[name]
-            else:
-                sidx, rr = rr, rr + 1
-            ctx = torch.cuda.stream(side[sidx % len(side)]) if side else _NullCtx()
+            ctx = torch.cuda.stream(side[stream_of[name] % len(side)]) if side else _NullCtx()
             with ctx:
-                opt.zero_grad()
-                err = loss_fn()
+                if name not in pre:
+                    opt.zero_grad()
+                err = loss_fn(pre.get(name))
                 active = torch.is_tensor(err)
                 if active:
                     err.backward()
