@@ -79,6 +79,18 @@ def cat_names(math):
 PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
+def csrc_hash():
+    """sha256 (16 hex digits) over obj-gan_amd/csrc/*.hip, *.h: the key of the committed counter passes (tools/pmc_traffic.py)"""
+    import hashlib
+    root = os.path.join(ROOT, "obj-gan_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_lookup(kernels, name):
     """HBM bytes per launch of a timing category from the committed counter passes: the category name is the kernel
     instance's, or (weight-gradient kernels: the 16-byte and the dword gather form report into one category) a pattern
@@ -632,12 +644,19 @@ def main():
     host = None
     if not args.no_kernel_timing:
         barrier()
+        tr.phase_events = []
         t0 = time.perf_counter()
         step()
         t1 = time.perf_counter()
         barrier()
         t2 = time.perf_counter()
         host = {"issue_ms": round(1000.0 * (t1 - t0), 2), "device_drain_ms": round(1000.0 * (t2 - t1), 2)}
+        try:        # where the main stream was at the phase boundaries of this one step (the side streams' work sits inside)
+            ev = tr.phase_events
+            host["main_stream_phases_ms"] = {ev[i + 1][0]: round(ev[i][1].elapsed_time(ev[i + 1][1]), 2) for i in range(len(ev) - 1)}
+        except Exception:                                       # noqa: BLE001 (CPU shim of the host tests)
+            pass
+        tr.phase_events = None
     if timing and args.shape_table:
         _write_shape_table(lib, args.shape_table, prof_steps)
     if use_dist:
@@ -694,10 +713,14 @@ def main():
                 if os.path.exists(PMC_TRAFFIC_JSON):
                     try:
                         pmc = json.load(open(PMC_TRAFFIC_JSON))
+                        # the counters answer for the run AND the kernel sources they were collected on
+                        here = csrc_hash()
                         same = (pmc.get("conv_math") == args.math and pmc.get("per_gpu_batch") == args.batch
-                                and args.workload == "stage3_obj")       # the run the counters were collected on
+                                and args.workload == "stage3_obj" and pmc.get("csrc_sha16") == here)
                         traffic = pmc_lookup(pmc.get("kernels", {}), name) if same else None
-                        traffic_source = "profiles/pmc_traffic.json (%s)" % pmc.get("source", "committed rocprofv3 --pmc passes")
+                        traffic_source = "profiles/pmc_traffic.json (%s; collected on csrc %s, this tree is %s%s)" % (
+                            pmc.get("source", "committed rocprofv3 --pmc passes"), pmc.get("csrc_sha16"), here,
+                            "" if pmc.get("csrc_sha16") == here else ": kernels changed since, traffic withheld")
                     except (ValueError, KeyError, OSError):
                         traffic = None
                 peak = {"fp32": FP32_MFMA_PEAK_TFLOPS, "bf16": BF16_MFMA_PEAK_TFLOPS,

@@ -703,6 +703,41 @@ def _conv_dgrad(g, w, N, Cin, H, W, stride, pad, refl, upsample, cacheable=True)
     return dxl
 
 
+# Weight gradients beside the data-gradient chain (round 6).  A backward pass is a serial chain of data gradients -- each
+# layer's needs the next layer's -- interleaved with normalisation / activation derivatives that do not fill 256 CUs; the
+# weight gradient of a layer feeds nothing but the optimizer.  Inside `wgrad_stream_scope(side)` (the trainer: around the
+# generator's backward pass, the one phase of the step that runs on a single stream) a weight gradient that goes straight
+# into its arena (`sink`) is LAUNCHED ON `side` behind an event of the issuing stream, and the issuing stream goes on with
+# the data gradient; whoever reads the gradient arena next (ArenaAdam.step, an all-reduce) calls `wgrad_join()` first.
+# Scale inputs / records are produced (or found in the per-stream caches) on the issuing stream BEFORE the hand-over, the
+# split workspace is allocated under `side`, and every tensor the launch reads is recorded on `side` for the caching
+# allocator.  Same kernels, same arguments: bit-identical gradients.
+_WG_ASYNC = {"stream": None, "pending": []}
+
+
+class wgrad_stream_scope(object):
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        self.prev = _WG_ASYNC["stream"]
+        _WG_ASYNC["stream"] = self.stream
+        return self
+
+    def __exit__(self, *exc):
+        _WG_ASYNC["stream"] = self.prev
+        return False
+
+
+def wgrad_join():
+    """the current stream waits for every weight gradient that was handed to a side stream"""
+    if _WG_ASYNC["pending"]:
+        cur = torch.cuda.current_stream()
+        for st in _WG_ASYNC["pending"]:
+            cur.wait_stream(st)
+        del _WG_ASYNC["pending"][:]
+
+
 def _conv_wgrad(x, g, Cout, k, stride, pad, refl, upsample, sink=None):
     """Gradient w.r.t. the filter bank [Cout, Cin, k, k] of conv(x, w) given g = dL/d(conv output).
     sink: the weight's (gradient view, notify) pair from its optimizer arena (`_grad_sink`): the ordered combine of the
@@ -718,8 +753,6 @@ def _conv_wgrad(x, g, Cout, k, stride, pad, refl, upsample, sink=None):
     if math == 4 and _demoted(site):
         math = 2                              # fp16x2 guard: x / dy channels too far apart for one scale per tensor
     geo = (N, Cin, H, W, int(upsample), refl, Cout, g.shape[2], g.shape[3], k, stride, pad, math)
-    nws = _q("objgan_conv_wgrad_ws_floats", *geo)
-    ws = torch.empty(nws, dtype=_F32, device=x.device) if nws > 0 else None
     xmax, gmax = (_absmax(x), _absmax(g)) if math == 4 else (None, None)
     if math == 4 and _H2_CENSUS is not None:
         _census("weight gradient: x channels (filter columns)", x, 1, site)
@@ -738,9 +771,24 @@ def _conv_wgrad(x, g, Cout, k, stride, pad, refl, upsample, sink=None):
         rec = _records(x, xmax, N, Cin, H * W, 2.0 * Cout * k * k * g.shape[2] * g.shape[3] / float(H * W), Cout)
         if rec is not None:
             geo = geo[:-1] + (5,)
-            nws = _q("objgan_conv_wgrad_ws_floats", *geo)
-            ws = torch.empty(nws, dtype=_F32, device=x.device) if nws > 0 else None
             xk = rec
+    nws = _q("objgan_conv_wgrad_ws_floats", *geo)
+    side = _WG_ASYNC["stream"] if (sink is not None and _H2_CENSUS is None) else None
+    if side is not None:
+        # hand the launch to the side stream: everything it reads exists on the issuing stream by now
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)
+        for t in (xk, g, xmax, gmax):
+            if t is not None:
+                t.record_stream(side)
+        with torch.cuda.stream(side):
+            ws = torch.empty(nws, dtype=_F32, device=x.device) if nws > 0 else None
+            _lib.call("objgan_conv_wgrad", _p(xk), _p(g), _p(dw_), *geo, 1, _p(xmax), _p(gmax), _p(ws), nws, _stream())
+        if side not in _WG_ASYNC["pending"]:
+            _WG_ASYNC["pending"].append(side)
+        sink[1]()
+        return None
+    ws = torch.empty(nws, dtype=_F32, device=x.device) if nws > 0 else None
     _lib.call("objgan_conv_wgrad", _p(xk), _p(g), _p(dw_), *geo, 0 if sink is None else 1, _p(xmax), _p(gmax), _p(ws), nws,
               _stream())
     if sink is not None:
@@ -834,10 +882,10 @@ class _Conv2dFn(torch.autograd.Function):
         else:
             g = dy
         dx = dw_ = db = None
+        if ctx.needs_input_grad[1]:             # (first: inside wgrad_stream_scope it leaves for a side stream at once)
+            dw_ = _conv_wgrad(x, g, Cout, k, stride, pad, refl, upsample, sink=_grad_sink(w, (Cout, Cin, k, k)))
         if ctx.needs_input_grad[0]:
             dx = _conv_dgrad(g, w, N, Cin, H, W, stride, pad, refl, upsample)
-        if ctx.needs_input_grad[1]:
-            dw_ = _conv_wgrad(x, g, Cout, k, stride, pad, refl, upsample, sink=_grad_sink(w, (Cout, Cin, k, k)))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(Cout, dtype=_F32, device=x.device)
             _channel_sum(g, db, N, Cout, g.shape[2] * g.shape[3])

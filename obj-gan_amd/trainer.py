@@ -201,6 +201,8 @@ class ArenaAdam(object):
         device, with the step counter on the device too: no host sync (reference trainer.py:429,440
         tests `float(err) > 0` on the host)."""
         a = self.arena
+        if hasattr(ops, "wgrad_join"):
+            ops.wgrad_join()                    # weight gradients that were handed to a side stream (ops.wgrad_stream_scope)
         a.sync_grads()
         a.epoch[0] += 1
         lr = self.param_groups[0]["lr"]
@@ -465,6 +467,27 @@ class condGANTrainer(object):
             got = cache[attr] = (enc, graphs.GraphedCallable(fn, version=ver, name=attr))
         return got[1]
 
+    # weight gradients of the generator's backward pass on a side stream (OBJGAN_ASYNC_WGRAD=0: on the issuing stream)
+    async_wgrad = os.environ.get("OBJGAN_ASYNC_WGRAD", "1") != "0"
+
+    def _wgrad_side_stream(self):
+        if (not self.async_wgrad or self.device.type != "cuda" or int(self.d_streams) <= 1 or not self.direct_wgrad
+                or not hasattr(ops, "wgrad_stream_scope")):
+            return None
+        st = getattr(self, "_wg_stream", None)
+        if st is None:
+            st = self._wg_stream = torch.cuda.Stream(device=self.device)
+        return st
+
+    # phase marks of a step on the main stream (measurement aid, off unless `phase_events` is a list: bench.py's host probe)
+    phase_events = None
+
+    def _phase(self, name):
+        if self.phase_events is not None and self.device.type == "cuda":
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.phase_events.append((name, ev))
+
     def _d_optimizers(self):
         return self.optimizersPatD + self.optimizersShpD + [self.optimizerObjSSD, self.optimizerObjLSD]
 
@@ -640,6 +663,7 @@ class condGANTrainer(object):
                 with torch.cuda.stream(side[stream_of[name] % len(side)]):
                     opt.zero_grad()
                     pre[name] = fn()
+        self._phase("start")
         # (2) generate fake images
         if noise is None:
             self.noise.normal_(0, 1)
@@ -648,6 +672,7 @@ class condGANTrainer(object):
         fake_imgs, bt_c_codes, _, _, mu, logvar = self.netG(
             noise, sent_emb, words_embs, glove_words_embs, clabels_feat, mask, hmaps, rois,
             fm_rois, num_rois, b["bt_masks"], b["fm_bt_masks"], glb_max_num_roi)
+        self._phase("g_forward")
         bt_c_codes = [c.detach() for c in bt_c_codes]
 
         # (3) the eight discriminator updates (reference trainer.py:398-443).  They are independent of
@@ -712,6 +737,7 @@ class condGANTrainer(object):
 
         if self.debug_after_d_updates is not None:      # (tests: e.g. put the oracle's updated discriminators in place)
             self.debug_after_d_updates(self)
+        self._phase("d_updates")
         # (4) generator: maximise log(D(G(z))) + DAMSM + KL, discriminators frozen
         d_opts = self._d_optimizers()
         for opt in d_opts:
@@ -731,10 +757,20 @@ class condGANTrainer(object):
         g_arena, handles = self.optimizerG.arena, []
         if self.ddp:
             def reduce_range(s0, e0):
+                if hasattr(ops, "wgrad_join"):
+                    ops.wgrad_join()            # (the bucket's weight gradients may still be running on the side stream)
                 self._comm_note(g_arena.grad[s0:e0])
                 handles.append(dist.all_reduce(g_arena.grad[s0:e0], op=dist.ReduceOp.SUM, async_op=True))
             g_arena.arm(reduce_range)
-        errG_total.backward()
+        self._phase("g_loss_forward")
+        wg_stream = self._wgrad_side_stream()
+        if wg_stream is not None:
+            # the generator's backward pass is the one phase on a single stream: its weight gradients leave for a side
+            # stream and the data-gradient chain goes on (ops.wgrad_stream_scope); ArenaAdam.step / the all-reduce join
+            with ops.wgrad_stream_scope(wg_stream):
+                errG_total.backward()
+        else:
+            errG_total.backward()
         for opt in d_opts:
             opt.arena.set_requires_grad(True)
         if self.ddp:
@@ -744,6 +780,7 @@ class condGANTrainer(object):
             self.g_buckets = (during, len(handles) - during)     # issued inside backward / after it
             for h in handles:
                 self._wait(h)
+        self._phase("g_backward")
         self.optimizerG.step(grad_scale=inv_world)
         ops.ema_update_(self.avg_param_G, self.optimizerG.arena.flat, 0.999)
         out["errG"] = errG_total.detach()
@@ -752,6 +789,7 @@ class condGANTrainer(object):
         if want_logs:
             out["G_logs"] = G_logs
 
+        self._phase("g_update")
         # (5) Inception-score monitor on a side stream (no data dependence on the update)
         if self.inception_model is not None:
             img = out["fake_imgs"][-1]

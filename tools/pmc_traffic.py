@@ -29,6 +29,20 @@ def load(dirglob, counter):
     return agg
 
 
+def csrc_hash():
+    """sha256 over the kernel sources the counters were collected on (bench.py prints it in `traffic_source` and drops the
+    traffic figure when the tree's hash differs: VERDICT r5 item 9)"""
+    import hashlib
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "obj-gan_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main(prefix, out):
     cal_f = load(prefix + "_pmc_cal_fetch/**/*counter_collection.csv", "FETCH_SIZE")
     cal_w = load(prefix + "_pmc_cal_write/**/*counter_collection.csv", "WRITE_SIZE")
@@ -53,6 +67,7 @@ def main(prefix, out):
         kernels[name] = {"launches": max(nf, nw), "fetch_bytes_per_launch": round(fb),
                          "write_bytes_per_launch": round(wb), "hbm_bytes_per_launch": round(fb + wb)}
     json.dump({"conv_math": "fp16x2", "per_gpu_batch": 16,      # the bench defaults tools/pmc_bench.sh runs
+               "csrc_sha16": csrc_hash(),
                "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py "
                          "(tools/pmc_bench.sh)",
                "calibration": {"known_bytes": KNOWN, "fetch_factor_stream_b128": f_stream,
