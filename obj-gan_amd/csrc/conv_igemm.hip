@@ -42,7 +42,8 @@ static void og_absmax_launch(const float* x, long n, float* out, hipStream_t s);
 
 // conv_igemm_rec.hip: the instances of conv_igemm3_kernel that read pre-split fp16 records (math 5)
 int og_launch_igemm3_rec(const IgemmArgs& a, int TM, int nw, int ng, dim3 grid, hipStream_t s);
-int og_launch_wgrad_rec(const WgradArgs& a, int tm, int nw, dim3 grid, int ksize, int Cp, hipStream_t s);
+int og_launch_wgrad_rec(const WgradArgs& a, int tm, int nw, dim3 grid, int ksize, int Cp, int dyp, hipStream_t s);
+void og_launch_h2_pair(const float* x, const float* xmax, float* out, long n, hipStream_t s);
 
 template <int WM, int TM>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
@@ -2867,12 +2868,15 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
     long ws_used = 0;
     if (plan_only) *ws_need = 0;
     if (ksize != 1 && ksize != 3 && ksize != 4) return OG_BAD_ARGS;
-    if (math < 0 || math > 5 || math == 3) return OG_BAD_ARGS;
+    if (math < 0 || math > 6 || math == 3) return OG_BAD_ARGS;
     if (math >= 4 && !plan_only && (!xmax || !dymax)) return OG_BAD_ARGS;
     if (N <= 0 || Cout <= 0 || Cin <= 0) return OG_OK;
     // math 5: x is the fp16 record of the source (conv_igemm_rec.hip), dy the fp32 tensor: conv_wgrad_rec_kernel.  The
     // caller asks objgan_conv_wgrad_rec_ok first; a geometry the record kernel does not take is an argument error here.
-    const bool rec = math == 5;
+    // math 6 (round 6): the same with dy pre-split too -- its fp16 pair is written into the workspace by one pass
+    // (h2_pair_kernel) and the kernel's K loop carries no operand split at all.
+    const bool rec = math == 5 || math == 6;
+    const bool dyp = math == 6;
     if (rec && !og_wgrad_rec_geometry(N, Cin, H, W, Cout, OH, OW, ksize)) return OG_BAD_ARGS;
     // fp16x2 lives in the register-fragment kernel; launches that plan the LDS-staged / first-generation kernels run
     // bf16x3 (both are fp32-result arithmetics)
@@ -2917,6 +2921,16 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
                 xb = reinterpret_cast<const __bf16*>(ws);
                 dyb = reinterpret_cast<const __bf16*>(ws + xb_floats);
                 ws_used = xb_floats + dyb_floats;
+            }
+        }
+        if (dyp) {                                         // the fp16 pair of dy: N * Cout * OHW floats' worth of workspace
+            const long dyp_floats = ((long)N * Cout * OHW + 3) & ~3L;
+            if (plan_only) { *ws_need += dyp_floats; }
+            else {
+                if (!ws || ws_floats < dyp_floats) return OG_BAD_ARGS;
+                og_launch_h2_pair(dy, dymax, ws, (long)N * Cout * OHW, s);
+                a.dy = ws;
+                ws_used = dyp_floats;
             }
         }
         int groups = og_cdiv(Cout, 32);
@@ -3030,7 +3044,7 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
                     else if (use3) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv>), grid, dim3(256), 0, s, a, ksize); \
                     else hipLaunchKernelGGL((conv_wgrad2_kernel<TMv>), grid, dim3(256), 0, s, a, ksize);
             if (rec) {
-                const int rc_ = og_launch_wgrad_rec(a, tm, nw, grid, ksize, Cpb, s);
+                const int rc_ = og_launch_wgrad_rec(a, tm, nw, grid, ksize, Cpb, dyp ? 1 : 0, s);
                 if (rc_ != OG_OK) { prof_end(pr, s); return rc_; }
             } else if (bfb) {
 #define OG_WGB(TMv) if (nw == 8) hipLaunchKernelGGL((conv_wgrad_bfb_kernel<(TMv <= 6 ? TMv : 6), 8>), grid, dim3(512), 0, s, a, xb, dyb, ksize, Cpb); \

@@ -143,7 +143,12 @@ int og_launch_igemm3_rec(const IgemmArgs& a, int TM, int nw, int ng, dim3 grid, 
 // [h 32 px | l 32 px], 144-byte pitch).  Products and their order per 16-pixel step as conv_wgrad3_kernel<.., 4>:
 // al.bh, ah.bh, ah.bl with fp32 accumulation; scales undone in the epilogue.
 // Requires OH * OW % 32 == 0, OH, OW <= 256, (H - 1) * W < 65535, k <= 4 (og_wgrad asks objgan_conv_wgrad_rec_ok).
-template <int TM, int NW>
+// DYP (round 6): dy ALSO arrives pre-split -- a.dy is the fp16 pair of the tensor in its own NCHW layout, plane h
+// followed by plane l (h2_pair_kernel below, same scale and the same two conversions as the loader's split) -- and
+// the loader threads copy 16-byte pieces (8 pixels of one plane) straight into the same LDS row image: no operand split is
+// left in the K loop (the PMC passes of round 5 charged 9.5 VALU instructions per MFMA to the in-loop splits of both
+// operands, profiles/r05_pmc_objd_l3_fp16x2.txt).  Same pieces, same products, same order: bit-identical to DYP = false.
+template <int TM, int NW, bool DYP = false>
 __global__ __launch_bounds__(64 * NW) void conv_wgrad_rec_kernel(const WgradArgs a, const int KS, const int Cp) {
     constexpr int NT = 64 * NW;
     constexpr int BM = 32 * TM;
@@ -195,7 +200,8 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_rec_kernel(const WgradArgs
     __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
         (void*)a.x, 0, (int)((unsigned)a.N * (unsigned)Cc * (unsigned)HW * 64u), OG_BUF_FLAGS);
     __amdgpu_buffer_rsrc_t dyres = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.dy, 0, (int)((unsigned)a.N * a.Cout * OHW * 4u), OG_BUF_FLAGS);
+        (void*)a.dy, 0, (int)((unsigned)a.N * a.Cout * OHW * 4u), OG_BUF_FLAGS);      // (DYP: two fp16 planes, the same bytes)
+    const unsigned dy_plane = (unsigned)a.N * (unsigned)a.Cout * (unsigned)OHW * 2u;  // bytes of one fp16 plane
 
     og_fp16_saturate();
     const int sx = og_h2_exponent(a.xmax, lane), sd = og_h2_exponent(a.dymax, lane);
@@ -277,14 +283,19 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_rec_kernel(const WgradArgs
         const int idx = tid + NT * i;
         const int row = idx >> 3, q = idx & 7;
         const bool on = (NA4 % NT == 0 || idx < NA4) && (m0 + row) < a.m_end;
-        avoff[i] = on ? ((unsigned)(m0 + row) * (unsigned)OHW + q * 4u) * 4u : OG_OOB;
-        alds[i] = (NA4 % NT == 0 || idx < NA4) ? row * ALD + q * 2 : -1;
+        if (DYP) {          // piece q < 4: pixels 8 q .. 8 q + 7 of plane h; q >= 4: the same of plane l -> LDS row image [h | l]
+            avoff[i] = on ? ((unsigned)(m0 + row) * (unsigned)OHW + (q & 3) * 8u) * 2u + (q >> 2) * dy_plane : OG_OOB;
+            alds[i] = (NA4 % NT == 0 || idx < NA4) ? row * ALD + q * 4 : -1;
+        } else {
+            avoff[i] = on ? ((unsigned)(m0 + row) * (unsigned)OHW + q * 4u) * 4u : OG_OOB;
+            alds[i] = (NA4 % NT == 0 || idx < NA4) ? row * ALD + q * 2 : -1;
+        }
     }
     int n_ld = p_begin / OHW;                        // scalar (image, offset) of the next dy iteration
     int rem_ld = p_begin - n_ld * OHW;
     f32x4 ra[NA_PER];
     auto load_a = [&]() {
-        const int so = (n_ld * a.Cout * OHW + rem_ld) * 4;
+        const int so = (n_ld * a.Cout * OHW + rem_ld) * (DYP ? 2 : 4);
         rem_ld += BK;
         if (rem_ld >= OHW) { rem_ld = 0; n_ld += 1; }
 #pragma unroll
@@ -294,6 +305,12 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_rec_kernel(const WgradArgs
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     auto store_a = [&](int buf) {
         float* As = ldsA + buf * ATILE;
+        if (DYP) {
+#pragma unroll
+            for (int i = 0; i < NA_PER; ++i)
+                if (NA4 % NT == 0 || alds[i] >= 0) *reinterpret_cast<f32x4*>(As + alds[i]) = ra[i];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NA_PER; ++i) {
             f16x4 h, l;
@@ -382,9 +399,39 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_rec_kernel(const WgradArgs
 }
 
 // launch of the record-reading weight gradient (called by og_wgrad in conv_igemm.hip)
-int og_launch_wgrad_rec(const WgradArgs& a, int tm, int nw, dim3 grid, int ksize, int Cp, hipStream_t s) {
+// fp32 -> its fp16 pair under the tensor's scale, same layout, plane h followed by plane l (n4 = elements / 4): the dy
+// operand of conv_wgrad_rec_kernel<.., true>
+__global__ __launch_bounds__(256) void h2_pair_kernel(const float* __restrict__ x, const float* __restrict__ xmax,
+                                                      _Float16* __restrict__ out, long n4) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    og_fp16_saturate();
+    const float xs = og_pow2(og_h2_exponent(xmax, threadIdx.x & 63));
+    _Float16* ol = out + 4 * n4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+        f16x4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float sv = v[j] * xs;
+            h[j] = (_Float16)sv;
+            l[j] = (_Float16)og_sub(sv, (float)h[j]);
+        }
+        *reinterpret_cast<f16x4*>(out + 4 * i) = h;
+        *reinterpret_cast<f16x4*>(ol + 4 * i) = l;
+    }
+}
+
+void og_launch_h2_pair(const float* x, const float* xmax, float* out, long n, hipStream_t s) {
+    const long n4 = n / 4;
+    hipLaunchKernelGGL(h2_pair_kernel, dim3(og_stream_grid(n4, 256)), dim3(256), 0, s, x, xmax,
+                       reinterpret_cast<_Float16*>(out), n4);
+}
+
+int og_launch_wgrad_rec(const WgradArgs& a, int tm, int nw, dim3 grid, int ksize, int Cp, int dyp, hipStream_t s) {
 #define OG_WGR(TMv)                                                                                                   \
-        if (nw == 8) hipLaunchKernelGGL((conv_wgrad_rec_kernel<(TMv <= 6 ? TMv : 6), 8>), grid, dim3(512), 0, s, a, ksize, Cp); \
+        if (dyp && nw == 8) hipLaunchKernelGGL((conv_wgrad_rec_kernel<(TMv <= 6 ? TMv : 6), 8, true>), grid, dim3(512), 0, s, a, ksize, Cp); \
+        else if (dyp) hipLaunchKernelGGL((conv_wgrad_rec_kernel<TMv, 4, true>), grid, dim3(256), 0, s, a, ksize, Cp); \
+        else if (nw == 8) hipLaunchKernelGGL((conv_wgrad_rec_kernel<(TMv <= 6 ? TMv : 6), 8>), grid, dim3(512), 0, s, a, ksize, Cp); \
         else hipLaunchKernelGGL((conv_wgrad_rec_kernel<TMv, 4>), grid, dim3(256), 0, s, a, ksize, Cp);
     if (nw == 8 && tm > 6) return OG_BAD_ARGS;
     switch (tm) {

@@ -229,6 +229,7 @@ _REC = {"on": _os.environ.get("OBJGAN_H2_RECORDS", "1") != "0",
         # through it.
         # the weight gradient reads x through its record where that pays ("all": wherever the geometry allows; "0": never)
         "wgrad": {"0": False, "all": "all"}.get(_os.environ.get("OBJGAN_REC_WGRAD", "1"), True),
+        "wgrad_math": 5 if _os.environ.get("OBJGAN_REC_WGRAD_DYP", "1") == "0" else 6,
         "min_i": float(_os.environ.get("OBJGAN_REC_MIN_I", "2500")),
         "min_i_short": float(_os.environ.get("OBJGAN_REC_MIN_I_SHORT", "1200"))}
 
@@ -770,7 +771,7 @@ def _conv_wgrad(x, g, Cout, k, stride, pad, refl, upsample, sink=None):
         # transposing LDS reads instead of 32-plane gathers and the split on the VALU
         rec = _records(x, xmax, N, Cin, H * W, 2.0 * Cout * k * k * g.shape[2] * g.shape[3] / float(H * W), Cout)
         if rec is not None:
-            geo = geo[:-1] + (5,)
+            geo = geo[:-1] + (_REC["wgrad_math"],)      # 6: dy pre-split too (its fp16 pair, one pass into the workspace); 5: split in the loop
             xk = rec
     nws = _q("objgan_conv_wgrad_ws_floats", *geo)
     side = _WG_ASYNC["stream"] if (sink is not None and _H2_CENSUS is None) else None

@@ -470,13 +470,16 @@ class condGANTrainer(object):
     # weight gradients of the generator's backward pass on a side stream (OBJGAN_ASYNC_WGRAD=0: on the issuing stream)
     async_wgrad = os.environ.get("OBJGAN_ASYNC_WGRAD", "1") != "0"
 
-    def _wgrad_side_stream(self):
+    async_wgrad_d = os.environ.get("OBJGAN_ASYNC_WGRAD_D", "0") == "1"     # the same inside the discriminator updates (A/B: see LAB)
+
+    def _wgrad_side_stream(self, k=0):
         if (not self.async_wgrad or self.device.type != "cuda" or int(self.d_streams) <= 1 or not self.direct_wgrad
                 or not hasattr(ops, "wgrad_stream_scope")):
             return None
-        st = getattr(self, "_wg_stream", None)
+        pool = self.__dict__.setdefault("_wg_streams", {})
+        st = pool.get(k)
         if st is None:
-            st = self._wg_stream = torch.cuda.Stream(device=self.device)
+            st = pool[k] = torch.cuda.Stream(device=self.device)
         return st
 
     # phase marks of a step on the main stream (measurement aid, off unless `phase_events` is a list: bench.py's host probe)
@@ -716,7 +719,13 @@ class condGANTrainer(object):
                 err = loss_fn(pre.get(name))
                 active = torch.is_tensor(err)
                 if active:
-                    err.backward()
+                    wg = self._wgrad_side_stream(stream_of[name] % len(side) + 1) if (side and self.async_wgrad_d) else None
+                    if wg is not None:              # this update's weight gradients beside its data-gradient chain
+                        with ops.wgrad_stream_scope(wg):
+                            err.backward()
+                        ops.wgrad_join()            # (this side stream waits: the all-reduce / Adam of the arena follow)
+                    else:
+                        err.backward()
                     opt.arena.grad[-1:].fill_(1.0)       # "this rank has a gradient" flag
                     out[name] = err.detach()
                 pending.append((opt, self._reduce_async(opt), active))

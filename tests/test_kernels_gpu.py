@@ -825,6 +825,42 @@ def test_fp16x2_on_records_equals_the_gather_form_bit_for_bit(dev, case):
     assert rel_l2(outs[0][2], outs[1][2]) < 5e-6, ("wgrad", rel_l2(outs[0][2], outs[1][2]))
 
 
+@pytest.mark.parametrize("case", [c for c in REC_CASES if c[4] >= 40 and (c[2] * c[3]) % 32 == 0][:9])
+def test_weight_gradient_on_presplit_dy_equals_the_in_loop_split_bit_for_bit(dev, case):
+    """Round 6: the record-form weight gradient reads dy as its fp16 PAIR (plane h, plane l; one pass of h2_pair_kernel into the
+    call's workspace) instead of splitting the fp32 rows on the way into LDS -- no operand split left in the K loop.  Same
+    scale, same two conversions, same products in the same order: BIT-identical to the in-loop split (and both within the
+    usual distance of the gather form, which orders its pixel splits differently)."""
+    ops = _ops()
+    N, Cin, H, W, Cout, k, s, p, pm, up = case
+    g = torch.Generator().manual_seed(4321)
+    x = torch.randn(N, Cin, H, W, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(dev)
+    prev, prev_min, prev_rec = ops.get_conv_math(), ops._H2_MIN_FLOP, dict(ops._REC)
+    ops.set_conv_math("fp16x2")
+    ops._H2_MIN_FLOP = 0.0
+    ops._REC["min_i"] = ops._REC["min_i_short"] = 0.0
+    ops._REC["wgrad"] = "all"
+    outs = {}
+    try:
+        for wm in (6, 5, 0):
+            ops._REC["wgrad_math"] = wm if wm else 5
+            ops.set_h2_records(wm != 0)
+            xd, wd = x.clone().requires_grad_(), w.clone().requires_grad_()
+            yd = ops.conv2d(xd, wd, None, s, p, pm, up, None)
+            gy = torch.randn(yd.shape, generator=torch.Generator().manual_seed(6)).to(dev)
+            yd.backward(gy)
+            torch.cuda.synchronize()
+            outs[wm] = wd.grad.clone()
+    finally:
+        ops._REC.update(prev_rec)
+        ops.set_conv_math(prev)
+        ops._H2_MIN_FLOP = prev_min
+    assert torch.isfinite(outs[6]).all()
+    assert torch.equal(outs[6], outs[5]), rel_l2(outs[6], outs[5])
+    assert rel_l2(outs[6], outs[0]) < 5e-6
+
+
 def test_h2_records_layout_and_split(dev):
     """objgan_h2_records: rec[n][c / 16][h | l][pixel][c % 16] fp16 with x * 2^s = h + l (round to nearest at each cut),
     max |x| * 2^s in [2^14, 2^15), channels beyond C zero -- against a torch evaluation of exactly that."""

@@ -61,7 +61,9 @@ int main(int argc, char** argv) {
     CK(hipStreamCreate(&st));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int g_math_arg = g_math;
     for (const Shape& sh : SHAPES) {
+        g_math = g_math_arg;
         if (filt[0] && !strstr(sh.name, filt)) continue;
         const int LH = sh.up ? 2 * sh.H : sh.H, LW = sh.up ? 2 * sh.W : sh.W;
         const int OH = (LH + 2 * sh.p - sh.k) / sh.s + 1, OW = (LW + 2 * sh.p - sh.k) / sh.s + 1;
@@ -86,6 +88,8 @@ int main(int argc, char** argv) {
         float* mxx; float* mxg;          // math 4 (fp16x2): per-workgroup maxima of x and of dy (objgan_absmax_partials)
         CK(hipMalloc(&mxx, 1024 * 4)); CK(hipMalloc(&mxg, 1024 * 4));
         float *recx = nullptr, *recg = nullptr;   // math 5: the fp16 records of x and dy
+        const int wmath = g_math == 6 ? 6 : 5;          // math 6: as 5, the weight gradient ALSO reads dy as its fp16 pair
+        if (g_math == 6) g_math = 5;
         const int kmath = g_math == 5 ? 4 : g_math;     // arithmetic of the calls that have no record form
         if (g_math == 5) {
             CK(hipMalloc(&recx, objgan_h2_records_floats(sh.N, sh.Cin, (long)sh.H * sh.W) * 4));
@@ -164,7 +168,7 @@ int main(int argc, char** argv) {
             // math 5: x as its record where the record form of the weight gradient takes the geometry
             const bool wrec = g_math == 5 && objgan_conv_wgrad_rec_ok(sh.N, sh.Cin, sh.H, sh.W, sh.Cout, OH, OW, sh.k);
             int rc = objgan_conv_wgrad(wrec ? recx : dx, dg, dgw, sh.N, sh.Cin, sh.H, sh.W, sh.up, sh.refl, sh.Cout, OH, OW, sh.k, sh.s, sh.p,
-                                       wrec ? 5 : kmath, 0, mxx, mxg, wsb, nwsb, st);
+                                       wrec ? wmath : kmath, 0, mxx, mxg, wsb, nwsb, st);
             if (rc != 1) { fprintf(stderr, "wgrad rc=%d\n", rc); exit(1); }
         };
         auto timeit = [&](auto&& fn) {
