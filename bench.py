@@ -258,7 +258,7 @@ def cpu_baseline(sample_batch=16, timed_steps=3, timeout_s=630):
 
 
 def side_configs(steps=6, warmup=2, timeout_s=240):
-    """Four short side records of the default N = 1 run, each a child `bench.py` on the same GPU after the headline is
+    """Five short side records of the default N = 1 run, each a child `bench.py` on the same GPU after the headline is
     measured (they are NOT the metric): the same step on the true fp32 MFMA (`--math fp32`, the arithmetic of rounds
     1-2), on the bf16 MFMA with exactly split operands (`--math bf16x3`, round 3's), BASELINE config 5
     (`--math bf16 --batch 32`: bf16 matrix-core inputs, fp32 accumulation), and the default step with every minibatch
@@ -267,7 +267,8 @@ def side_configs(steps=6, warmup=2, timeout_s=240):
     out = {}
     for key, extra in (("fp32_mfma_b16", ["--math", "fp32"]), ("bf16x3_b16", ["--math", "bf16x3"]),
                        ("config5_bf16_b32", ["--math", "bf16", "--batch", "32"]),
-                       ("pcie_inclusive_b16", ["--host-batches", "--no-kernel-timing"])):
+                       ("pcie_inclusive_b16", ["--host-batches", "--no-kernel-timing"]),
+                       ("jpeg_input_b16", ["--jpeg-input", "--no-kernel-timing"])):
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup),
                "--no-cpu-baseline", "--no-side-configs"] + extra
         try:
@@ -278,6 +279,8 @@ def side_configs(steps=6, warmup=2, timeout_s=240):
             out[key]["per_gpu_batch"] = r["config"]["per_gpu_batch"]
             if "host_batches" in r["config"]:
                 out[key]["host_batches"] = r["config"]["host_batches"]
+            if "jpeg_input" in r["config"]:
+                out[key]["jpeg_input"] = r["config"]["jpeg_input"]
             if "roofline" in r:
                 out[key]["roofline"] = {k: r["roofline"].get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "traffic")}
             if "conv_total" in r:
@@ -485,6 +488,11 @@ def main():
                     help="PCIe-inclusive side measurement: the minibatches stay in pinned HOST memory in the reference's "
                          "hand-over form (float32 images, 80-channel layout maps, box masks) and every step's batch is "
                          "uploaded inside the timed region (copy stream, one step ahead).  Never the headline value.")
+    ap.add_argument("--jpeg-input", action="store_true",
+                    help="real-input-shaped side measurement: every step's training images arrive as JPEG FILES (synthetic "
+                         "480x640 photographs encoded once with Pillow, four batches in rotation): the file bytes cross PCIe, "
+                         "are decoded on the device (csrc/jpeg.hip, entropy index after the first pass) and resized to the "
+                         "branch sizes there, one step ahead on a side stream.  Never the headline value.")
     ap.add_argument("--no-is-monitor", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--force-ddp", action="store_true",
@@ -578,7 +586,57 @@ def main():
                 ready[k] = ev
         refill(0, 0)
 
+    jpeg_info = None
+    if args.jpeg_input:
+        # the loader side of the reference step (miscc/load.py:141-151: PIL decode + three PIL resizes per sample) on the
+        # device: files -> jpeg_decode_batch -> resize_pil_bilinear_device, on a side stream while the previous step trains
+        import io
+        import numpy as np
+        from PIL import Image
+        rng = np.random.RandomState(77 + rank)
+        jfiles = []
+        for i in range(nb * args.batch):
+            a = rng.rand(480 // 4 + 2, 640 // 4 + 2, 3)
+            im = Image.fromarray((a * 255).astype(np.uint8)).resize((640, 480), Image.BICUBIC)
+            a = np.clip(np.asarray(im).astype(np.float32) + rng.randn(480, 640, 3) * 14.0, 0, 255).astype(np.uint8)
+            buf = io.BytesIO()
+            Image.fromarray(a).save(buf, "JPEG", quality=90, subsampling=2)
+            jfiles.append(buf.getvalue())
+        jcache = ops.JpegIndexCache()
+        jstream = torch.cuda.Stream(device)
+        sizes = [64 << b_ for b_ in range(branch_num)]
+        jready = [None] * nb
+        jpeg_info = {"files_per_step": args.batch, "bytes_per_step_and_gpu": int(sum(len(f) for f in jfiles) / nb),
+                     "image_size": "480x640, 4:2:0, quality 90"}
+
+        def jload(i):
+            k = i % nb
+            with torch.cuda.stream(jstream):
+                fs = jfiles[k * args.batch:(k + 1) * args.batch]
+                src, offs, hs, ws_ = ops.jpeg_decode_batch(fs, device, jcache, [(k, j) for j in range(args.batch)])
+                imgs = ops.resize_pil_bilinear_device(src, offs, hs, ws_, sizes)
+                ev = torch.cuda.Event()
+                ev.record(jstream)
+            jready[k] = (imgs, ev)
+        for k_ in range(nb):                # "epoch 1": every file decoded once by one lane, its entropy index cached on the device
+            jload(k_)
+        torch.cuda.synchronize()
+        jpeg_info["first_pass_index_misses"] = jcache.misses
+        jload(0)
+
     def step():
+        if args.jpeg_input:
+            k = it[0] % nb
+            imgs, ev = jready[k]
+            torch.cuda.current_stream().wait_event(ev)
+            b_ = dict(batches[k])
+            b_["imgs"] = imgs
+            for t_ in imgs:
+                t_.record_stream(torch.cuda.current_stream())
+            jload(it[0] + 1)
+            out = tr.train_step(b_)
+            it[0] += 1
+            return out
         if args.host_batches:
             k = it[0] % 2
             torch.cuda.current_stream().wait_event(ready[k])
@@ -692,6 +750,14 @@ def main():
                                                "bf16x3 (six products on the bf16 MFMA)",
                                      "bf16": "operands rounded to bf16, fp32 accumulation"}[args.math]},
         }
+        if jpeg_info is not None:
+            jpeg_info["index_cache"] = {"hits": jcache.hits, "misses": jcache.misses}
+            jpeg_info["what"] = ("real-input-shaped side measurement: the training images of every step arrive as JPEG files; "
+                                 "bytes over PCIe, Huffman + IDCT + upsampling + colour + the three Pillow-exact resizes on "
+                                 "the device, one step ahead on a side stream (first pass of a file: one lane; later passes: "
+                                 "one lane per MCU row from the cached entropy index -- the first pass over the four batches happens before "
+                                 "the warm-up, as epoch 1 would)")
+            res["config"]["jpeg_input"] = jpeg_info
         if args.host_batches:
             res["config"]["host_batches"] = {
                 "bytes_per_step_and_gpu": int(host_bytes),

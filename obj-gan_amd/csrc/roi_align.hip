@@ -286,11 +286,13 @@ __device__ __forceinline__ float roi_tap_value(float dv, float h_ratio, float w_
     return dh_ * w_ratio;
 }
 
+#define ROI_LDS_START 4608          // anchor-range starts of the map in LDS (HW + 1 <= this: the 64 x 64 maps of the hot path)
 __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
     const float* __restrict__ top_grad, const int* __restrict__ ws, float* __restrict__ bottom_grad,
     int C, int HW, int W, int S, RoiTabDims d, int cpb) {
     __shared__ int4 s_smp[ROI_LDS_SMP];
     __shared__ float s_g[ROI_LDS_G];
+    __shared__ int s_start[ROI_LDS_START];
     const int b = blockIdx.y;
     const int* hdr = ws + (size_t)b * d.stride;
     const int* pix = hdr + 4;
@@ -303,6 +305,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
     const int nc = min(cpb, C - c0);
     const int sub = threadIdx.x & (ROI_SUB - 1), grp = threadIdx.x / ROI_SUB;
     const bool staged = n_e <= ROI_LDS_SMP && nlist * nc * S <= ROI_LDS_G;          // (uniform over the workgroup)
+    const bool st_lds = HW + 1 <= ROI_LDS_START;
     if (staged) {
         for (int k = threadIdx.x; k < n_e; k += 256) s_smp[k] = smp[sorted[k]];
         const int per = nc * S;                                                     // floats of one roi's slab
@@ -310,40 +313,47 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
             const int kl = i / per, j = i - kl * per;
             s_g[i] = top_grad[((size_t)rlist[kl] * C + c0) * S + j];
         }
-        __syncthreads();
     }
-    for (int i = grp; i < n_pix * nc; i += 256 / ROI_SUB) {
-        const int ci = i / n_pix, ip = i - ci * n_pix;
-        const int c = c0 + ci;
+    if (st_lds)
+        for (int i = threadIdx.x; i <= HW; i += 256) s_start[i] = start[i];
+    __syncthreads();
+    // 16 lanes per touched pixel; the pixel's four anchor ranges are looked up ONCE and serve every channel of the slab
+    // (round 5 looked them up per (pixel, channel) element: nine dependent global loads in front of every element)
+    for (int ip = grp; ip < n_pix; ip += 256 / ROI_SUB) {
         const int p = pix[ip];
         int k0[4], lim[4];                                              // range starts; cumulative lengths
         int total = 0;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int q = p - (t & 1) - (t >> 1) * W;                   // anchor whose tap t lands on p
-            k0[t] = q >= 0 ? start[q] : 0;
-            total += q >= 0 ? start[q + 1] - k0[t] : 0;
+            const int s0 = q >= 0 ? (st_lds ? s_start[q] : start[q]) : 0;
+            const int s1 = q >= 0 ? (st_lds ? s_start[q + 1] : start[q + 1]) : 0;
+            k0[t] = s0;
+            total += s1 - s0;
             lim[t] = total;
         }
-        float acc = 0.f;
-        for (int m = sub; m < total; m += ROI_SUB) {
-            const int t = (m >= lim[0]) + (m >= lim[1]) + (m >= lim[2]);
-            const int k = t == 0 ? k0[0] + m : t == 1 ? k0[1] + m - lim[0] : t == 2 ? k0[2] + m - lim[1] : k0[3] + m - lim[2];
-            float dv, h_ratio, w_ratio;
-            if (staged) {
-                const int4 g = s_smp[k];
-                h_ratio = __int_as_float(g.y); w_ratio = __int_as_float(g.z);
-                dv = s_g[(g.x * nc + ci) * S + (g.w & 255)];
-            } else {
-                const int4 g = smp[sorted[k]];
-                h_ratio = __int_as_float(g.y); w_ratio = __int_as_float(g.z);
-                dv = top_grad[((size_t)(g.w >> 8) * C + c) * S + (g.w & 255)];
+        for (int ci = 0; ci < nc; ++ci) {
+            const int c = c0 + ci;
+            float acc = 0.f;
+            for (int m = sub; m < total; m += ROI_SUB) {
+                const int t = (m >= lim[0]) + (m >= lim[1]) + (m >= lim[2]);
+                const int k = t == 0 ? k0[0] + m : t == 1 ? k0[1] + m - lim[0] : t == 2 ? k0[2] + m - lim[1] : k0[3] + m - lim[2];
+                float dv, h_ratio, w_ratio;
+                if (staged) {
+                    const int4 g = s_smp[k];
+                    h_ratio = __int_as_float(g.y); w_ratio = __int_as_float(g.z);
+                    dv = s_g[(g.x * nc + ci) * S + (g.w & 255)];
+                } else {
+                    const int4 g = smp[sorted[k]];
+                    h_ratio = __int_as_float(g.y); w_ratio = __int_as_float(g.z);
+                    dv = top_grad[((size_t)(g.w >> 8) * C + c) * S + (g.w & 255)];
+                }
+                acc += roi_tap_value(dv, h_ratio, w_ratio, t);
             }
-            acc += roi_tap_value(dv, h_ratio, w_ratio, t);
-        }
 #pragma unroll
-        for (int o = ROI_SUB / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-        if (sub == 0) bottom_grad[((size_t)b * C + c) * HW + p] += acc;
+            for (int o = ROI_SUB / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (sub == 0) bottom_grad[((size_t)b * C + c) * HW + p] += acc;
+        }
     }
 }
 

@@ -448,7 +448,9 @@ class condGANTrainer(object):
     # forward) are shape-static and launch-bound: each is captured once into hipGraphs and replayed (objgan_hip.graphs).
     use_graphs = True
     # the discriminators' real-image passes run on the side streams beside the generator's forward pass (train_step (1b))
-    hoist_real_passes = os.environ.get("OBJGAN_HOIST_REAL", "1") != "0"
+    # (measured in round 6: 136.7 / 133.9 ms with, 135.0 / 134.5 without on one box -- the device has no idle capacity left
+    # during the generator's forward pass; off by default, profiles/r06_ab_variants.txt)
+    hoist_real_passes = os.environ.get("OBJGAN_HOIST_REAL", "0") == "1"
     # fp16x2 run-time guard: every `h2_guard_every` iterations (and on the first) one step is a checked step (0: never)
     h2_guard_every = 500
 

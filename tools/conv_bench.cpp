@@ -3,7 +3,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 tools/conv_bench.cpp -Iinclude -L obj-gan_amd/objgan_hip -lobjgan_hip \
 //         -Wl,-rpath,'$ORIGIN/../obj-gan_amd/objgan_hip' -o tools/conv_bench
-//   tools/conv_bench [filter] [iters] [math: 0 fp32 | 1 bf16 inputs | 2 bf16x3 | 4 fp16x2 | 5 fp16x2 on records]
+//   tools/conv_bench [filter] [iters] [math: 0 fp32 | 1 bf16 inputs | 2 bf16x3 | 4 fp16x2 | 5 fp16x2 on records | 6: 5 + weight gradient on pre-split dy]
 //   (math 5: forward / data gradient read the pre-split fp16 record of their pixel operand; the record passes are timed
 //    on their own line; the weight gradient runs math 4; `hash` columns: FNV-1a of the output bits -- equal between
 //    math 4 and math 5 when the two are bit-identical)
@@ -83,7 +83,7 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&dgx, ngx * 4)); CK(hipMalloc(&dgw, nw * 4)); CK(hipMalloc(&wt, nwt * 4));
         // one scratch buffer large enough for every split-K / weight-gradient workspace of this shape
         float* wsb;
-        const long nwsb = 96L << 20;      // 384 MB of floats
+        const long nwsb = 192L << 20;     // 768 MB of floats (math 6: + the fp16 pair of dy)
         CK(hipMalloc(&wsb, nwsb * 4));
         float* mxx; float* mxg;          // math 4 (fp16x2): per-workgroup maxima of x and of dy (objgan_absmax_partials)
         CK(hipMalloc(&mxx, 1024 * 4)); CK(hipMalloc(&mxg, 1024 * 4));
