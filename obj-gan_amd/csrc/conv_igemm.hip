@@ -44,6 +44,7 @@ static void og_absmax_launch(const float* x, long n, float* out, hipStream_t s);
 int og_launch_igemm3_rec(const IgemmArgs& a, int TM, int nw, int ng, dim3 grid, hipStream_t s);
 int og_launch_wgrad_rec(const WgradArgs& a, int tm, int nw, dim3 grid, int ksize, int Cp, int dyp, hipStream_t s);
 void og_launch_h2_pair(const float* x, const float* xmax, float* out, long n, hipStream_t s);
+int og_launch_wgrad_rec2(const WgradArgs& a, int tm, dim3 grid, int ksize, int Cp, hipStream_t s);
 
 template <int WM, int TM>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
@@ -2868,15 +2869,18 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
     long ws_used = 0;
     if (plan_only) *ws_need = 0;
     if (ksize != 1 && ksize != 3 && ksize != 4) return OG_BAD_ARGS;
-    if (math < 0 || math > 6 || math == 3) return OG_BAD_ARGS;
+    if (math < 0 || math > 7 || math == 3) return OG_BAD_ARGS;
     if (math >= 4 && !plan_only && (!xmax || !dymax)) return OG_BAD_ARGS;
     if (N <= 0 || Cout <= 0 || Cin <= 0) return OG_OK;
     // math 5: x is the fp16 record of the source (conv_igemm_rec.hip), dy the fp32 tensor: conv_wgrad_rec_kernel.  The
     // caller asks objgan_conv_wgrad_rec_ok first; a geometry the record kernel does not take is an argument error here.
     // math 6 (round 6): the same with dy pre-split too -- its fp16 pair is written into the workspace by one pass
     // (h2_pair_kernel) and the kernel's K loop carries no operand split at all.
-    const bool rec = math == 5 || math == 6;
+    // math 7 (round 6): the record form with TWO column groups per wave (conv_wgrad_rec2_kernel: block rows <= 128 rows,
+    // 8-wave workgroups); launches of fewer than 16 384 pixels keep the one-group kernel.
+    const bool rec = math == 5 || math == 6 || math == 7;
     const bool dyp = math == 6;
+    const bool rec2 = math == 7 && (long)N * OH * OW >= 16384;
     if (rec && !og_wgrad_rec_geometry(N, Cin, H, W, Cout, OH, OW, ksize)) return OG_BAD_ARGS;
     // fp16x2 lives in the register-fragment kernel; launches that plan the LDS-staged / first-generation kernels run
     // bf16x3 (both are fp32-result arithmetics)
@@ -2943,7 +2947,7 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
             og_row_plan(groups - 1, tiles_n0, 1, &TM, &full_rows, &rest);
             if (TM >= 2 && full_rows >= 1) groups -= 1; else xrows = false;
         }
-        og_row_plan(groups, tiles_n0, 1, &TM, &full_rows, &rest, 100, rec ? og_wgrad_rec_tmmax() : 7);      // (tall tiles: independent of the column tiling)
+        og_row_plan(groups, tiles_n0, 1, &TM, &full_rows, &rest, 100, rec2 ? 4 : (rec ? og_wgrad_rec_tmmax() : 7));      // (tall tiles: independent of the column tiling)
         a.xr_begin = groups * 32;
         for (int part = 0; part < 2; ++part) {
             const int tm = part == 0 ? TM : rest;
@@ -2969,10 +2973,10 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
             const bool use3 = bf ? tm <= 2 : (sp ? x3_frag : (tm <= og_wgrad3_maxtm() || b128));
             // bf16x3, register-fragment form: 8-wave workgroups (256 columns per dy row tile), as in run_igemm2
             const int nw = bfb ? ((tm <= 6 && Npix >= 16384) ? 8 : 4)
-                               : (rec ? ((tm <= 6 && Npix >= 16384 && og_wgrad_rec_nw8()) ? 8 : 4)
+                               : (rec2 ? 8 : rec ? ((tm <= 6 && Npix >= 16384 && og_wgrad_rec_nw8()) ? 8 : 4)
                                       : ((sp && use3 && tm >= 4 && og_nw8_min() > 0 && Npix >= 16384) ? 8 : 4));
             // column tiles: 32 columns (ci * T + t) per wave; bfb / rec: one (tap, 32-channel group) per wave
-            const int tiles_n = (bfb || rec) ? og_cdiv(ksize * ksize * og_cdiv(Cpb, 32), nw) : og_cdiv(a.ncol, 32 * nw);
+            const int tiles_n = (bfb || rec) ? og_cdiv(ksize * ksize * og_cdiv(Cpb, 32), rec2 ? 2 * nw : nw) : og_cdiv(a.ncol, 32 * nw);
             int splits;
             const int max_splits = og_cdiv(Npix, 512);       // >= 32 K steps per split
             if (og_wgrad_oldsplit()) {
@@ -3043,7 +3047,10 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
                     else if (use3 && b128) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv, 0, true>), grid, dim3(256), 0, s, a, ksize); \
                     else if (use3) hipLaunchKernelGGL((conv_wgrad3_kernel<TMv>), grid, dim3(256), 0, s, a, ksize); \
                     else hipLaunchKernelGGL((conv_wgrad2_kernel<TMv>), grid, dim3(256), 0, s, a, ksize);
-            if (rec) {
+            if (rec2) {
+                const int rc_ = og_launch_wgrad_rec2(a, tm, grid, ksize, Cpb, s);
+                if (rc_ != OG_OK) { prof_end(pr, s); return rc_; }
+            } else if (rec) {
                 const int rc_ = og_launch_wgrad_rec(a, tm, nw, grid, ksize, Cpb, dyp ? 1 : 0, s);
                 if (rc_ != OG_OK) { prof_end(pr, s); return rc_; }
             } else if (bfb) {

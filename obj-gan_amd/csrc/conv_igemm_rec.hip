@@ -399,6 +399,279 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_rec_kernel(const WgradArgs
 }
 
 // launch of the record-reading weight gradient (called by og_wgrad in conv_igemm.hip)
+// ---- weight gradient on records, TWO column groups per wave (round 6) --------------------------------------------------
+// conv_wgrad_rec_kernel above is bound by its LDS fragment reads: per 32-pixel iteration the eight waves of a 192-row tile
+// read 8 x 24 KB of dy row fragments (every wave the same rows, for its own 32 columns) -- ~2 060 cycles at 128 B/clk against
+// 2 300 cycles of MFMA per SIMD, and with two waves per SIMD the two do not overlap (MFMA pipe 35-40 % busy,
+// profiles/r05_roofline_table.md).  Here a wave owns TWO (tap, 32-channel) column groups and a 32 * TM <= 128 row tile:
+// one set of row fragments feeds twice the MFMAs (LDS bytes per MAC: 0.047 against 0.073), the x records of both groups go
+// through two wave-private LDS images.  Same products per 16-pixel step, same order inside a column group: a column of dw
+// is the same sum as in the one-group kernel with the same pixel splits (bit-identical when the plans agree).
+template <int TM>
+__global__ __launch_bounds__(512) void conv_wgrad_rec2_kernel(const WgradArgs a, const int KS, const int Cp) {
+    constexpr int NW = 8, NCG = 2;
+    constexpr int NT = 64 * NW;
+    constexpr int BM = 32 * TM;
+    constexpr int BK = 32;
+    constexpr int ALD = 36;
+    constexpr int ATILE = BM * ALD;
+    constexpr int NA4 = BM * 8;
+    constexpr int NA_PER = (NA4 + NT - 1) / NT;
+    constexpr int BTILE = 1024;
+    constexpr int TAB = 256;
+    static_assert((2 * ATILE + NW * NCG * BTILE) * 4 + 2 * 4 * TAB * 2 <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) float ldsA[2 * ATILE];
+    __shared__ __attribute__((aligned(16))) float ldsB[NW * NCG * BTILE];
+    __shared__ unsigned short rtab[4 * TAB], ctab[4 * TAB];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane >> 5;
+    const int lcol = lane & 31;
+
+    const int T = KS * KS;
+    const int Cc = Cp >> 4;
+    const int CG = (Cc + 1) >> 1;
+    const int ngroups = T * CG;
+    const int tiles_m = (a.m_end - a.m_begin + BM - 1) / BM;
+    const int tiles_n = (ngroups + NW * NCG - 1) / (NW * NCG);
+    const int nwg = tiles_m * tiles_n;
+    const int vid = og_xcd_remap(blockIdx.x + nwg * blockIdx.y, nwg * gridDim.y);
+    const int split = vid / nwg;
+    const int wg = vid - split * nwg;
+    const int tile_m = wg % tiles_m;
+    const int tile_n = wg / tiles_m;
+    const int m0 = a.m_begin + tile_m * BM;
+
+    const int OHW = a.OH * a.OW;
+    const int HW = a.H * a.W;
+    const int Npix = a.N * OHW;
+    const int p_begin = split * a.pix_per_split;
+    const int p_end = min(Npix, p_begin + a.pix_per_split);
+    const int nk = (p_end - p_begin + BK - 1) / BK;
+
+    __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.x, 0, (int)((unsigned)a.N * (unsigned)Cc * (unsigned)HW * 64u), OG_BUF_FLAGS);
+    __amdgpu_buffer_rsrc_t dyres = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.dy, 0, (int)((unsigned)a.N * a.Cout * OHW * 4u), OG_BUF_FLAGS);
+
+    og_fp16_saturate();
+    const int sx = og_h2_exponent(a.xmax, lane), sd = og_h2_exponent(a.dymax, lane);
+    const float h2_dys = og_pow2(sd), h2_inv = og_pow2_sum(-sx, -sd);
+
+    // ---- the wave's two column groups
+    bool grp_ok[NCG], rec_ok[NCG];
+    int tg[NCG], cgg[NCG];
+    unsigned rec_lane[NCG];
+    const unsigned short* rt[NCG];
+    const unsigned short* ct[NCG];
+#pragma unroll
+    for (int j = 0; j < NCG; ++j) {
+        const int group = (tile_n * NW + wid) * NCG + j;
+        grp_ok[j] = group < ngroups;
+        tg[j] = grp_ok[j] ? group / CG : 0;
+        cgg[j] = grp_ok[j] ? group - tg[j] * CG : 0;
+        const int kh = tg[j] / KS;
+        const int chunk = cgg[j] * 2 + ((lane >> 1) & 1);
+        rec_ok[j] = grp_ok[j] && chunk < Cc;
+        rec_lane[j] = (unsigned)chunk * 2u * (unsigned)HW;
+        rt[j] = rtab + kh * TAB;
+        ct[j] = ctab + (tg[j] - kh * KS) * TAB;
+    }
+    const unsigned img_recs = (unsigned)Cc * 2u * (unsigned)HW;
+    const int us = a.upsample ? 1 : 0;
+    const bool refl = a.pad_mode == 1;
+    for (int i = tid; i < KS * (a.OH + a.OW); i += NT) {             // tap geometry tables (see conv_wgrad_rec_kernel)
+        const bool is_row = i < KS * a.OH;
+        const int e = is_row ? i : i - KS * a.OH;
+        const int L = is_row ? a.OH : a.OW, LL = is_row ? a.LH : a.LW;
+        const int kk = e / L, o = e - kk * L;
+        const int iv = o * a.stride + kk - a.pad;
+        int ivr = iv < 0 ? -iv : iv;
+        ivr = ivr >= LL ? 2 * (LL - 1) - ivr : ivr;
+        const bool ok = refl || ((unsigned)iv < (unsigned)LL);
+        const int src = (refl ? ivr : iv) >> us;
+        const unsigned short v = ok ? (unsigned short)(is_row ? src * a.W : src) : (unsigned short)0xffffu;
+        if (is_row) rtab[kk * TAB + o] = v; else ctab[kk * TAB + o] = v;
+    }
+    const int rows16 = 16 / a.OW, cols16 = 16 - rows16 * a.OW;
+    const int rows32 = 32 / a.OW, cols32 = 32 - rows32 * a.OW;
+    int pn, poh, pow_;
+    {
+        const int p = p_begin + (lane >> 2);
+        pn = p / OHW;
+        const int r = p - pn * OHW;
+        poh = r / a.OW;
+        pow_ = r - poh * a.OW;
+    }
+    int p_ld = p_begin + (lane >> 2);
+    const unsigned half16 = (unsigned)((lane & 1) * 16);
+    auto load_b = [&](f32x4 (&rb)[NCG][4]) {         // rb[group][piece * 2 + half]
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int n = pn, oh = poh, ow = pow_;
+            if (h == 1) {
+                ow += cols16;
+                const int c = ow >= a.OW ? 1 : 0;
+                ow -= c ? a.OW : 0;
+                oh += rows16 + c;
+                while (oh >= a.OH) { oh -= a.OH; n += 1; }
+            }
+            const bool in = p_ld + 16 * h < p_end;
+#pragma unroll
+            for (int j = 0; j < NCG; ++j) {
+                const unsigned r = rt[j][oh], c = ct[j][ow];
+                const bool ok = rec_ok[j] && in && r != 0xffffu && c != 0xffffu;
+                const unsigned rec = (unsigned)n * img_recs + rec_lane[j] + r + c;
+                const unsigned off = ok ? rec * 32u + half16 : OG_OOB;
+                rb[j][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 0));
+                rb[j][2 + h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, HW * 32, 0));
+            }
+        }
+        p_ld += BK;
+        pow_ += cols32;
+        const int c = pow_ >= a.OW ? 1 : 0;
+        pow_ -= c ? a.OW : 0;
+        poh += rows32 + c;
+        while (poh >= a.OH) { poh -= a.OH; pn += 1; }
+    };
+    auto store_b = [&](const f32x4 (&rb)[NCG][4]) {
+#pragma unroll
+        for (int j = 0; j < NCG; ++j) {
+            float* Bs = ldsB + (wid * NCG + j) * BTILE;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(Bs + q * 256 + lane * 4) = rb[j][q];
+        }
+    };
+    const int b_rd = ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;   // bytes
+
+    // ---- dy rows (fp32 in HBM; scaled and split into two fp16 pieces by the loader thread)
+    unsigned avoff[NA_PER];
+    int alds[NA_PER];
+#pragma unroll
+    for (int i = 0; i < NA_PER; ++i) {
+        const int idx = tid + NT * i;
+        const int row = idx >> 3, q = idx & 7;
+        const bool on = (NA4 % NT == 0 || idx < NA4) && (m0 + row) < a.m_end;
+        avoff[i] = on ? ((unsigned)(m0 + row) * (unsigned)OHW + q * 4u) * 4u : OG_OOB;
+        alds[i] = (NA4 % NT == 0 || idx < NA4) ? row * ALD + q * 2 : -1;
+    }
+    int n_ld = p_begin / OHW;
+    int rem_ld = p_begin - n_ld * OHW;
+    f32x4 ra[NA_PER];
+    auto load_a = [&]() {
+        const int so = (n_ld * a.Cout * OHW + rem_ld) * 4;
+        rem_ld += BK;
+        if (rem_ld >= OHW) { rem_ld = 0; n_ld += 1; }
+#pragma unroll
+        for (int i = 0; i < NA_PER; ++i)
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyres, avoff[i], so, 0));
+    };
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    auto store_a = [&](int buf) {
+        float* As = ldsA + buf * ATILE;
+#pragma unroll
+        for (int i = 0; i < NA_PER; ++i) {
+            f16x4 h, l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float sv = ra[i][j] * h2_dys;
+                h[j] = (_Float16)sv;
+                l[j] = (_Float16)og_sub(sv, (float)h[j]);
+            }
+            if (NA4 % NT == 0 || alds[i] >= 0) {
+                *reinterpret_cast<f16x4*>(As + alds[i]) = h;
+                *reinterpret_cast<f16x4*>(As + alds[i] + 16) = l;
+            }
+        }
+    };
+
+    f32x16 acc[NCG][TM];
+#pragma unroll
+    for (int j = 0; j < NCG; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+    typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4;
+    auto mma = [&](int buf, auto&& mid) {
+        const float* As = ldsA + buf * ATILE + lcol * ALD + lrow * 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f16x8 ah[TM], al[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                al[i] = *reinterpret_cast<const f16x8*>(As + i * 32 * ALD + 16 + h * 8);
+                ah[i] = *reinterpret_cast<const f16x8*>(As + i * 32 * ALD + h * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < NCG; ++j) {
+                const char* Bs = reinterpret_cast<const char*>(ldsB + (wid * NCG + j) * BTILE) + b_rd;
+                const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Bs + h * 1024));
+                const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Bs + h * 1024 + 256));
+                const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Bs + 2048 + h * 1024));
+                const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Bs + 2048 + h * 1024 + 256));
+                const f16x8 bh = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                const f16x8 bl = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int i = 0; i < TM; ++i) OG_MFMA_H(al[i], bh, acc[j][i]);
+                if (h == 1 && j == 0) {       // the refill behind the first TM MFMAs of the second half
+                    __builtin_amdgcn_sched_barrier(0);
+                    mid();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) OG_MFMA_H(ah[i], bh, acc[j][i]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) OG_MFMA_H(ah[i], bl, acc[j][i]);
+            }
+        }
+    };
+
+    f32x4 rb[NCG][4];
+    __syncthreads();                                  // tables
+    load_a(); load_b(rb);
+    store_a(0); store_b(rb);
+    load_a(); load_b(rb);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        mma(0, [&]() { store_a(1); store_b(rb); load_a(); load_b(rb); });
+        __syncthreads();
+        mma(1, [&]() { store_a(0); store_b(rb); load_a(); load_b(rb); });
+        __syncthreads();
+    }
+    if (kt < nk) mma(0, [] {});
+
+#pragma unroll
+    for (int j = 0; j < NCG; ++j) {
+        const int ci = cgg[j] * 32 + lcol;
+        if (!grp_ok[j] || ci >= a.Cin) continue;
+        const int ocol = ci * T + tg[j];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                if (m < a.m_end) og_wgrad_store(a, m, ocol, acc[j][i][r] * h2_inv, split);
+            }
+        }
+    }
+}
+
+int og_launch_wgrad_rec2(const WgradArgs& a, int tm, dim3 grid, int ksize, int Cp, hipStream_t s) {
+    switch (tm) {
+        case 1: hipLaunchKernelGGL((conv_wgrad_rec2_kernel<1>), grid, dim3(512), 0, s, a, ksize, Cp); break;
+        case 2: hipLaunchKernelGGL((conv_wgrad_rec2_kernel<2>), grid, dim3(512), 0, s, a, ksize, Cp); break;
+        case 3: hipLaunchKernelGGL((conv_wgrad_rec2_kernel<3>), grid, dim3(512), 0, s, a, ksize, Cp); break;
+        case 4: hipLaunchKernelGGL((conv_wgrad_rec2_kernel<4>), grid, dim3(512), 0, s, a, ksize, Cp); break;
+        default: return OG_BAD_ARGS;
+    }
+    return og_launch_status();
+}
+
 // fp32 -> its fp16 pair under the tensor's scale, same layout, plane h followed by plane l (n4 = elements / 4): the dy
 // operand of conv_wgrad_rec_kernel<.., true>
 __global__ __launch_bounds__(256) void h2_pair_kernel(const float* __restrict__ x, const float* __restrict__ xmax,

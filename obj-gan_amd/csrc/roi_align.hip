@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void roi_tap_table_kernel(
 // path for an image whose table or gradient slab does not fit (ROI_LDS_SMP samples / ROI_LDS_G floats).
 #define ROI_SUB 16
 #define ROI_LDS_SMP 1024
-#define ROI_LDS_G 8192
+#define ROI_LDS_G 4096
 __device__ __forceinline__ float roi_tap_value(float dv, float h_ratio, float w_ratio, int t) {
     // reference kernel.cu:137-140: `(1. - h_ratio)` is double, `(1 - w_ratio)` is FLOAT (int
     // literal); the two h_ratio terms are all-float products.
@@ -287,6 +287,7 @@ __device__ __forceinline__ float roi_tap_value(float dv, float h_ratio, float w_
 }
 
 #define ROI_LDS_START 4608          // anchor-range starts of the map in LDS (HW + 1 <= this: the 64 x 64 maps of the hot path)
+#define ROI_SEQ 24                  // an element with at most this many taps is summed by ONE lane
 __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
     const float* __restrict__ top_grad, const int* __restrict__ ws, float* __restrict__ bottom_grad,
     int C, int HW, int W, int S, RoiTabDims d, int cpb) {
@@ -303,7 +304,6 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
     const int n_pix = hdr[0], n_e = hdr[1], nlist = hdr[3];
     const int c0 = blockIdx.x * cpb;
     const int nc = min(cpb, C - c0);
-    const int sub = threadIdx.x & (ROI_SUB - 1), grp = threadIdx.x / ROI_SUB;
     const bool staged = n_e <= ROI_LDS_SMP && nlist * nc * S <= ROI_LDS_G;          // (uniform over the workgroup)
     const bool st_lds = HW + 1 <= ROI_LDS_START;
     if (staged) {
@@ -317,42 +317,61 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
     if (st_lds)
         for (int i = threadIdx.x; i <= HW; i += 256) s_start[i] = start[i];
     __syncthreads();
-    // 16 lanes per touched pixel; the pixel's four anchor ranges are looked up ONCE and serve every channel of the slab
-    // (round 5 looked them up per (pixel, channel) element: nine dependent global loads in front of every element)
-    for (int ip = grp; ip < n_pix; ip += 256 / ROI_SUB) {
-        const int p = pix[ip];
-        int k0[4], lim[4];                                              // range starts; cumulative lengths
+    auto ranges = [&](int p, int (&k0)[4], int (&lim)[4]) -> int {                  // the four anchor ranges whose taps land on p
         int total = 0;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int q = p - (t & 1) - (t >> 1) * W;                   // anchor whose tap t lands on p
+            const int q = p - (t & 1) - (t >> 1) * W;                               // anchor whose tap t lands on p
             const int s0 = q >= 0 ? (st_lds ? s_start[q] : start[q]) : 0;
             const int s1 = q >= 0 ? (st_lds ? s_start[q + 1] : start[q + 1]) : 0;
             k0[t] = s0;
             total += s1 - s0;
             lim[t] = total;
         }
+        return total;
+    };
+    auto tap = [&](int m, const int (&k0)[4], const int (&lim)[4], int ci, int c) -> float {
+        const int t = (m >= lim[0]) + (m >= lim[1]) + (m >= lim[2]);
+        const int k = t == 0 ? k0[0] + m : t == 1 ? k0[1] + m - lim[0] : t == 2 ? k0[2] + m - lim[1] : k0[3] + m - lim[2];
+        float dv, h_ratio, w_ratio;
+        if (staged) {
+            const int4 g = s_smp[k];
+            h_ratio = __int_as_float(g.y); w_ratio = __int_as_float(g.z);
+            dv = s_g[(g.x * nc + ci) * S + (g.w & 255)];
+        } else {
+            const int4 g = smp[sorted[k]];
+            h_ratio = __int_as_float(g.y); w_ratio = __int_as_float(g.z);
+            dv = top_grad[((size_t)(g.w >> 8) * C + c) * S + (g.w & 255)];
+        }
+        return roi_tap_value(dv, h_ratio, w_ratio, t);
+    };
+    // Two regimes, decided per element by its tap count (a function of the rois alone: the same path in every run).
+    // (1) Few taps -- boxes that spread their 7 x 7 samples over many pixels: ONE lane per (pixel, channel) element sums its
+    //     taps in order; 256 read-modify-writes of bottom_grad in flight per workgroup instead of 16 (round 5's 16-lane
+    //     groups were latency-bound there: 111 us per launch for 20 MB).
+    for (int e = threadIdx.x; e < n_pix * nc; e += 256) {
+        const int ci = e / n_pix, ip = e - ci * n_pix;
+        int k0[4], lim[4];
+        const int p = pix[ip];
+        const int total = ranges(p, k0, lim);
+        if (total > ROI_SEQ) continue;
+        float acc = 0.f;
+        for (int m = 0; m < total; ++m) acc += tap(m, k0, lim, ci, c0 + ci);
+        bottom_grad[((size_t)b * C + c0 + ci) * HW + p] += acc;
+    }
+    // (2) Many taps -- small boxes whose samples share a handful of anchors: 16 lanes stride the tap list, fixed butterfly.
+    const int sub = threadIdx.x & (ROI_SUB - 1), grp = threadIdx.x / ROI_SUB;
+    for (int ip = grp; ip < n_pix; ip += 256 / ROI_SUB) {
+        int k0[4], lim[4];
+        const int p = pix[ip];
+        const int total = ranges(p, k0, lim);
+        if (total <= ROI_SEQ) continue;
         for (int ci = 0; ci < nc; ++ci) {
-            const int c = c0 + ci;
             float acc = 0.f;
-            for (int m = sub; m < total; m += ROI_SUB) {
-                const int t = (m >= lim[0]) + (m >= lim[1]) + (m >= lim[2]);
-                const int k = t == 0 ? k0[0] + m : t == 1 ? k0[1] + m - lim[0] : t == 2 ? k0[2] + m - lim[1] : k0[3] + m - lim[2];
-                float dv, h_ratio, w_ratio;
-                if (staged) {
-                    const int4 g = s_smp[k];
-                    h_ratio = __int_as_float(g.y); w_ratio = __int_as_float(g.z);
-                    dv = s_g[(g.x * nc + ci) * S + (g.w & 255)];
-                } else {
-                    const int4 g = smp[sorted[k]];
-                    h_ratio = __int_as_float(g.y); w_ratio = __int_as_float(g.z);
-                    dv = top_grad[((size_t)(g.w >> 8) * C + c) * S + (g.w & 255)];
-                }
-                acc += roi_tap_value(dv, h_ratio, w_ratio, t);
-            }
+            for (int m = sub; m < total; m += ROI_SUB) acc += tap(m, k0, lim, ci, c0 + ci);
 #pragma unroll
             for (int o = ROI_SUB / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-            if (sub == 0) bottom_grad[((size_t)b * C + c) * HW + p] += acc;
+            if (sub == 0) bottom_grad[((size_t)b * C + c0 + ci) * HW + p] += acc;
         }
     }
 }

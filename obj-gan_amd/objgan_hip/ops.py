@@ -233,7 +233,8 @@ _REC = {"on": _os.environ.get("OBJGAN_H2_RECORDS", "1") != "0",
         # Built and measured in round 6: bit-identical, and NOT faster -- the pair pass costs more than the in-loop split of
         # dy it removes (every eligible weight gradient on records: 137.0 ms per step with the in-loop split, 138.6 with the
         # pair, profiles/r06_ab_variants.txt): the record kernel is bound by its LDS fragment reads, not by the VALU.  Off.
-        "wgrad_math": 6 if _os.environ.get("OBJGAN_REC_WGRAD_DYP", "0") == "1" else 5,
+        # 7: two column groups per wave (conv_wgrad_rec2_kernel)
+        "wgrad_math": int(_os.environ.get("OBJGAN_REC_WGRAD_MATH", "6" if _os.environ.get("OBJGAN_REC_WGRAD_DYP", "0") == "1" else "5")),
         "min_i": float(_os.environ.get("OBJGAN_REC_MIN_I", "2500")),
         "min_i_short": float(_os.environ.get("OBJGAN_REC_MIN_I_SHORT", "1200"))}
 

@@ -843,7 +843,7 @@ def test_weight_gradient_on_presplit_dy_equals_the_in_loop_split_bit_for_bit(dev
     ops._REC["wgrad"] = "all"
     outs = {}
     try:
-        for wm in (6, 5, 0):
+        for wm in (6, 7, 5, 0):
             ops._REC["wgrad_math"] = wm if wm else 5
             ops.set_h2_records(wm != 0)
             xd, wd = x.clone().requires_grad_(), w.clone().requires_grad_()
@@ -859,6 +859,8 @@ def test_weight_gradient_on_presplit_dy_equals_the_in_loop_split_bit_for_bit(dev
     assert torch.isfinite(outs[6]).all()
     assert torch.equal(outs[6], outs[5]), rel_l2(outs[6], outs[5])
     assert rel_l2(outs[6], outs[0]) < 5e-6
+    # two column groups per wave (math 7): the same products per column, other block rows / pixel splits
+    assert torch.isfinite(outs[7]).all() and rel_l2(outs[7], outs[0]) < 5e-6, rel_l2(outs[7], outs[0])
 
 
 def test_h2_records_layout_and_split(dev):

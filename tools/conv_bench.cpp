@@ -88,8 +88,8 @@ int main(int argc, char** argv) {
         float* mxx; float* mxg;          // math 4 (fp16x2): per-workgroup maxima of x and of dy (objgan_absmax_partials)
         CK(hipMalloc(&mxx, 1024 * 4)); CK(hipMalloc(&mxg, 1024 * 4));
         float *recx = nullptr, *recg = nullptr;   // math 5: the fp16 records of x and dy
-        const int wmath = g_math == 6 ? 6 : 5;          // math 6: as 5, the weight gradient ALSO reads dy as its fp16 pair
-        if (g_math == 6) g_math = 5;
+        const int wmath = g_math >= 6 ? g_math : 5;     // math 6: as 5, the weight gradient ALSO reads dy as its fp16 pair; 7: two column groups per wave
+        if (g_math >= 6) g_math = 5;
         const int kmath = g_math == 5 ? 4 : g_math;     // arithmetic of the calls that have no record form
         if (g_math == 5) {
             CK(hipMalloc(&recx, objgan_h2_records_floats(sh.N, sh.Cin, (long)sh.H * sh.W) * 4));
