@@ -617,7 +617,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_rec2_kernel(const WgradArgs a,
                 const f16x8 bl = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                 for (int i = 0; i < TM; ++i) OG_MFMA_H(al[i], bh, acc[j][i]);
-                if (h == 1 && j == 0) {       // the refill behind the first TM MFMAs of the second half
+                if (h == 1 && j == NCG - 1) { // the refill of the (single-buffered, wave-private) x images: behind the LAST
+                                              // transposing reads of this iteration -- the second half of the last group
                     __builtin_amdgcn_sched_barrier(0);
                     mid();
                     __builtin_amdgcn_sched_barrier(0);

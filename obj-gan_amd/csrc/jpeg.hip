@@ -5,14 +5,16 @@
 // fancy upsampling, RGB output).  Here the file BYTES cross PCIe and the image is decoded on the device, bit for bit what
 // Pillow returns, in three kernels:
 //
-//   jpeg_entropy_kernel   one 64-lane workgroup per image.  The Huffman-coded scan is a serial bit stream (no restart markers
+//   jpeg_entropy_kernel   The Huffman-coded scan is a serial bit stream (no restart markers
 //                         in ordinary files): a file seen for the FIRST time is walked by one lane -- JPEG Annex F /
 //                         jdhuff.c decode_mcu: 9-bit look-ahead table, canonical-code walk for longer codes, DC prediction,
 //                         EOB / ZRL, restart intervals; tables and a per-lane 128-byte window of the file in LDS -- and on the
 //                         way the lane records its state (byte position, bit accumulator, DC predictors) at every MCU-row
 //                         start: the file's ENTROPY INDEX (48 bytes per MCU row).  A training set is decoded once per epoch,
 //                         so from the second epoch on the file arrives with its index and every MCU row is decoded by its own
-//                         lane (60 rows of a 640 x 480 image at once).  Same state machine, same state: bit-identical.
+//                         lane (the 60 rows of a 640 x 480 image at once, four decoding lanes per wave: lanes of one wave that
+//                         walk different bit streams serialise on every data-dependent branch).  Same state machine, same
+//                         state: bit-identical.
 //                         Output: quantised coefficients, int16 [block][64] in natural order, written sparsely into a
 //                         zero-filled buffer.
 //   jpeg_idct_kernel      one thread per 8 x 8 block: de-quantisation and the accurate integer inverse DCT of jidctint.c
@@ -68,6 +70,7 @@ __constant__ int c_zigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 1
 // segment (state: start of the scan) walked by one lane, which writes the state at every MCU-row start into the file's
 // INDEX as it passes; a file that comes with its index is decoded by up to 64 lanes at once, one MCU row each.
 #define OG_WIN 128                     // bytes of the file each lane holds in LDS (refilled by the lane itself, 16-byte loads)
+#define OG_JPEG_LPW 4                  // decoding lanes per wave (see the kernel)
 
 struct JpegSeg {                       // decoder state in front of MCU `mcu` (48 bytes)
     unsigned long long acc;            // bit accumulator (the low `nbits` bits are the unread bits)
@@ -171,6 +174,7 @@ __global__ __launch_bounds__(64) void jpeg_entropy_kernel(const unsigned char* _
     __shared__ unsigned char zz[64];
     const JpegDesc& d = descs[blockIdx.x];
     if (d.reason != 0) return;
+    if ((int)blockIdx.y * OG_JPEG_LPW >= (d.nseg > 0 ? d.nseg : 1)) return;     // (grid.y is sized for the image with most rows)
     const int lane = threadIdx.x;
     const unsigned char* file = files + d.file_offset;
     // Huffman tables used by the components (at most two DC + two AC in one scan; components that share ids share a slot)
@@ -212,7 +216,12 @@ __global__ __launch_bounds__(64) void jpeg_entropy_kernel(const unsigned char* _
     const int nseg = d.nseg > 0 ? d.nseg : 1;
     JpegSeg* iout = seg_out ? seg_out + d.idx_offset : nullptr;
 
-    for (int sg = lane; sg < nseg; sg += 64) {
+    // OG_JPEG_LPW lanes of a wave decode (one segment each): lanes of one wave walk DIFFERENT bit streams, and every
+    // data-dependent branch of the decoder serialises them -- measured with 60 rows on the 64 lanes of one wave: 13 ms per
+    // batch of sixteen 640 x 480 files, little better than the 60 rows one after the other; a few lanes per wave and many
+    // waves (blockIdx.y) spread the rows over the CUs instead
+    const int sg = (int)blockIdx.y * OG_JPEG_LPW + lane;
+    if (lane < OG_JPEG_LPW && sg < nseg) {
         BitReader br;
         br.file = file; br.win = wins + lane * OG_WIN; br.wbase = -OG_WIN; br.nbytes = d.nbytes;
         int pred[OG_JPEG_MAXC] = {0, 0, 0};
@@ -656,7 +665,9 @@ int objgan_jpeg_decode(const unsigned char* files, const void* descs_host, const
     short* coef = reinterpret_cast<short*>(ws);
     unsigned char* planes = reinterpret_cast<unsigned char*>(ws);
     if (hipMemsetAsync(coef, 0, (size_t)blocks * 128, s) != hipSuccess) return og_launch_status();
-    hipLaunchKernelGGL(jpeg_entropy_kernel, dim3(n), dim3(64), 0, s, files, dd, coef,
+    int max_seg = 1;
+    for (int i = 0; i < n; ++i) max_seg = h[i].nseg > max_seg ? h[i].nseg : max_seg;
+    hipLaunchKernelGGL(jpeg_entropy_kernel, dim3(n, og_cdiv(max_seg, OG_JPEG_LPW)), dim3(64), 0, s, files, dd, coef,
                        reinterpret_cast<const JpegSeg*>(index_in), reinterpret_cast<JpegSeg*>(index_out));
     hipLaunchKernelGGL(jpeg_idct_kernel, dim3(og_cdiv(max_blocks, 256), n), dim3(256), 0, s, dd, coef, planes, (int)max_blocks);
     hipLaunchKernelGGL(jpeg_color_kernel, dim3(og_cdiv(max_quads, 256), n), dim3(256), 0, s, dd, planes, out, (int)max_quads);
