@@ -56,50 +56,6 @@ __global__ __launch_bounds__(256) void h2_records_kernel(const float* __restrict
     }
 }
 
-// The same pass for HW % 4 == 0 (every map of the hot path): 64 channels x 128 pixels per workgroup, the fp32 rows fetched
-// as 16-byte pieces (512 contiguous bytes per 32 lanes, a quarter of the load instructions of the dword form above; round 5
-// measured the dword form at 3.4 TB/s of 8).  Same values, same conversions: bit-identical records.
-__global__ __launch_bounds__(256) void h2_records4_kernel(const float* __restrict__ x, const float* __restrict__ xmax,
-                                                          _Float16* __restrict__ out, int C, int HW, int Cp) {
-    __shared__ __attribute__((aligned(16))) float tile[64][132];
-    og_fp16_saturate();
-    const float xs = og_pow2(og_h2_exponent(xmax, threadIdx.x & 63));
-    const int n = blockIdx.z;
-    const int p0 = blockIdx.x * 128, c0 = blockIdx.y * 64;
-    const int q = threadIdx.x & 31, ty = threadIdx.x >> 5;             // 16-byte piece of the row; row of an 8-row pass
-    const float* xn = x + (size_t)n * C * HW;
-    f32x4 v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = c0 + ty + 8 * i, p = p0 + 4 * q;
-        v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (c < C && p < HW) v[i] = *reinterpret_cast<const f32x4*>(xn + (size_t)c * HW + p);     // (HW % 4 == 0: whole pieces)
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(&tile[ty + 8 * i][4 * q]) = v[i];
-    __syncthreads();
-    const int cg = threadIdx.x >> 5;                   // 8 channels = one 16-byte store per piece
-    if (c0 + cg * 8 >= Cp) return;
-    const int chunk = (c0 + cg * 8) >> 4, half = cg & 1;
-    _Float16* oh = out + ((size_t)n * (Cp / 16) + chunk) * 2 * (size_t)HW * 16 + half * 8;
-    _Float16* ol = oh + (size_t)HW * 16;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int pp = (threadIdx.x & 31) + 32 * it;
-        const int p = p0 + pp;
-        if (p >= HW) continue;
-        f16x8 h, l;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float sv = tile[cg * 8 + j][pp] * xs;
-            h[j] = (_Float16)sv;
-            l[j] = (_Float16)og_sub(sv, (float)h[j]);
-        }
-        *reinterpret_cast<f16x8*>(oh + (size_t)p * 16) = h;
-        *reinterpret_cast<f16x8*>(ol + (size_t)p * 16) = l;
-    }
-}
-
 // launch of the record-reading instances (called by run_igemm2 in conv_igemm.hip)
 int og_launch_igemm3_rec(const IgemmArgs& a, int TM, int nw, int ng, dim3 grid, hipStream_t s) {
 #define OG_REC(TMv, NGv)                                                                                              \
@@ -736,12 +692,10 @@ int objgan_h2_records(const float* x, const float* xmax, void* rec, int N, int C
     if (N <= 0 || C <= 0 || HW <= 0) return OG_OK;
     const int Cp = (C + 15) / 16 * 16;
     if ((double)N * Cp * (double)HW * 4.0 >= 4.0e9 || N > 65535) return OG_BAD_ARGS;
-    if (HW % 4 == 0 && HW >= 128 && !((size_t)x & 15))
-        hipLaunchKernelGGL(h2_records4_kernel, dim3(og_cdiv(HW, 128), og_cdiv(Cp, 64), N), dim3(256), 0, (hipStream_t)stream,
-                           x, xmax, reinterpret_cast<_Float16*>(rec), C, (int)HW, Cp);
-    else
-        hipLaunchKernelGGL(h2_records_kernel, dim3(og_cdiv(HW, 64), og_cdiv(Cp, 64), N), dim3(256), 0, (hipStream_t)stream,
-                           x, xmax, reinterpret_cast<_Float16*>(rec), C, (int)HW, Cp);
+    // (round 6 tried 64 x 128 tiles fetched as 16-byte pieces: 7.8 ms per step against 7.0 for this form in the same profile
+    //  -- the larger LDS tile halves the workgroups per CU; rejected, profiles/r06_ab_variants.txt)
+    hipLaunchKernelGGL(h2_records_kernel, dim3(og_cdiv(HW, 64), og_cdiv(Cp, 64), N), dim3(256), 0, (hipStream_t)stream,
+                       x, xmax, reinterpret_cast<_Float16*>(rec), C, (int)HW, Cp);
     return og_launch_status();
 }
 

@@ -376,107 +376,6 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
     }
 }
 
-// Dense form for maps of at most ROI_DENSE_HW pixels (the 64 x 64 maps of the hot path).  The gather kernel above ends every
-// (pixel, channel) element with a 4-byte read-modify-write of bottom_grad at a scattered address -- ~10 M of them per launch
-// when the boxes spread their samples over the map: 100 us, bound by 32-byte sectors that carry 4 useful bytes.  Here a
-// workgroup builds the gradient planes of its 4 channels in LDS (one writer per element, plain LDS stores) and adds them to
-// bottom_grad as whole planes with 16-byte accesses.  Same taps, same per-element order as the gather kernel: identical sums.
-#define ROI_DENSE_HW 4096
-#define ROI_DENSE_C 4
-#define ROI_DENSE_G 2048
-__global__ __launch_bounds__(256) void roi_align_bwd_dense_kernel(
-    const float* __restrict__ top_grad, const int* __restrict__ ws, float* __restrict__ bottom_grad,
-    int C, int HW, int W, int S, RoiTabDims d) {
-    __shared__ __attribute__((aligned(16))) float s_plane[ROI_DENSE_C * ROI_DENSE_HW];
-    __shared__ int4 s_smp[ROI_LDS_SMP];
-    __shared__ float s_g[ROI_DENSE_G];
-    __shared__ int s_start[ROI_DENSE_HW + 4];
-    const int b = blockIdx.y;
-    const int* hdr = ws + (size_t)b * d.stride;
-    const int* pix = hdr + 4;
-    const int* start = hdr + d.o_start;
-    const int* sorted = hdr + d.o_sorted;
-    const int4* smp = reinterpret_cast<const int4*>(hdr + d.o_smp);
-    const int* rlist = hdr + d.o_rlist;
-    const int n_pix = hdr[0], n_e = hdr[1], nlist = hdr[3];
-    const int c0 = blockIdx.x * ROI_DENSE_C;
-    const int nc = min(ROI_DENSE_C, C - c0);
-    if (n_pix == 0) return;                                                         // no roi in this image: nothing to add
-    const bool staged = n_e <= ROI_LDS_SMP && nlist * nc * S <= ROI_DENSE_G;        // (uniform over the workgroup)
-    for (int i = threadIdx.x; i < nc * HW; i += 256) s_plane[i] = 0.f;
-    if (staged) {
-        for (int k = threadIdx.x; k < n_e; k += 256) s_smp[k] = smp[sorted[k]];
-        const int per = nc * S;
-        for (int i = threadIdx.x; i < nlist * per; i += 256) {
-            const int kl = i / per, j = i - kl * per;
-            s_g[i] = top_grad[((size_t)rlist[kl] * C + c0) * S + j];
-        }
-    }
-    for (int i = threadIdx.x; i <= HW; i += 256) s_start[i] = start[i];
-    __syncthreads();
-    auto ranges = [&](int p, int (&k0)[4], int (&lim)[4]) -> int {
-        int total = 0;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int q = p - (t & 1) - (t >> 1) * W;
-            const int s0 = q >= 0 ? s_start[q] : 0;
-            const int s1 = q >= 0 ? s_start[q + 1] : 0;
-            k0[t] = s0;
-            total += s1 - s0;
-            lim[t] = total;
-        }
-        return total;
-    };
-    auto tap = [&](int m, const int (&k0)[4], const int (&lim)[4], int ci, int c) -> float {
-        const int t = (m >= lim[0]) + (m >= lim[1]) + (m >= lim[2]);
-        const int k = t == 0 ? k0[0] + m : t == 1 ? k0[1] + m - lim[0] : t == 2 ? k0[2] + m - lim[1] : k0[3] + m - lim[2];
-        float dv, h_ratio, w_ratio;
-        if (staged) {
-            const int4 g = s_smp[k];
-            h_ratio = __int_as_float(g.y); w_ratio = __int_as_float(g.z);
-            dv = s_g[(g.x * nc + ci) * S + (g.w & 255)];
-        } else {
-            const int4 g = smp[sorted[k]];
-            h_ratio = __int_as_float(g.y); w_ratio = __int_as_float(g.z);
-            dv = top_grad[((size_t)(g.w >> 8) * C + c) * S + (g.w & 255)];
-        }
-        return roi_tap_value(dv, h_ratio, w_ratio, t);
-    };
-    for (int e = threadIdx.x; e < n_pix * nc; e += 256) {                           // few taps: one lane per element
-        const int ci = e / n_pix, ip = e - ci * n_pix;
-        int k0[4], lim[4];
-        const int p = pix[ip];
-        const int total = ranges(p, k0, lim);
-        if (total > ROI_SEQ) continue;
-        float acc = 0.f;
-        for (int m = 0; m < total; ++m) acc += tap(m, k0, lim, ci, c0 + ci);
-        s_plane[ci * HW + p] = acc;
-    }
-    const int sub = threadIdx.x & (ROI_SUB - 1), grp = threadIdx.x / ROI_SUB;       // many taps: 16 lanes per element
-    for (int ip = grp; ip < n_pix; ip += 256 / ROI_SUB) {
-        int k0[4], lim[4];
-        const int p = pix[ip];
-        const int total = ranges(p, k0, lim);
-        if (total <= ROI_SEQ) continue;
-        for (int ci = 0; ci < nc; ++ci) {
-            float acc = 0.f;
-            for (int m = sub; m < total; m += ROI_SUB) acc += tap(m, k0, lim, ci, c0 + ci);
-#pragma unroll
-            for (int o = ROI_SUB / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-            if (sub == 0) s_plane[ci * HW + p] = acc;
-        }
-    }
-    __syncthreads();
-    // whole planes into bottom_grad (HW % 4 == 0: checked by the host), 16 bytes per lane
-    float* dst = bottom_grad + ((size_t)b * C + c0) * HW;
-    for (int i = threadIdx.x * 4; i < nc * HW; i += 256 * 4) {
-        float4 v = *reinterpret_cast<const float4*>(dst + i);
-        const float4 a4 = *reinterpret_cast<const float4*>(s_plane + i);
-        v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
-        *reinterpret_cast<float4*>(dst + i) = v;
-    }
-}
-
 // ---- 2x2 stride-1 average pool over the last two dims (RoIAlignAvg tail) ------------
 // in: [P, IH, IW] -> out: [P, IH-1, IW-1]
 __global__ __launch_bounds__(256) void avgpool2s1_fwd_kernel(
@@ -597,12 +496,9 @@ int objgan_roi_align_backward_ordered(const float* top_grad, const float* rois, 
     hipLaunchKernelGGL(roi_tap_table_kernel, dim3(batch_size), dim3(256), lds, (hipStream_t)stream,
                        rois, reinterpret_cast<int*>(ws), num_rois, channels, height, width,
                        aligned_height, aligned_width, spatial_scale, d);
-    if (HW <= ROI_DENSE_HW && HW % 4 == 0 && !((size_t)bottom_grad & 15)) {
-        hipLaunchKernelGGL(roi_align_bwd_dense_kernel, dim3(og_cdiv(channels, ROI_DENSE_C), batch_size), dim3(256), 0,
-                           (hipStream_t)stream, top_grad, reinterpret_cast<const int*>(ws), bottom_grad,
-                           channels, HW, width, S, d);
-        return og_launch_status();
-    }
+    // (round 6 also built a dense form -- the slab's gradient planes in LDS, added to bottom_grad as whole planes with 16-byte
+    //  accesses: 292 us per launch against 101 for the gather kernel, one workgroup per CU and 200 MB of plane traffic;
+    //  removed, profiles/r06_ab_variants.txt (f))
     const int cpb = channels >= 64 ? 8 : 1;
     hipLaunchKernelGGL(roi_align_bwd_gather_kernel, dim3(og_cdiv(channels, cpb), batch_size), dim3(256), 0,
                        (hipStream_t)stream, top_grad, reinterpret_cast<const int*>(ws), bottom_grad,
