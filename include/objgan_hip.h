@@ -166,7 +166,12 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
  * half records and transpose them through LDS (ds_read_b64_tr_b16) instead of gathering 32 (channel, tap) planes per
  * wave from the fp32 tensor and splitting on the VALU.  Same products per 16-pixel step as math 4 (fp32 results; the
  * pixel splits differ, so the two are equal up to summation order).  Only where objgan_conv_wgrad_rec_ok says so
- * (OH * OW % 32 == 0, OH, OW <= 256, (H - 1) * W < 65535). */
+ * (OH * OW % 32 == 0, OH, OW <= 256, (H - 1) * W < 65535).
+ * math 6 (round 6): as 5, and dy is ALSO read pre-split -- its fp16 pair (plane h, plane l, same layout) is written into
+ * the workspace by one pass and the K loop carries no operand split; bit-identical to math 5.  math 7 (round 6): as 5 with
+ * two (tap, 32-channel) column groups per wave and block rows of at most 128 rows (launches of fewer than 16 384 pixels
+ * take math 5's kernel).  Both measured no faster in the training step (profiles/r06_ab_variants.txt): kept for the
+ * record, not used by the Python layer's default. */
 int objgan_conv_wgrad_rec_ok(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ksize);
 
 /* ---- frozen text encoder (reference model.py:85-179 RNN_ENCODER: Embedding + bidirectional LSTM on

@@ -452,7 +452,7 @@ class condGANTrainer(object):
     # during the generator's forward pass; off by default, profiles/r06_ab_variants.txt)
     hoist_real_passes = os.environ.get("OBJGAN_HOIST_REAL", "0") == "1"
     # fp16x2 run-time guard: every `h2_guard_every` iterations (and on the first) one step is a checked step (0: never)
-    h2_guard_every = 500
+    h2_guard_every = int(os.environ.get("OBJGAN_H2_GUARD_EVERY", "500"))     # (profiling recipes set 0: a checked step syncs)
 
     def _graphed(self, attr):
         import encoders

@@ -409,3 +409,46 @@ def test_bench_traffic_lookup_resolves_category_patterns():
     assert pmc["conv_math"] == "fp16x2" and pmc["per_gpu_batch"] == 16
     assert bench.pmc_lookup(pmc["kernels"], "conv_wgrad3_kernel<6, 4, *, 0, 8>") > 0
     assert bench.pmc_lookup(pmc["kernels"], "conv_igemm3_kernel<7, false, 5, 8, 1>") > 0
+
+
+def test_graphed_callable_runs_eagerly_where_nothing_can_be_captured():
+    """objgan_hip.graphs.GraphedCallable is an optimisation of the issue path: on a CPU tensor, with graphs switched off, or
+    under a checked step of the fp16x2 guard (host syncs) it calls the wrapped chain directly -- same results, no capture;
+    attribute access falls through to the wrapped callable."""
+    from objgan_hip import graphs, ops
+
+    class Chain(object):
+        nef = 7
+
+        def __call__(self, x):
+            return (x * 2.0, x.sum(1))
+    wrapped = graphs.GraphedCallable(Chain(), name="chain")
+    x = torch.randn(3, 5, requires_grad=True)
+    before = graphs.stats()
+    a, b = wrapped(x)
+    assert torch.equal(a, x * 2.0) and torch.equal(b, x.sum(1)) and wrapped.nef == 7
+    prev = graphs.enabled()
+    graphs.enable(False)
+    try:
+        assert torch.equal(wrapped(x)[0], x * 2.0)
+    finally:
+        graphs.enable(prev)
+    ops.h2_guard_begin()
+    try:
+        assert torch.equal(wrapped(x)[0], x * 2.0)
+    finally:
+        assert ops.h2_guard_end() == []
+    after = graphs.stats()
+    assert after["captures"] == before["captures"] and after["replays"] == before["replays"]
+
+
+def test_jpeg_index_cache_keys_on_file_identity():
+    """ops.JpegIndexCache: an entry is used only for a file of the same byte count and row count (a re-written bigfile under
+    the same key must not be decoded from a stale index)."""
+    from objgan_hip import ops
+    cache = ops.JpegIndexCache()
+    idx = torch.zeros(3 * 48, dtype=torch.uint8)
+    cache.put("a", 1000, idx)
+    assert cache.get("a", 1000, 3, 48) is idx and cache.hits == 1
+    assert cache.get("a", 1001, 3, 48) is None and cache.get("a", 1000, 4, 48) is None and cache.get("b", 1000, 3, 48) is None
+    assert cache.misses == 3

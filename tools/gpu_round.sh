@@ -26,11 +26,11 @@ opsrc) ( timeout 600 python tools/op_sources.py ) > gpurun_out/${TAG}_opsrc.txt 
 benchenv) ( time env $OG_ENV timeout 600 python bench.py --steps 8 --warmup 2 --no-cpu-baseline ) > gpurun_out/${TAG}_benchenv.log 2>&1; tail -3 gpurun_out/${TAG}_benchenv.log | cut -c1-400 ;;
 profenv) cd /tmp && env $OG_ENV timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_profenv -o prof -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing > $R/gpurun_out/${TAG}_profenv.log 2>&1
   cd $R; find gpurun_out/${TAG}_profenv -type f ! -name '*stats*' -size +1M -delete ;;
-prof1) cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof1 -o prof -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --d-streams 1 > $R/gpurun_out/${TAG}_prof1.log 2>&1
+prof1) cd /tmp && OBJGAN_H2_GUARD_EVERY=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof1 -o prof -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --d-streams 1 > $R/gpurun_out/${TAG}_prof1.log 2>&1
   cd $R; find gpurun_out/${TAG}_prof1 -type f ! -name '*stats*' -size +1M -delete ;;
 prof) cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof -o prof -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing > $R/gpurun_out/${TAG}_prof.log 2>&1
   cd $R; find gpurun_out/${TAG}_prof -type f | head; find gpurun_out/${TAG}_prof -type f ! -name '*stats*' -size +1M -delete ;;
-timeline) cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_tl -o tl -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing > $R/gpurun_out/${TAG}_tl.log 2>&1
+timeline) cd /tmp && OBJGAN_H2_GUARD_EVERY=0 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_tl -o tl -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing > $R/gpurun_out/${TAG}_tl.log 2>&1
   cd $R; python tools/timeline.py gpurun_out/${TAG}_tl 4 100 | tee gpurun_out/${TAG}_timeline.txt; python tools/timeline.py gpurun_out/${TAG}_tl 4 30 | tee -a gpurun_out/${TAG}_timeline.txt
   find gpurun_out/${TAG}_tl -type f -size +40M -delete ;;
 esac; done

@@ -9,7 +9,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   s=$(echo $c | cut -d_ -f1 | tr A-Z a-z)
   timeout 120 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/${TAG}_pmc_cal_$s -o pmc -- $R/tools/pmc_calib > $R/gpurun_out/${TAG}_pmc_cal_$s.log 2>&1
   d=$R/gpurun_out/${TAG}_pmc_$s
-  timeout 400 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "conv_igemm3_kernel|conv_wgrad" --output-format csv -d $d -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-is-monitor --d-streams 1 > $d.log 2>&1
+  OBJGAN_H2_GUARD_EVERY=0 timeout 400 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "conv_igemm3_kernel|conv_wgrad" --output-format csv -d $d -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-is-monitor --d-streams 1 > $d.log 2>&1
   find $d -type f -name '*kernel_trace*' -size +3M -delete
 done
 cd $R; python tools/pmc_traffic.py gpurun_out/${TAG} gpurun_out/${TAG}_pmc_traffic.json > gpurun_out/${TAG}_pmc_traffic.log 2>&1

@@ -8,6 +8,6 @@ TAG=$1; R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p $R/gpurun_out; cd /tmp
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1)); d=/tmp/${TAG}_pmcstep$i
-  timeout 400 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $d -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --d-streams 1 > $R/gpurun_out/${TAG}_pmcstep$i.log 2>&1
+  OBJGAN_H2_GUARD_EVERY=0 timeout 400 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $d -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --d-streams 1 > $R/gpurun_out/${TAG}_pmcstep$i.log 2>&1
 done
 cd $R; python tools/pmc_step.py /tmp/${TAG}_pmcstep gpurun_out/${TAG}_pmcstep.json
