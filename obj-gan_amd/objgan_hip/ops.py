@@ -986,28 +986,28 @@ class _UpConv3x3Fn(torch.autograd.Function):
         return dx, dw_
 
 
-_WSLICE = {}        # (weight address, shape, lo, hi) -> [w, _version, epoch, slice copy]
-
-
 def _w_slice(w, lo, hi):
     """contiguous copy of w[:, lo:hi] kept while the weights are unchanged (rebuilt IN PLACE when they changed, so that
     its packed banks stay cached as well -- `_up_bank` does the same for the pre-summed up-convolution bank): the
     per-input data gradients of conv2d_cat packed their slice's bank on every call (80 pack launches per training step).
+    The cache lives ON the weight object (a process-wide table keyed on the address pinned dead weights and their
+    slices until it overflowed): it dies with the weight.
     -> (slice, cacheable)"""
     ep = getattr(w, "_og_epoch", None)
     if ep is None and w.requires_grad:
         return w[:, lo:hi].contiguous(), False
-    key = (w.data_ptr(), tuple(w.shape), lo, hi)
-    ent = _WSLICE.get(key)
+    try:
+        cache = w.__dict__.setdefault("_og_wslices", {})
+    except AttributeError:
+        return w[:, lo:hi].contiguous(), False
+    ent = cache.get((lo, hi))
     epv = ep[0] if ep is not None else -1
-    if ent is not None and ent[0] is w and ent[1] == w._version and ent[2] == epv:
-        return ent[3], True
-    ws = ent[3] if ent is not None and ent[0] is w else torch.empty(
+    if ent is not None and ent[0] == w._version and ent[1] == epv and ent[3] == w.data_ptr():
+        return ent[2], True
+    ws = ent[2] if (ent is not None and ent[3] == w.data_ptr()) else torch.empty(
         (w.shape[0], hi - lo) + tuple(w.shape[2:]), dtype=_F32, device=w.device)
     ws.copy_(w.detach()[:, lo:hi])                      # in place: bumps ws._version
-    if len(_WSLICE) >= 256:
-        _WSLICE.clear()
-    _WSLICE[key] = [w, w._version, epv, ws]
+    cache[(lo, hi)] = [w._version, epv, ws, w.data_ptr()]
     return ws, True
 
 
