@@ -80,12 +80,12 @@ PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
 def csrc_hash():
-    """sha256 (16 hex digits) over obj-gan_amd/csrc/*.hip, *.h: the key of the committed counter passes (tools/pmc_traffic.py)"""
+    """sha256 (16 hex digits) over the convolution kernel sources (obj-gan_amd/csrc/conv_igemm*, common.h): the key of the committed counter passes (tools/pmc_traffic.py)"""
     import hashlib
     root = os.path.join(ROOT, "obj-gan_amd", "csrc")
     h = hashlib.sha256()
     for f in sorted(os.listdir(root)):
-        if f.endswith((".hip", ".h")):
+        if f.startswith("conv_igemm") or f == "common.h":           # the sources of the measured (convolution) kernels
             h.update(f.encode())
             h.update(open(os.path.join(root, f), "rb").read())
     return h.hexdigest()[:16]

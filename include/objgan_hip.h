@@ -334,7 +334,7 @@ int objgan_resize_pil_rgb8(const unsigned char* src, const long* offs, const int
  *                       MCUs per row, MCU rows, restart interval, reason, scan offset}.  Returns 1 for a file the device
  *                       decodes (baseline / sequential Huffman, 8 bit, one interleaved scan, grey or YCbCr 4:4:4 / 4:2:2 /
  *                       4:2:0) and 0 with reason != 0 for anything else (1 not JPEG, 2 progressive / arithmetic / lossless,
- *                       3 precision, 4 components, 5 sampling, 6 scan, 7 tables, 8 truncated): the caller routes that file
+ *                       3 precision, 4 components, 5 sampling, 6 scan, 7 tables, 8 truncated, 9 RGB-coded): the caller routes that file
  *                       to its host decoder knowingly.
  * objgan_jpeg_plan      HOST ONLY.  Lays a batch out: descs[i] gets its file's byte offset in the batch buffer
  *                       (file_offsets[i], multiples of 16), its output byte offset, its workspace slices and the slice of

@@ -482,7 +482,7 @@ long objgan_jpeg_desc_bytes(void) { return (long)sizeof(JpegDesc); }
 
 // Reasons objgan_jpeg_parse refuses a file (JpegDesc::reason)
 enum { OG_JPEG_OK = 0, OG_JPEG_NOT_JPEG = 1, OG_JPEG_PROGRESSIVE = 2, OG_JPEG_PRECISION = 3, OG_JPEG_COMPONENTS = 4,
-       OG_JPEG_SAMPLING = 5, OG_JPEG_SCAN = 6, OG_JPEG_TABLES = 7, OG_JPEG_TRUNCATED = 8 };
+       OG_JPEG_SAMPLING = 5, OG_JPEG_SCAN = 6, OG_JPEG_TABLES = 7, OG_JPEG_TRUNCATED = 8, OG_JPEG_COLORSPACE = 9 };
 
 int objgan_jpeg_parse(const unsigned char* f, long n, void* desc_out) {
     JpegDesc& d = *reinterpret_cast<JpegDesc*>(desc_out);
@@ -492,6 +492,8 @@ int objgan_jpeg_parse(const unsigned char* f, long n, void* desc_out) {
          have_ac[4] = {false, false, false, false};
     int cid[OG_JPEG_MAXC] = {0, 0, 0};
     bool have_sof = false;
+    bool saw_jfif = false, saw_adobe = false;          // colour-space guess of libjpeg (jdapimin.c default_decompress_parms)
+    int adobe_transform = 1;
 #define OG_REFUSE(why) do { d.reason = (why); return OG_BAD_ARGS; } while (0)
     if (n < 4 || f[0] != 0xFF || f[1] != 0xD8) OG_REFUSE(OG_JPEG_NOT_JPEG);
     long pos = 2;
@@ -546,6 +548,13 @@ int objgan_jpeg_parse(const unsigned char* f, long n, void* desc_out) {
             have_sof = true;
         } else if (m == 0xC2 || m == 0xC3 || (m >= 0xC5 && m <= 0xC7) || (m >= 0xC9 && m <= 0xCB) || (m >= 0xCD && m <= 0xCF)) {
             OG_REFUSE(OG_JPEG_PROGRESSIVE);
+        } else if (m == 0xE0) {
+            if (sl >= 5 && s[0] == 'J' && s[1] == 'F' && s[2] == 'I' && s[3] == 'F' && s[4] == 0) saw_jfif = true;
+        } else if (m == 0xEE) {
+            if (sl >= 12 && s[0] == 'A' && s[1] == 'd' && s[2] == 'o' && s[3] == 'b' && s[4] == 'e') {
+                saw_adobe = true;
+                adobe_transform = s[11];
+            }
         } else if (m == 0xDD) {
             if (sl < 2) OG_REFUSE(OG_JPEG_TRUNCATED);
             d.restart_interval = (s[0] << 8) | s[1];
@@ -572,6 +581,13 @@ int objgan_jpeg_parse(const unsigned char* f, long n, void* desc_out) {
                     if (j == na) aid[na++] = d.cta[k];
                 }
                 if (nd > 2 || na > 2) OG_REFUSE(OG_JPEG_TABLES);
+            }
+            if (d.ncomp == 3) {
+                // libjpeg decides the colour space of a three-component file like this: JFIF -> YCbCr; else an Adobe marker with
+                // transform 0 -> RGB (no conversion); else component ids 'R','G','B' -> RGB; else YCbCr.  The device path
+                // converts YCbCr: an RGB-coded file is refused and decoded on the host.
+                const bool rgb_ids = cid[0] == 'R' && cid[1] == 'G' && cid[2] == 'B';
+                if (!saw_jfif && ((saw_adobe && adobe_transform == 0) || (!saw_adobe && rgb_ids))) OG_REFUSE(OG_JPEG_COLORSPACE);
             }
             if (d.ncomp == 1) { d.ch[0] = d.cv[0] = 1; }                   // a single-component scan is never interleaved
             d.hmax = d.vmax = 1;

@@ -1610,7 +1610,7 @@ class JpegUnsupported(_lib.ObjganHipError):
 
     REASONS = {1: "not a JPEG file", 2: "progressive / lossless / arithmetic-coded frame", 3: "sample precision is not 8 bits",
                4: "neither 1 nor 3 components", 5: "unsupported chroma sampling", 6: "non-interleaved or missing scan",
-               7: "missing / oversized table", 8: "truncated file"}
+               7: "missing / oversized table", 8: "truncated file", 9: "RGB-coded (Adobe transform 0 / 'RGB' component ids)"}
 
     def __init__(self, index, reason):
         super().__init__("JPEG %d: %s" % (index, self.REASONS.get(reason, "reason %d" % reason)))

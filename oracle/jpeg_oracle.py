@@ -38,6 +38,8 @@ def parse(data):
         raise Unsupported("no SOI")
     pos = 2
     out = {"qt": {}, "dc": {}, "ac": {}, "restart_interval": 0}
+    saw_jfif = saw_adobe = False
+    adobe_transform = 1
     n = len(data)
     while pos < n:
         if data[pos] != 0xFF:
@@ -80,6 +82,10 @@ def parse(data):
             out["comps"] = [(seg[6 + 3 * c], seg[7 + 3 * c] >> 4, seg[7 + 3 * c] & 15, seg[8 + 3 * c]) for c in range(nc)]
         elif m in (0xC2, 0xC3, 0xC5, 0xC6, 0xC7, 0xC9, 0xCA, 0xCB, 0xCD, 0xCE, 0xCF):
             raise Unsupported("SOF%d (progressive / lossless / arithmetic)" % (m - 0xC0))
+        elif m == 0xE0 and seg[:5] == b"JFIF\x00":
+            saw_jfif = True
+        elif m == 0xEE and seg[:5] == b"Adobe" and len(seg) >= 12:
+            saw_adobe, adobe_transform = True, seg[11]
         elif m == 0xDD:
             out["restart_interval"] = struct.unpack(">H", seg[:2])[0]
         elif m == 0xDA:
@@ -88,6 +94,10 @@ def parse(data):
             out["scan"] = [(ids.index(seg[1 + 2 * k]), seg[2 + 2 * k] >> 4, seg[2 + 2 * k] & 15) for k in range(ns)]
             if ns != len(out["comps"]):
                 raise Unsupported("non-interleaved scans")
+            # libjpeg's colour-space guess (jdapimin.c default_decompress_parms): JFIF -> YCbCr; else Adobe transform 0 -> RGB;
+            # else component ids 'R', 'G', 'B' -> RGB; else YCbCr.  RGB-coded files are outside this restatement.
+            if len(ids) == 3 and not saw_jfif and ((saw_adobe and adobe_transform == 0) or (not saw_adobe and ids == [82, 71, 66])):
+                raise Unsupported("RGB-coded file (no colour transform)")
             out["scan_offset"] = pos + L
             return out
         pos += L

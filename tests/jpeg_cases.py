@@ -52,7 +52,15 @@ def refused():
     """(name, bytes, reason code of objgan_jpeg_parse)"""
     rng = np.random.RandomState(3)
     pic = _picture(rng, 40, 56)
+    plain = _enc(pic, quality=80)
+    # the same file with its JFIF marker replaced by an Adobe marker that says "no colour transform": libjpeg (and Pillow)
+    # then read the three components as R, G, B -- the device path converts YCbCr and must refuse the file
+    i = plain.index(b"\xff\xe0")
+    n = (plain[i + 2] << 8) | plain[i + 3]
+    adobe = b"\xff\xee\x00\x0eAdobe\x00\x64\x00\x00\x00\x00\x00"
+    rgb_coded = plain[:i] + adobe + plain[i + 2 + n:]
     return [("progressive", _enc(pic, quality=80, progressive=True), 2),
+            ("adobe transform 0 (RGB-coded)", rgb_coded, 9),
             ("cmyk", _enc(pic.convert("CMYK"), quality=80), 4),
             ("png bytes", b"\x89PNG\r\n\x1a\n" + bytes(64), 1),
             ("truncated header", _enc(pic, quality=80)[:40], 8)]

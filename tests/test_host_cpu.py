@@ -407,6 +407,8 @@ def test_bench_traffic_lookup_resolves_category_patterns():
     # the committed file answers for the categories the bench line names on the configuration it was collected on
     pmc = json.load(open(bench.PMC_TRAFFIC_JSON))
     assert pmc["conv_math"] == "fp16x2" and pmc["per_gpu_batch"] == 16
+    # (round 6) the counters are keyed on the kernel sources they were collected on; bench.py withholds the figure otherwise
+    assert len(pmc["csrc_sha16"]) == 16 and len(bench.csrc_hash()) == 16
     assert bench.pmc_lookup(pmc["kernels"], "conv_wgrad3_kernel<6, 4, *, 0, 8>") > 0
     assert bench.pmc_lookup(pmc["kernels"], "conv_igemm3_kernel<7, false, 5, 8, 1>") > 0
 

@@ -30,14 +30,14 @@ def load(dirglob, counter):
 
 
 def csrc_hash():
-    """sha256 over the kernel sources the counters were collected on (bench.py prints it in `traffic_source` and drops the
+    """sha256 over the convolution kernel sources (csrc/conv_igemm*, common.h) the counters were collected on (bench.py prints it in `traffic_source` and drops the
     traffic figure when the tree's hash differs: VERDICT r5 item 9)"""
     import hashlib
     import os
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "obj-gan_amd", "csrc")
     h = hashlib.sha256()
     for f in sorted(os.listdir(root)):
-        if f.endswith((".hip", ".h")):
+        if f.startswith("conv_igemm") or f == "common.h":           # the sources of the measured (convolution) kernels
             h.update(f.encode())
             h.update(open(os.path.join(root, f), "rb").read())
     return h.hexdigest()[:16]
