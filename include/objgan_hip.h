@@ -173,6 +173,17 @@ int objgan_conv_wgrad(const float* x, const float* dy, float* dw,
  * take math 5's kernel).  Both measured no faster in the training step (profiles/r06_ab_variants.txt): kept for the
  * record, not used by the Python layer's default. */
 int objgan_conv_wgrad_rec_ok(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ksize);
+/* bf16 mode (math 1, BASELINE config 5) with the operand copy made ONCE per tensor (round 6).  math 1 writes a bf16
+ * channel-blocked copy [N][Cp/16][HW][16] of its pixel operand into the call's workspace on every call: the forward
+ * convolution and the weight gradient of a layer each copy the same x, every branch of an Inception block copies its shared
+ * input (32.9 ms of 216 per B = 32 step were such copies).  objgan_nhwc_bf16 makes that copy on its own
+ * (objgan_nhwc_bf16_floats floats; 0 = too large, stay on math 1), and math 3 is math 1 with `x` pointing to it:
+ * objgan_conv_igemm(..., math = 3) where objgan_conv_bank_layout(..., math = 1) answers class 3, objgan_conv_wgrad(...,
+ * math = 3) where objgan_conv_wgrad_bfb_ok says so (dy is still copied per call).  Same values, same kernels: bit-identical
+ * to math 1. */
+long objgan_nhwc_bf16_floats(int N, int C, long HW);
+int objgan_nhwc_bf16(const float* x, float* out, int N, int C, long HW, void* stream);
+int objgan_conv_wgrad_bfb_ok(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ksize);
 
 /* ---- frozen text encoder (reference model.py:85-179 RNN_ENCODER: Embedding + bidirectional LSTM on
  * a packed sequence).  table [ntoken][I]; captions [B][L] int64; lens [B] int32; wt_ih [2][I][4H] and

@@ -2341,7 +2341,7 @@ static long igemm2_nhwc_floats(int math, int N, int H, int W, int Cp) {
     return ((long)N * H * W * Cp / 2 + 3) & ~3L;
 }
 static long igemm2_ws_floats(const IgemmArgs& a, const Igemm2Plan& p) {
-    const long nh = a.nhwc ? igemm2_nhwc_floats(a.math, a.N, a.H, a.W, a.Cp) : 0;
+    const long nh = a.nhwc == 1 ? igemm2_nhwc_floats(a.math, a.N, a.H, a.W, a.Cp) : 0;
     if (p.splits <= 1 || !p.full_cover) return nh;
     const long seg = (long)a.N * a.M * a.OHf * a.OWf + (a.ring ? (long)a.N * a.M * (2 * a.PW + 2 * a.PH) : 0);
     return nh + seg * p.splits;
@@ -2349,9 +2349,9 @@ static long igemm2_ws_floats(const IgemmArgs& a, const Igemm2Plan& p) {
 
 static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed, float* ws, long ws_floats, float* ymax = nullptr) {
     a.ymax = nullptr;
-    if (a.nhwc && !ws) a.nhwc = 0;              // no workspace: fp32 NCHW gathers (conv_igemm3_kernel<.., 1, ..>)
+    if (a.nhwc == 1 && !ws) a.nhwc = 0;         // no workspace: fp32 NCHW gathers (conv_igemm3_kernel<.., 1, ..>)
     const Igemm2Plan p = igemm2_plan(a, y_prezeroed);
-    if (a.nhwc) {                               // bf16 channel-blocked copy of the source: first part of the workspace
+    if (a.nhwc == 1) {                          // bf16 channel-blocked copy of the source: first part of the workspace
         const long nh = igemm2_nhwc_floats(a.math, a.N, a.H, a.W, a.Cp);
         if (ws_floats < igemm2_ws_floats(a, p)) return OG_BAD_ARGS;
         hipLaunchKernelGGL(nchw_to_nhwc_bf16_kernel, dim3(og_cdiv(a.H * a.W, 64), og_cdiv(a.Cp, 64), a.N), dim3(256), 0, s,
@@ -2373,7 +2373,7 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed, float* ws, lo
     if (splits > 1) {
         a.ksplit_steps = p.ksplit_steps;
         a.bias = nullptr; a.act = OG_ACT_NONE;
-        const long need = igemm2_ws_floats(a, p) - (a.nhwc ? igemm2_nhwc_floats(a.math, a.N, a.H, a.W, a.Cp) : 0);
+        const long need = igemm2_ws_floats(a, p) - (a.nhwc == 1 ? igemm2_nhwc_floats(a.math, a.N, a.H, a.W, a.Cp) : 0);
         if (need > 0) {                       // two-level reduction through the caller's workspace
             if (!ws || ws_floats < need) return OG_BAD_ARGS;
             a.ws = ws; a.ws_stride = y_elems + ring_elems;
@@ -2612,7 +2612,12 @@ static int og_igemm_setup(PackArgs& p, IgemmArgs& a, int& MT, const float* x, co
     if (Tg < 1 || Tg > OG_MAX_TAPS) return OG_BAD_ARGS;
     if (ring && !(osh == 1 && osw == 1 && ooh == 0 && oow == 0 && PH == OHf + 2 && PW == OWf + 2 && !bias && !act))
         return OG_BAD_ARGS;
-    if (math < 0 || math > 5 || math == 3) return OG_BAD_ARGS;
+    if (math < 0 || math > 5) return OG_BAD_ARGS;
+    // math 3 (round 6): the arithmetic of math 1 (bf16-rounded operands) with the pixel operand handed over AS its bf16
+    // channel-blocked copy (objgan_nhwc_bf16) -- the copy of a tensor is made once and serves every convolution that reads it
+    // (the forward call AND the weight gradient of the layer, every branch of an Inception block) instead of once per call
+    const bool copy_in = math == 3;
+    if (copy_in) math = 1;
     if (Torig < 1 || Torig > 127) return OG_BAD_ARGS;
     const int M = transpose ? Cin : Cout;
     const int Ck = transpose ? Cout : Cin;
@@ -2630,6 +2635,10 @@ static int og_igemm_setup(PackArgs& p, IgemmArgs& a, int& MT, const float* x, co
     a.xmax = xmax; a.wmax = p.wmax;
     if (kmath >= 4 && x && !xmax) return OG_BAD_ARGS;      // fp16x2 needs the maxima of its pixel operand (x == NULL: size query)
     a.nhwc = igemm2_nhwc_floats(kmath, N, H, W, p.Cp) > 0 ? 1 : 0;
+    if (copy_in) {
+        if (p.m_major != 3 || !a.nhwc) return OG_BAD_ARGS;    // the bf16 MFMA kernel only (ask objgan_conv_bank_layout: class 3)
+        a.nhwc = 2;                                            // x IS the copy: nothing to make, nothing in the workspace
+    }
     a.Krow = og_krow(a.Kpad, kmath);
     a.m_begin = 0; a.m_end = M;
     a.PH = PH; a.PW = PW; a.OHf = OHf; a.OWf = OWf;
@@ -2869,7 +2878,11 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
     long ws_used = 0;
     if (plan_only) *ws_need = 0;
     if (ksize != 1 && ksize != 3 && ksize != 4) return OG_BAD_ARGS;
-    if (math < 0 || math > 7 || math == 3) return OG_BAD_ARGS;
+    if (math < 0 || math > 7) return OG_BAD_ARGS;
+    // math 3 (round 6): math 1 with x handed over AS its bf16 channel-blocked copy (objgan_nhwc_bf16; usually the one the
+    // forward call of the layer read): only the bf16 copy of dy is made here.  objgan_conv_wgrad_bfb_ok says where.
+    const bool x_copy_in = math == 3;
+    if (x_copy_in) math = 1;
     if (math >= 4 && !plan_only && (!xmax || !dymax)) return OG_BAD_ARGS;
     if (N <= 0 || Cout <= 0 || Cin <= 0) return OG_OK;
     // math 5: x is the fp16 record of the source (conv_igemm_rec.hip), dy the fp32 tensor: conv_wgrad_rec_kernel.  The
@@ -2902,6 +2915,7 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
     const bool v2 = !og_igemm_v1() && (OW % 8 == 0) && (OHW % 16 == 0)
                     && (double)N * Cin * H * W * 4.0 < 4.0e9 && (double)N * Cout * OHW * 4.0 < 4.0e9;
     a.math = math;
+    if (x_copy_in && !v2) return OG_BAD_ARGS;
     if (v2) {
         const bool bf = math == 1, sp = math == 2;
         // bf16 mode: bf16 operands, x from its channel-blocked copy in the workspace (conv_wgrad_bfb_kernel); without a
@@ -2909,7 +2923,8 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
         const int Cpb = (Cin + 15) / 16 * 16;
         bool bfb = bf && OHW % 32 == 0 && OH <= 256 && OW <= 256 && (long)(H - 1) * W < 65535 && ksize <= 4
                    && (double)N * Cpb * H * W * 2.0 < 4.0e9 && (plan_only || ws != nullptr);
-        const long xb_floats = bfb ? (((long)N * H * W * Cpb / 2 + 3) & ~3L) : 0;
+        if (x_copy_in && !bfb) return OG_BAD_ARGS;
+        const long xb_floats = (bfb && !x_copy_in) ? (((long)N * H * W * Cpb / 2 + 3) & ~3L) : 0;
         const long dyb_floats = bfb ? (((long)N * Cout * OHW / 2 + 3) & ~3L) : 0;       // (OHW % 32 == 0: a multiple of 4)
         const __bf16* xb = nullptr;
         const __bf16* dyb = nullptr;
@@ -2917,12 +2932,13 @@ static int og_wgrad(const float* x, const float* dy, float* dw,
             if (plan_only) { *ws_need += xb_floats + dyb_floats; }
             else {
                 if (ws_floats < xb_floats + dyb_floats) return OG_BAD_ARGS;
-                hipLaunchKernelGGL(nchw_to_nhwc_bf16_kernel, dim3(og_cdiv(H * W, 64), og_cdiv(Cpb, 64), N), dim3(256), 0, s,
-                                   x, reinterpret_cast<__bf16*>(ws), Cin, H * W, Cpb);
+                if (!x_copy_in)
+                    hipLaunchKernelGGL(nchw_to_nhwc_bf16_kernel, dim3(og_cdiv(H * W, 64), og_cdiv(Cpb, 64), N), dim3(256), 0, s,
+                                       x, reinterpret_cast<__bf16*>(ws), Cin, H * W, Cpb);
                 const long n4 = (long)N * Cout * OHW / 4;
                 hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(og_stream_grid(n4, 256)), dim3(256), 0, s, dy,
                                    reinterpret_cast<__bf16*>(ws + xb_floats), n4);
-                xb = reinterpret_cast<const __bf16*>(ws);
+                xb = x_copy_in ? reinterpret_cast<const __bf16*>(x) : reinterpret_cast<const __bf16*>(ws);
                 dyb = reinterpret_cast<const __bf16*>(ws + xb_floats);
                 ws_used = xb_floats + dyb_floats;
             }
@@ -3170,6 +3186,33 @@ long objgan_conv_wgrad_ws_floats(int N, int Cin, int H, int W, int upsample, int
 int objgan_conv_wgrad_rec_ok(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ksize) {
     if (N <= 0 || Cin <= 0 || Cout <= 0 || OH <= 0 || OW <= 0) return 0;
     return og_wgrad_rec_geometry(N, Cin, H, W, Cout, OH, OW, ksize) ? 1 : 0;
+}
+
+// 1 if objgan_conv_wgrad takes math 3 (x as its bf16 channel-blocked copy) for this geometry.  Host-only.
+int objgan_conv_wgrad_bfb_ok(int N, int Cin, int H, int W, int Cout, int OH, int OW, int ksize) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || OH <= 0 || OW <= 0) return 0;
+    const long OHW = (long)OH * OW;
+    const long Cpb = ((long)Cin + 15) / 16 * 16;
+    const bool v2 = !og_igemm_v1() && (OW % 8 == 0) && (OHW % 16 == 0)
+                    && (double)N * Cin * H * W * 4.0 < 4.0e9 && (double)N * Cout * OHW * 4.0 < 4.0e9;
+    return (v2 && OHW % 32 == 0 && OH <= 256 && OW <= 256 && (long)(H - 1) * W < 65535 && ksize <= 4
+            && (ksize == 1 || ksize == 3 || ksize == 4) && (double)N * Cpb * H * W * 2.0 < 4.0e9) ? 1 : 0;
+}
+
+// The bf16 channel-blocked copy [N][Cp/16][HW][16] (RNE) of an fp32 [N][C][HW] tensor: what the bf16-mode kernels read
+// (math 3).  objgan_nhwc_bf16_floats: its size in floats (0: too large for the 32-bit buffer range -- use math 1).
+long objgan_nhwc_bf16_floats(int N, int C, long HW) {
+    const long Cp = ((long)C + 15) / 16 * 16;
+    if (N <= 0 || C <= 0 || HW <= 0 || (double)N * HW * Cp * 2.0 >= 4.0e9 || HW >= (1L << 31)) return 0;
+    return ((long)N * HW * Cp / 2 + 3) & ~3L;
+}
+int objgan_nhwc_bf16(const float* x, float* out, int N, int C, long HW, void* stream) {
+    OG_ENTRY();
+    if (!x || !out || objgan_nhwc_bf16_floats(N, C, HW) == 0) return OG_BAD_ARGS;
+    const int Cp = (C + 15) / 16 * 16;
+    hipLaunchKernelGGL(nchw_to_nhwc_bf16_kernel, dim3(og_cdiv(HW, 64), og_cdiv(Cp, 64), N), dim3(256), 0, (hipStream_t)stream,
+                       x, reinterpret_cast<__bf16*>(out), C, (int)HW, Cp);
+    return og_launch_status();
 }
 
 // dw [Cout][Cin][k][k] = (accumulate ? dw : 0) + sum dy * x.  ws: objgan_conv_wgrad_ws_floats(...) floats of scratch.

@@ -88,6 +88,8 @@ SIGNATURES = {
     "objgan_prof_enable": [_c_int],
     "objgan_conv_bank_layout": [_c_int] * 10,
     "objgan_conv_wgrad_rec_ok": [_c_int] * 8,
+    "objgan_conv_wgrad_bfb_ok": [_c_int] * 8,
+    "objgan_nhwc_bf16": [_ptr, _ptr, _c_int, _c_int, _c_long, _ptr],
     "objgan_prof_collect": [_ptr, _ptr, _ptr],
     "objgan_prof_dump": [_ptr, _ptr, _ptr, _c_int, _ptr],
 }
@@ -97,6 +99,7 @@ LONG_RETURN = {"objgan_conv_packed_floats": [_c_int, _c_int, _c_int],
                "objgan_conv_dgrad_s2_phases_ws_floats": [_c_int] * 5,
                "objgan_conv_dgrad_s2_thin_floats": [_c_int, _c_int],
                "objgan_h2_records_floats": [_c_int, _c_int, _c_long],
+               "objgan_nhwc_bf16_floats": [_c_int, _c_int, _c_long],
                "objgan_norm_ws_floats": [_c_int] * 4,
                "objgan_attn_general_backward_ws_floats": [_c_int] * 4,
                "objgan_masked_max_backward_ws_floats": [_c_int] * 4,

@@ -267,6 +267,35 @@ def _records(t, amax, N, C, HW, intensity=None, rows=0):
     return rec
 
 
+# bf16 mode (BASELINE config 5): the matrix kernels read their pixel operand from a bf16 channel-blocked copy.  Round 6: the
+# copy of a tensor is made ONCE (objgan_nhwc_bf16) and kept on the tensor object like its record -- the forward convolution
+# and the weight gradient of a layer, and every branch of an Inception block, read the same copy (math 3) instead of
+# writing their own into their workspace on every call (math 1: 32.9 of 216 ms per B = 32 step, 1 161 copy launches).
+_B16 = {"on": _os.environ.get("OBJGAN_BF16_COPY_CACHE", "1") != "0"}
+
+
+def _bf16_copy(t, N, C, HW):
+    """the bf16 channel-blocked copy of the contiguous fp32 tensor t [N, C, HW] (None: too large -- the call keeps math 1)"""
+    sid = torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    cache = getattr(t, "_og_b16", None)
+    if cache is not None:
+        got = cache.get(sid)
+        if got is not None and got[0] == t._version:
+            return got[1]
+    nfl = _q("objgan_nhwc_bf16_floats", N, C, HW)
+    if nfl <= 0 or (t.data_ptr() & 15):
+        return None
+    buf = torch.empty(nfl, dtype=_F32, device=t.device)
+    _lib.call("objgan_nhwc_bf16", _p(t), _p(buf), N, C, HW, _stream())
+    try:
+        if cache is None:
+            cache = t._og_b16 = {}
+        cache[sid] = (t._version, buf)
+    except (AttributeError, RuntimeError):
+        pass
+    return buf
+
+
 # Packed filter banks are kept while their weights are unchanged.  A weight tensor is eligible
 # when something vouches for its contents: either it carries `_og_epoch` (a one-element list owned
 # by its optimizer arena, bumped by every ArenaAdam.step -- the fused Adam kernel writes through a
@@ -501,6 +530,10 @@ def _igemm(x, w, bias, y, N, C, H, W, upsample, pad_mode, Cout, Cin, Torig, tran
         _census("data gradient: filter columns (input channels)" if transpose else "forward: filter rows (output channels)",
                 w, 1 if transpose else 0, site)
     kmath, xk = math, x
+    if math == 1 and _B16["on"] and _BF16_CHANNELS_LAST and (layout & 255) == 3:
+        xc = _bf16_copy(x, N, C, H * W)
+        if xc is not None:
+            kmath, xk = 3, xc
     if math == 4 and _REC["on"] and not (x.data_ptr() & 15):
         # same arithmetic, same bank; the pixel operand as its fp16 record where that pays
         rec = _records(x, xmax, N, C, H * W, 2.0 * M * Tg * PH * PW / float(H * W), M)
@@ -778,6 +811,12 @@ def _conv_wgrad(x, g, Cout, k, stride, pad, refl, upsample, sink=None):
         if rec is not None:
             geo = geo[:-1] + (_REC["wgrad_math"],)      # 6: dy pre-split too (its fp16 pair, one pass into the workspace); 5: split in the loop
             xk = rec
+    if (math == 1 and _B16["on"] and _BF16_CHANNELS_LAST
+            and _q("objgan_conv_wgrad_bfb_ok", N, Cin, H, W, Cout, g.shape[2], g.shape[3], k)):
+        xc = _bf16_copy(x, N, Cin, H * W)            # (usually the copy the forward convolution of this layer made)
+        if xc is not None:
+            geo = geo[:-1] + (3,)
+            xk = xc
     nws = _q("objgan_conv_wgrad_ws_floats", *geo)
     side = _WG_ASYNC["stream"] if (sink is not None and _H2_CENSUS is None) else None
     if side is not None:
