@@ -748,16 +748,25 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackArg
 
 // out[e] = act(bias[(e / HW) % M] + sum_{s < splits} ws[s * ws_stride + seg_off + e]): the second level of split-K
 // (conv_igemm3_kernel writes the partial tiles), splits summed in order.
+// ymax (may be null; zeroed by the caller): the partial maxima of |out| for an fp16x2 consumer, added with one integer
+// atomicMax per workgroup -- round 6: this was a separate pass over the output behind every split launch with a fused
+// ReLU / LeakyReLU (the Inception chain's small maps).
 __global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __restrict__ ws, int splits, long ws_stride,
                                                              long seg_off, float* __restrict__ out, long total,
-                                                             const float* __restrict__ bias, int M, int HW, int act) {
+                                                             const float* __restrict__ bias, int M, int HW, int act,
+                                                             float* __restrict__ ymax) {
+    __shared__ float red[4];
+    float vmax = 0.f;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const float* p = ws + seg_off + e;
         float v = p[0];
         for (int k = 1; k < splits; ++k) v += p[(size_t)k * ws_stride];
         if (bias) v += bias[(e / HW) % M];
-        out[e] = og_act(v, act);
+        v = og_act(v, act);
+        out[e] = v;
+        vmax = fmaxf(vmax, fabsf(v));
     }
+    if (ymax) og_amax_atomic(og_block_max(vmax, red), ymax, blockIdx.x);
 }
 
 // dw rows <- sum over the splits of a weight-gradient launch (WgradArgs::ws): local row r of the slot is dw row
@@ -2407,12 +2416,14 @@ static int run_igemm2(IgemmArgs a, hipStream_t s, int y_prezeroed, float* ws, lo
         if (rc != OG_OK) return rc;
     }
     if (a.ws) {         // second level: sum the splits in order, + bias, activation
+        // (the maxima of y ride in the combine unless a later pass changes y: tanh / sigmoid heads, ring mode)
+        const bool ymax_in_combine = ymax && !act_later && ring_elems == 0;
         hipLaunchKernelGGL(splitk_combine_kernel, dim3(og_stream_grid(y_elems, 256)), dim3(256), 0, s, a.ws, splits,
-                           a.ws_stride, 0L, a.y, y_elems, bias, a.M, a.OHf * a.OWf, act);
+                           a.ws_stride, 0L, a.y, y_elems, bias, a.M, a.OHf * a.OWf, act, ymax_in_combine ? ymax : (float*)nullptr);
         if (ring_elems > 0)
             hipLaunchKernelGGL(splitk_combine_kernel, dim3(og_stream_grid(ring_elems, 256)), dim3(256), 0, s, a.ws, splits,
-                               a.ws_stride, y_elems, a.ring, ring_elems, (const float*)nullptr, 1, 1, OG_ACT_NONE);
-        if (ymax) og_absmax_launch(a.y, y_elems, ymax, s);
+                               a.ws_stride, y_elems, a.ring, ring_elems, (const float*)nullptr, 1, 1, OG_ACT_NONE, (float*)nullptr);
+        if (ymax && !ymax_in_combine) og_absmax_launch(a.y, y_elems, ymax, s);
         return og_launch_status();
     }
     if ((splits > 1 || act_later) && (bias || act != OG_ACT_NONE) && full_cover) {
