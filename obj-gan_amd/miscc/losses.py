@@ -166,14 +166,14 @@ def patD_loss(netPatD, real_imgs, fake_imgs, conditions, real=None):
     return (cond_real + (cond_fake + cond_wrong) / 2.) * lam_t
 
 
-def shpD_loss(netShpD, real_imgs, fake_imgs, seg_conditions, rois, num_rois, real=None):
+def shpD_loss(netShpD, real_imgs, fake_imgs, seg_conditions, rois, num_rois, real=None, draw=None):
     net = _net(netShpD)
     # the encoded layout map is the same tensor in the real and the fake pass: evaluate it once
     if real is None:
         real = shpD_real(netShpD, real_imgs, seg_conditions)
     s_code, real_features = real["s_code"], real["real_features"]
     fake_features = netShpD(fake_imgs.detach(), seg_conditions, s_code=s_code)
-    wrong_seg, valid = permuted_valid_seg(seg_conditions, rois, num_rois)
+    wrong_seg, valid = permuted_valid_seg(seg_conditions, rois, num_rois, draw=draw)
     errD = _bce(net.UNCOND_DNET(real_features), 1)
     fake_err = _bce(net.UNCOND_DNET(fake_features), 0)
     if len(valid) > 0:
@@ -195,7 +195,7 @@ def _obj_conditions(class_table, classes, bt_c_codes, count=None):
 
 
 def objD_loss(netObjD, real_imgs, fake_imgs, seg_conditions, raw_conditions, raw_bt_c_codes,
-              fm_rois, num_rois, is_large_scale=False, real=None):
+              fm_rois, num_rois, is_large_scale=False, real=None, draw=None):
     net = _net(netObjD)
     if real is None:
         real = objD_real(netObjD, real_imgs, seg_conditions, fm_rois, num_rois)
@@ -205,7 +205,7 @@ def objD_loss(netObjD, real_imgs, fake_imgs, seg_conditions, raw_conditions, raw
     fake_pooled = netObjD(fake_imgs.detach(), seg_conditions, fm_rois, num_rois, s_code=s_code)
     fake_features, _, _ = feat_select(fake_pooled, raw_bt_c_codes, fm_rois, num_rois,
                                       is_large_scale=is_large_scale)
-    wrong_seg, valid = permuted_valid_seg(seg_conditions, fm_rois, num_rois)
+    wrong_seg, valid = permuted_valid_seg(seg_conditions, fm_rois, num_rois, draw=draw)
     classes2 = []
     if len(valid) > 0:
         rois_v, num_v = take_rows(fm_rois, valid), take_rows(num_rois, valid)      # host copies stay attached

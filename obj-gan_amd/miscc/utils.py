@@ -140,11 +140,20 @@ def permute_seg(seg_conditions, rois, num_rois):
     return new_seg, valid_mask
 
 
-def permuted_valid_seg(seg_conditions, rois, num_rois):
+def draw_class_permutations(seg_conditions, rois, num_rois):
+    """The RANDOM part of permuted_valid_seg on its own (host only: python's `random` + the host copies of the box tables).
+    The trainer draws the permutations of all five users of a step up front, in the reference's order (reference
+    trainer.py:398-443 calls the losses in that order), and hands them to the losses through `draw=`: the ORDER IN WHICH THE
+    HOST ISSUES the discriminator jobs is then free of the RNG sequence."""
+    return _class_permutations(seg_conditions.size(1), rois, num_rois)
+
+
+def permuted_valid_seg(seg_conditions, rois, num_rois, draw=None):
     """(permuted layout maps of the CHANGED samples only [len(valid), C, H, W], valid_mask): what the
-    discriminator losses consume -- permute_seg(...)[0][valid_mask] without building the unchanged rows."""
+    discriminator losses consume -- permute_seg(...)[0][valid_mask] without building the unchanged rows.
+    draw: the (perm, valid_mask) pair of draw_class_permutations for these arguments (None: drawn here)."""
     C = seg_conditions.size(1)
-    perm, valid_mask = _class_permutations(C, rois, num_rois)
+    perm, valid_mask = draw if draw is not None else _class_permutations(C, rois, num_rois)
     if not valid_mask:
         return None, valid_mask
     dev = seg_conditions.device

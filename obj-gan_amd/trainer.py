@@ -29,7 +29,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from miscc.config import cfg
-from miscc.utils import (mkdir_p, weights_init, form_clabels_feat, _host, compute_inception_score,
+from miscc.utils import (mkdir_p, weights_init, form_clabels_feat, _host, compute_inception_score, draw_class_permutations,
                          negative_log_posterior_probability)
 from miscc.losses import patD_loss, shpD_loss, objD_loss, G_loss, KL_loss, patD_real, shpD_real, objD_real
 import model as M
@@ -270,7 +270,7 @@ def _dist_on():
 # ---------------------------------------------------------------------------------------------
 # trainer
 # ---------------------------------------------------------------------------------------------
-def resolve_d_job_order(job_names, order):
+def resolve_d_job_order(job_names, order, rng_free=False):
     """The issue order of the discriminator jobs of one step under a `d_job_order` / OBJGAN_D_ORDER request: the listed jobs
     first, the rest behind them in the reference order (reference trainer.py:398-443).  Every job but the patch
     discriminators draws from the python RNG (permute_seg, miscc/utils.py), so the FINAL order must keep those jobs in the
@@ -283,7 +283,8 @@ def resolve_d_job_order(job_names, order):
                          % (unknown or order, list(job_names)))
     final = order + [n for n in job_names if n not in order]
     ref = [n for n in job_names if not n.startswith("errPatD")]
-    if [n for n in final if not n.startswith("errPatD")] != ref:
+    # rng_free: the permutations were drawn up front in the reference order (train_step) -- any issue order is safe
+    if not rng_free and [n for n in final if not n.startswith("errPatD")] != ref:
         raise ValueError("d_job_order moves a job that draws random numbers out of the reference order: %s "
                          "(issue order would be %s)" % (order, final))
     return final
@@ -517,6 +518,7 @@ class condGANTrainer(object):
     # sequence of the shape / object discriminators' permute_seg (which stay in the reference's relative order); the
     # networks are independent, so the results do not depend on the order.  OBJGAN_D_ORDER="errPatD2,..." overrides.
     d_job_order = None
+    predraw_permutations = True
 
     @classmethod
     def _stream_map_from_env(cls):
@@ -683,6 +685,16 @@ class condGANTrainer(object):
         # (3) the eight discriminator updates (reference trainer.py:398-443).  They are independent of
         # each other (own weights, the real batch, the detached fake images): the host issues them in the
         # reference's order, each on one of the side streams (`d_stream_map`, below).
+        # The five users of the python RNG (permute_seg of the shape / object discriminators) get their class permutations
+        # NOW, in the reference's order: the permutations are host work on the box tables and nothing else, so the order in
+        # which the host issues the eight jobs below no longer has to follow the reference's (heaviest streams first).
+        draws = {}
+        if self.predraw_permutations:
+            for i in range(len(self.optimizersShpD)):
+                draws["errShpD%d" % i] = draw_class_permutations(hmaps[i], rois[i], num_rois)
+            if self.use_obj:
+                draws["errObjSSD"] = draw_class_permutations(hmaps[-1], rois[0], num_rois)
+                draws["errObjLSD"] = draw_class_permutations(hmaps[-1], fm_rois, num_rois)
         jobs = []
         for i, opt in enumerate(self.optimizersPatD):
             jobs.append(("errPatD%d" % i, opt,
@@ -690,16 +702,17 @@ class condGANTrainer(object):
         for i, opt in enumerate(self.optimizersShpD):
             jobs.append(("errShpD%d" % i, opt,
                          lambda real=None, i=i: shpD_loss(self.netsShpD[i], imgs[i], fake_imgs[i], hmaps[i], rois[i], num_rois,
-                                                          real=real)))
+                                                          real=real, draw=draws.get("errShpD%d" % i))))
         # the reference updates an object discriminator only `if float(err) > 0`, i.e. when at least one
         # box of the wanted scale exists (BCE of a sigmoid is > 0 otherwise)
         obj_jobs = (("errObjSSD", self.netObjSSD, self.optimizerObjSSD, rois[0], False),
                     ("errObjLSD", self.netObjLSD, self.optimizerObjLSD, fm_rois, True)) if self.use_obj else ()
         for name, net, opt, r, large in obj_jobs:
             jobs.append((name, opt,
-                         lambda real=None, net=net, r=r, large=large: objD_loss(net, imgs[-1], fake_imgs[-1], hmaps[-1],
+                         lambda real=None, net=net, r=r, large=large, name=name: objD_loss(net, imgs[-1], fake_imgs[-1], hmaps[-1],
                                                                                 clabels_emb, bt_c_codes[-1], r, num_rois,
-                                                                                is_large_scale=large, real=real)))
+                                                                                is_large_scale=large, real=real,
+                                                                                draw=draws.get(name))))
         # The eight discriminator updates read the same fake images and touch disjoint networks: they are spread
         # round-robin over `d_streams` HIP streams so that the many launches that do not fill 256 CUs on their own
         # (discriminator heads on 4x4 .. 16x16 maps, normalisation / combine kernels of small layers) overlap with
@@ -709,7 +722,7 @@ class condGANTrainer(object):
                  else self.d_job_order)
         if order:
             by_name = dict((j[0], j) for j in jobs)
-            jobs = [by_name[n] for n in resolve_d_job_order([j[0] for j in jobs], order)]
+            jobs = [by_name[n] for n in resolve_d_job_order([j[0] for j in jobs], order, rng_free=bool(draws))]
         pending = []
         for s_ in side:
             s_.wait_stream(main)
