@@ -90,31 +90,54 @@ struct LdsHuff {
     unsigned char vals[256];
 };
 
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+
 struct BitReader {
     const unsigned char* file;         // global
-    unsigned char* win;                // this lane's LDS window: file[wbase .. wbase + OG_WIN)
+    lds_u8* win;                       // this lane's LDS window: file[wbase .. wbase + OG_WIN) (LDS address space: ds_read, not flat)
     long wbase, nbytes, pos;           // pos: next byte of the file to read
     unsigned long long acc;
     int nbits;
     bool marker;                       // a marker was reached: the rest of the segment reads as zeros (jdhuff.c)
 };
 
+// make file[p .. p + need) resident in the lane's window (need <= 8)
+__device__ __forceinline__ void br_window(BitReader& b, long p, int need) {
+    if (p >= b.wbase && p + need <= b.wbase + OG_WIN) return;
+    b.wbase = p & ~15L;
+#pragma unroll
+    for (int i = 0; i < OG_WIN; i += 16) {
+        uint4 v = {0xD9D9D9D9u, 0xD9D9D9D9u, 0xD9D9D9D9u, 0xD9D9D9D9u};
+        // (whole 16-byte pieces inside the batch buffer: files start on 16-byte boundaries and the buffer is padded)
+        if (b.wbase + i < ((b.nbytes + 15) & ~15L)) v = *reinterpret_cast<const uint4*>(b.file + b.wbase + i);
+        lds_u32* w = (lds_u32*)(b.win + i);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    }
+}
+
 __device__ __forceinline__ unsigned br_byte(BitReader& b, long p) {
     if (p >= b.nbytes) return 0xD9u;
-    if (p < b.wbase || p >= b.wbase + OG_WIN) {             // refill: the 16-byte aligned window that starts at p
-        b.wbase = p & ~15L;
-#pragma unroll
-        for (int i = 0; i < OG_WIN; i += 16) {
-            uint4 v = {0xD9D9D9D9u, 0xD9D9D9D9u, 0xD9D9D9D9u, 0xD9D9D9D9u};
-            // (whole 16-byte pieces inside the batch buffer: files start on 16-byte boundaries and the buffer is padded)
-            if (b.wbase + i < ((b.nbytes + 15) & ~15L)) v = *reinterpret_cast<const uint4*>(b.file + b.wbase + i);
-            *reinterpret_cast<uint4*>(b.win + i) = v;
-        }
-    }
+    br_window(b, p, 1);
     return b.win[p - b.wbase];
 }
 
 __device__ __forceinline__ void br_fill(BitReader& b) {
+    // fast path: four bytes at once when none of them is 0xFF (no stuffing, no marker) -- two aligned LDS dwords, one byte
+    // alignment, one byte swap instead of four byte loads with their checks
+    if (!b.marker && b.nbits <= 31 && b.pos + 4 <= b.nbytes) {
+        br_window(b, b.pos, 8);
+        const int off = (int)(b.pos - b.wbase);
+        lds_u32* w = (lds_u32*)(b.win + (off & ~3));
+        const unsigned v = __builtin_amdgcn_alignbyte(w[1], w[0], off & 3);     // bytes pos .. pos + 3, first byte lowest
+        const unsigned inv = ~v;
+        if (((inv - 0x01010101u) & ~inv & 0x80808080u) == 0) {                   // no byte equals 0xFF
+            b.acc = (b.acc << 32) | __builtin_bswap32(v);
+            b.nbits += 32;
+            b.pos += 4;
+            return;
+        }
+    }
     while (b.nbits <= 48) {
         unsigned v = 0;
         if (!b.marker) {
@@ -223,7 +246,7 @@ __global__ __launch_bounds__(64) void jpeg_entropy_kernel(const unsigned char* _
     const int sg = (int)blockIdx.y * OG_JPEG_LPW + lane;
     if (lane < OG_JPEG_LPW && sg < nseg) {
         BitReader br;
-        br.file = file; br.win = wins + lane * OG_WIN; br.wbase = -OG_WIN; br.nbytes = d.nbytes;
+        br.file = file; br.win = (lds_u8*)(wins + lane * OG_WIN); br.wbase = -OG_WIN; br.nbytes = d.nbytes;
         int pred[OG_JPEG_MAXC] = {0, 0, 0};
         int mcu, mcu_end, todo;
         if (d.nseg > 0) {
