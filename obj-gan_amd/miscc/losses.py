@@ -252,7 +252,7 @@ def _obj_g_term(netObjD, fake_img, seg, slabels_emb, raw_bt_c_codes, rois, num_r
 
 def G_loss(netsPatD, netsShpD, netObjSSD, netObjLSD, image_encoder, fake_imgs, seg_conditions,
            words_embs, sent_emb, slabels_emb, raw_bt_c_codes, match_labels, cap_lens, class_ids,
-           rois, fm_rois, num_rois, quiet=False, use_obj=True, streams=None):
+           rois, fm_rois, num_rois, quiet=False, use_obj=True, streams=None, damsm_pre=None):
     """quiet=True skips the log string, the DAMSM accuracies and attention maps (every `.item()` / `.cpu()` in
     them is a device->host sync).
     streams (quiet only): HIP streams the nine terms -- DAMSM first, then the discriminators in the order below --
@@ -264,7 +264,7 @@ def G_loss(netsPatD, netsShpD, netObjSSD, netObjLSD, image_encoder, fake_imgs, s
     if streams and quiet:
         return _g_loss_streams(netsPatD, netsShpD, netObjSSD, netObjLSD, image_encoder, fake_imgs, seg_conditions,
                                words_embs, sent_emb, slabels_emb, raw_bt_c_codes, match_labels, cap_lens, class_ids,
-                               rois, fm_rois, num_rois, use_obj, streams), ''
+                               rois, fm_rois, num_rois, use_obj, streams, damsm_pre=damsm_pre), ''
     numDs = len(netsPatD)
     batch_size = fake_imgs[0].size(0)
     logs = ''
@@ -315,10 +315,24 @@ def G_loss(netsPatD, netsShpD, netObjSSD, netObjLSD, image_encoder, fake_imgs, s
     return errG_total, logs
 
 
+def damsm_term(image_encoder, fake_img, words_embs, sent_emb, match_labels, cap_lens, class_ids):
+    """the DAMSM term of G_loss on the last stage's image -> (word part, sentence part), both x DAMSM_LAMBDA
+    (reference miscc/losses.py:421-432)"""
+    batch_size = fake_img.size(0)
+    region_features, cnn_code = image_encoder(fake_img)
+    w0, w1, _, _ = words_loss(region_features, words_embs, match_labels, cap_lens, class_ids, batch_size,
+                              top1=False, need_att_maps=False)
+    s0, s1, _ = sent_loss(cnn_code, sent_emb, match_labels, class_ids, batch_size, top1=False)
+    lam = cfg.TRAIN.SMOOTH.DAMSM_LAMBDA
+    return (w0 + w1) * lam, (s0 + s1) * lam
+
+
 def _g_loss_streams(netsPatD, netsShpD, netObjSSD, netObjLSD, image_encoder, fake_imgs, seg_conditions,
                     words_embs, sent_emb, slabels_emb, raw_bt_c_codes, match_labels, cap_lens, class_ids,
-                    rois, fm_rois, num_rois, use_obj, streams):
-    """The terms of G_loss (same arithmetic, same summation order) issued round-robin on `streams`."""
+                    rois, fm_rois, num_rois, use_obj, streams, damsm_pre=None):
+    """The terms of G_loss (same arithmetic, same summation order) issued round-robin on `streams`.
+    damsm_pre = (terms, stream): the DAMSM term was already issued on `stream` (trainer: beside the discriminator
+    updates, it does not depend on them); this function joins that stream instead of computing the term."""
     numDs = len(netsPatD)
     batch_size = fake_imgs[0].size(0)
     sm = cfg.TRAIN.SMOOTH
@@ -328,11 +342,7 @@ def _g_loss_streams(netsPatD, netsShpD, netObjSSD, netObjLSD, image_encoder, fak
     jobs = []
 
     def damsm():
-        region_features, cnn_code = image_encoder(fake_imgs[numDs - 1])
-        w0, w1, _, _ = words_loss(region_features, words_embs, match_labels, cap_lens, class_ids, batch_size,
-                                  top1=False, need_att_maps=False)
-        s0, s1, _ = sent_loss(cnn_code, sent_emb, match_labels, class_ids, batch_size, top1=False)
-        return (w0 + w1) * sm.DAMSM_LAMBDA, (s0 + s1) * sm.DAMSM_LAMBDA
+        return damsm_term(image_encoder, fake_imgs[numDs - 1], words_embs, sent_emb, match_labels, cap_lens, class_ids)
 
     def pat(i):
         p = _net(netsPatD[i])
@@ -346,7 +356,8 @@ def _g_loss_streams(netsPatD, netsShpD, netObjSSD, netObjLSD, image_encoder, fak
         n = _net(netsShpD[i])
         return _bce(n.UNCOND_DNET(netsShpD[i](fake_imgs[i], seg_conditions[i])), 1) * sm.SHP_LAMBDA
 
-    order = [("damsm", damsm)]                    # the longest chain of small launches first: it overlaps everything
+    # the longest chain of small launches first: it overlaps everything
+    order = [("damsm", damsm)] if damsm_pre is None else []
     for i in range(numDs):
         order += [("pat%d" % i, lambda i=i: pat(i)), ("shp%d" % i, lambda i=i: shp(i))]
     if use_obj:
@@ -355,11 +366,15 @@ def _g_loss_streams(netsPatD, netsShpD, netObjSSD, netObjLSD, image_encoder, fak
                   ("objls", lambda: _obj_g_term(netObjLSD, fake_imgs[-1], seg_conditions[-1], slabels_emb,
                                                 raw_bt_c_codes, fm_rois, num_rois, True))]
     terms = {}
+    if damsm_pre is not None:
+        terms["damsm"] = damsm_pre[0]
     for j, (name, fn) in enumerate(order):
         with torch.cuda.stream(streams[j % len(streams)]):
             terms[name] = fn()
     for s_ in streams:
         main.wait_stream(s_)
+    if damsm_pre is not None:
+        main.wait_stream(damsm_pre[1])
     # the reference's summation order: pat_i, shp_i (i ascending), DAMSM after the last pair, then the object terms
     total = 0
     for i in range(numDs):

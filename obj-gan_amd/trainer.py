@@ -473,6 +473,11 @@ class condGANTrainer(object):
     # weight gradients of the generator's backward pass on a side stream (OBJGAN_ASYNC_WGRAD=0: on the issuing stream)
     async_wgrad = os.environ.get("OBJGAN_ASYNC_WGRAD", "1") != "0"
 
+    # the DAMSM term of the generator loss (frozen Inception encoder on the fake image: ~330 small launches, one graph
+    # replay) does not depend on the discriminator updates: issue it on its own stream right after the generator's
+    # forward pass, beside them.  Same kernels, same autograd sequence (it was already the first term of G_loss):
+    # bit-identical steps (tests/test_modules_gpu.py).  OFF: measured 3-4 ms per step SLOWER in steady state (LAB 10.9).
+    early_damsm = os.environ.get("OBJGAN_EARLY_DAMSM", "0") == "1"
     async_wgrad_d = os.environ.get("OBJGAN_ASYNC_WGRAD_D", "0") == "1"     # the same inside the discriminator updates (A/B: see LAB)
 
     def _wgrad_side_stream(self, k=0):
@@ -681,6 +686,16 @@ class condGANTrainer(object):
             fm_rois, num_rois, b["bt_masks"], b["fm_bt_masks"], glb_max_num_roi)
         self._phase("g_forward")
         bt_c_codes = [c.detach() for c in bt_c_codes]
+        self._damsm_pre = None
+        if side and self.early_damsm and not want_logs:
+            import miscc.losses as L
+            st = self.__dict__.get("_damsm_stream")
+            if st is None:
+                st = self._damsm_stream = torch.cuda.Stream(device=self.device)
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                self._damsm_pre = (L.damsm_term(self._graphed("image_encoder"), fake_imgs[-1], words_embs, sent_emb,
+                                                self.match_labels, b["cap_lens"], b["class_ids"]), st)
 
         # (3) the eight discriminator updates (reference trainer.py:398-443).  They are independent of
         # each other (own weights, the real batch, the detached fake images): the host issues them in the
@@ -939,5 +954,6 @@ def _g_loss_quiet(tr, fake_imgs, hmaps, words_embs, sent_emb, clabels_emb, bt_c,
     total, _ = L.G_loss(tr.netsPatD, tr.netsShpD, tr.netObjSSD, tr.netObjLSD, tr._graphed("image_encoder"),
                         fake_imgs, hmaps, words_embs, sent_emb, clabels_emb, bt_c, tr.match_labels,
                         b["cap_lens"], b["class_ids"], rois[0], fm_rois, num_rois, quiet=True,
-                        use_obj=tr.use_obj, streams=tr._d_side_streams() or None)
+                        use_obj=tr.use_obj, streams=tr._d_side_streams() or None,
+                        damsm_pre=tr.__dict__.pop("_damsm_pre", None))
     return total, ''
