@@ -589,7 +589,7 @@ def main():
     jpeg_info = None
     if args.jpeg_input:
         # the loader side of the reference step (miscc/load.py:141-151: PIL decode + three PIL resizes per sample) on the
-        # device: files -> jpeg_decode_batch -> resize_pil_bilinear_device, on a side stream while the previous step trains
+        # device: files -> jpeg_decode_batch -> resize_pil_bilinear_device, issued one step ahead
         import io
         import numpy as np
         from PIL import Image
@@ -609,14 +609,19 @@ def main():
         jpeg_info = {"files_per_step": args.batch, "bytes_per_step_and_gpu": int(sum(len(f) for f in jfiles) / nb),
                      "image_size": "480x640, 4:2:0, quality 90"}
 
+        # the decode of the NEXT batch is issued on the step's own stream ahead of the step (4.2 ms of device time per batch of
+        # 16): on a side stream (OBJGAN_JPEG_INLINE=0) it is an eleventh stream on a device-bound step and costs 2.5 ms more
+        # (135.5 against 138.0 ms per step, 129.4 without JPEG input: profiles/r06_ab_variants.txt m)
+        jinline = os.environ.get("OBJGAN_JPEG_INLINE", "1") == "1"
+
         def jload(i):
             k = i % nb
-            with torch.cuda.stream(jstream):
+            with torch.cuda.stream(torch.cuda.current_stream() if jinline else jstream):
                 fs = jfiles[k * args.batch:(k + 1) * args.batch]
                 src, offs, hs, ws_ = ops.jpeg_decode_batch(fs, device, jcache, [(k, j) for j in range(args.batch)])
                 imgs = ops.resize_pil_bilinear_device(src, offs, hs, ws_, sizes)
                 ev = torch.cuda.Event()
-                ev.record(jstream)
+                ev.record(torch.cuda.current_stream())
             jready[k] = (imgs, ev)
         for k_ in range(nb):                # "epoch 1": every file decoded once by one lane, its entropy index cached on the device
             jload(k_)
@@ -624,12 +629,28 @@ def main():
         jpeg_info["first_pass_index_misses"] = jcache.misses
         jload(0)
 
+    def fresh(b):
+        # The synthetic batches stay resident in HBM across steps, but nothing DERIVED from them may: objgan_hip.ops keeps the
+        # |x| maxima / fp16 records of a tensor on the tensor OBJECT, and a training loop gets new tensors from its loader every
+        # step.  Hand train_step new tensor objects over the same storage (detach(): no copy), so every step pays those passes.
+        def f(v):
+            if torch.is_tensor(v):
+                d = v.detach()
+                h = getattr(v, "_og_host", None)      # (the loader's own host copy of the box tables travels with the batch)
+                if h is not None:
+                    d._og_host = h
+                return d
+            if isinstance(v, (list, tuple)):
+                return type(v)(f(x) for x in v)
+            return v
+        return dict((k_, f(v)) for k_, v in b.items())
+
     def step():
         if args.jpeg_input:
             k = it[0] % nb
             imgs, ev = jready[k]
             torch.cuda.current_stream().wait_event(ev)
-            b_ = dict(batches[k])
+            b_ = fresh(batches[k])
             b_["imgs"] = imgs
             for t_ in imgs:
                 t_.record_stream(torch.cuda.current_stream())
@@ -646,7 +667,7 @@ def main():
             ev.record()                   # (train_step has joined its side streams into this one when it returns)
             free[k] = ev
         else:
-            out = tr.train_step(batches[it[0] % nb])
+            out = tr.train_step(batches[it[0] % nb] if os.environ.get("OBJGAN_BENCH_KEEP_DERIVED") == "1" else fresh(batches[it[0] % nb]))
         it[0] += 1
         return out
 
