@@ -8,4 +8,4 @@ hipcc --offload-arch=gfx950 -O2 tools/pmc_calib.cpp -o tools/pmc_calib 2>/dev/nu
 bash tools/pmc_bench.sh ${TAG} > gpurun_out/${TAG}_pmc.log 2>&1; tail -8 gpurun_out/${TAG}_pmc_traffic.log | cut -c1-200
 cp gpurun_out/${TAG}_pmc_traffic.json profiles/pmc_traffic.json
 ( time timeout 1700 python bench.py --steps 20 --warmup 5 --shape-table gpurun_out/${TAG}_conv_shapes.txt ) > gpurun_out/${TAG}_benchfull.log 2> gpurun_out/${TAG}_benchfull.err; tail -1 gpurun_out/${TAG}_benchfull.log | cut -c1-700
-bash tools/r6_profiles.sh ${TAG} 2>&1 | tail -6
+bash tools/profile_round.sh ${TAG} 2>&1 | tail -6
