@@ -1,5 +1,6 @@
-"""device time of the four-phase thin data gradient (objgan_conv_dgrad_s2_thin) on the discriminator stems; checks variants bit for bit
-against the default kernel (OG_THIN_VARIANT is read once per process: run once per variant, compare through a saved tensor)"""
+"""device time of the four-phase thin data gradient (objgan_conv_dgrad_s2_thin) on the discriminator stems.  OG_THIN_VARIANT selected
+kernel variants in a development build (LAB 10.10: none faster; the library ignores it now); a run with the variable set compares its
+output bit for bit with the tensor a variant-0 run saved."""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "obj-gan_amd"))
 from objgan_hip import _lib
